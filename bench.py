@@ -1,0 +1,382 @@
+#!/usr/bin/env python3
+"""bench.py — DuoAttention split-head attention hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): Llama-3-8B shape (32 layers, 32 q heads, 8 kv heads, D=128),
+50 % streaming kv heads (per-layer retrieval-head counts of the shipped
+Llama-3-8B-Instruct-Gradient-1048k pattern, seed 42, sparsity 0.5), sink 128 + recent 256,
+bf16, B=1:  chunked prefill of a 131072-token context, then 128 single-token decode steps at that
+context length (the reference's protocol, eval/efficiency/benchmark_static.py:68-105: decode steps
+are followed by kv_cache.evict_last(1), so every step runs at the full context).
+
+One "step" = one whole job = for every layer: RoPE -> KV append -> split-head attention ->
+streaming-pool update, for every prefill chunk and every decode token.  Inputs are synthetic
+N(0,1) bf16 q/k/v already resident in HBM (the q/k/v projections and MLP are hipBLASLt GEMMs
+outside the path).  `value` = (prefill tokens + decode tokens) / job time; prefill tok/s and
+decode tok/s are reported next to it, as is the same job with every head a retrieval head
+("full attention").
+
+Multi-GPU (--gpus N under torch.distributed.run): the 32 layers are sharded contiguously over
+N ranks (strong scaling), prefill chunks are pipelined through the stages with RCCL send/recv of
+the [1, C, 4096] hidden state; decode is sequential through the stages.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "duo-attention_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# retrieval ("full") kv heads per layer: attn_patterns/Llama-3-8B-Instruct-Gradient-1048k,
+# seed_everything(42) + sparsify_attention_heads(sparsity=0.5)  (tests/golden/make_golden.py)
+LLAMA3_8B_FULL_KV_HEADS = [1, 1, 2, 2, 2, 4, 2, 4, 6, 4, 5, 3, 2, 6, 5, 5, 5, 6, 3, 5, 6, 3, 3, 6, 4, 5, 3, 4, 6, 5, 8, 2]
+HQ, HKV, D, HIDDEN = 32, 8, 128, 4096
+SINK, RECENT = 128, 256
+ROPE_THETA, ROPE_SCALE = 3580165449.0, 1.0
+HBM_PEAK = 8.0e12       # B/s, MI355X_MICROARCH.md
+MFMA_BF16_PEAK = 2.5e15  # FLOP/s dense
+
+
+class _ShapeModel:
+    def __init__(self, n_layers, device):
+        import types
+
+        self.config = types.SimpleNamespace(num_hidden_layers=n_layers, num_attention_heads=HQ,
+                                            num_key_value_heads=HKV, hidden_size=HQ * D)
+        self._p = torch.zeros(1, device=device, dtype=torch.bfloat16)
+
+    def parameters(self):
+        yield self._p
+
+
+def decode_bytes(counts, N, W=SINK + RECENT):
+    """algorithmic K+V bytes one decode token reads, per layer."""
+    return [(nf * (N + 1) + (HKV - nf) * min(N + 1, W + 1)) * 2 * D * 2 for nf in counts]
+
+
+def prefill_flops(counts, N, C, W=SINK + RECENT):
+    """algorithmic attention FLOPs of a chunked prefill, per (chunk, layer)."""
+    G = HQ // HKV
+    out = []
+    for s in range(0, N, C):
+        c = min(C, N - s)
+        row = []
+        for nf in counts:
+            tri = c * (c + 1) / 2
+            f_full = 4 * D * (c * s + tri)
+            f_str = 4 * D * (c * (min(s, W) if s > 0 else 0) + tri)
+            row.append(G * (nf * f_full + (HKV - nf) * f_str) if s > 0 else G * HKV * f_full)
+        out.append(row)
+    return out
+
+
+class HotPath:
+    """The per-rank state of one job configuration (duo or full attention)."""
+
+    def __init__(self, counts, layer_range, ctx, chunk, device):
+        from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+        self.l0, self.l1 = layer_range
+        self.counts = counts[self.l0:self.l1]
+        self.ctx, self.chunk, self.device = ctx, chunk, device
+        heads = [[1.0] * nf + [0.0] * (HKV - nf) for nf in self.counts]
+        self.cache = DuoAttentionStaticKVCache(_ShapeModel(len(self.counts), device), heads, 1, ctx + 5,
+                                               SINK, RECENT)
+        g = torch.Generator(device=device).manual_seed(1234)
+        mk = lambda s, h: torch.randn(1, s, h, D, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+        self.q_c, self.k_c, self.v_c = mk(chunk, HQ), mk(chunk, HKV), mk(chunk, HKV)
+        self.q_1, self.k_1, self.v_1 = mk(1, HQ), mk(1, HKV), mk(1, HKV)
+        self.hidden_c = torch.zeros(1, chunk, HIDDEN, device=device, dtype=torch.bfloat16)
+        self.hidden_1 = torch.zeros(1, 1, HIDDEN, device=device, dtype=torch.bfloat16)
+        self.chunks = [(s, min(chunk, ctx - s)) for s in range(0, ctx, chunk)]
+
+    def free(self):
+        self.cache = None
+        torch.cuda.empty_cache()
+
+    def layer_core(self, li, S, pos0, q, k, v):
+        from duo_attn.patch._duo import duo_static_attention_core
+
+        return duo_static_attention_core(q[:, :S], k[:, :S], v[:, :S], self.cache, li, pos0, ROPE_SCALE, ROPE_THETA)
+
+    def prefill_stage(self, i, x):
+        s, c = self.chunks[i]
+        for li in range(len(self.counts)):
+            self.layer_core(li, c, s, self.q_c, self.k_c, self.v_c)
+        return x if x is not None else self.hidden_c[:, :c]
+
+    def decode_stage(self, i, x):
+        for li in range(len(self.counts)):
+            self.layer_core(li, 1, self.ctx, self.q_1, self.k_1, self.v_1)
+        self.cache.evict_last(1)   # reference benchmark_static.py:104
+        return x if x is not None else self.hidden_1
+
+
+def sync_all(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def run_job(hp: HotPath, pipe, n_decode, world, device):
+    """One whole job; returns (t_total, t_prefill, t_decode) seconds (wall, max over ranks not yet taken)."""
+    hp.cache.clear()
+    sync_all(world)
+    t0 = time.perf_counter()
+    pipe.run([(1, c, HIDDEN) for _, c in hp.chunks], hp.prefill_stage, device)
+    sync_all(world)
+    t1 = time.perf_counter()
+    pipe.run([(1, 1, HIDDEN)] * n_decode, hp.decode_stage, device)
+    sync_all(world)
+    t2 = time.perf_counter()
+    return t2 - t0, t1 - t0, t2 - t1
+
+
+def kernel_rooflines(hp: HotPath, counts_local, n_rep=3):
+    """HIP-event timing of the two attention kernels alone, on the stream they are launched on.
+
+    decode: the split-KV kernel of every local layer at context N (merge launch suppressed with
+    debug flag bit 1 so the events bracket exactly one kernel); prefill: the MFMA kernel of every
+    (chunk, layer) launch of one prefill pass.  Returns dicts with summed algorithmic work and time."""
+    from duo_attn import _hip
+    from duo_attn.backend import get_backend
+
+    be = get_backend()
+    cache = hp.cache
+    N = hp.ctx
+    G = HQ // HKV
+    scale = D ** -0.5
+    # ---- prefill pass with per-launch events --------------------------------------------------
+    cache.clear()
+    pf = prefill_flops(counts_local, hp.ctx, hp.chunk)
+    evs = []
+    for ci, (s, c) in enumerate(hp.chunks):
+        for li, nf in enumerate(counts_local):
+            q, k, v = hp.q_c[:, :c], hp.k_c[:, :c], hp.v_c[:, :c]
+            fk, fv, sk, sv = cache.split_kv(li, k, v)
+            past_l = cache.kv_seq_len_list[li]
+            cache.put_full_kv(li, fk, fv)
+            out = torch.empty_like(q)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if s == 0:
+                e0.record()
+                be.attention(q[0], out[0], G, (HKV, 0, None, (k[0], v[0])), None, scale)
+                e1.record()
+            else:
+                ns = HKV - nf
+                pk, pv = cache.full_key_states_list[li], cache.full_value_states_list[li]
+                ck, cv = cache.get_streaming_kv(li)
+                full = (nf, 0, (pk[0, :past_l], pv[0, :past_l]), (pk[0, past_l:past_l + c], pv[0, past_l:past_l + c])) if nf else None
+                stream = (ns, nf * G, (ck[0], cv[0]), (sk[0], sv[0])) if ns else None
+                e0.record()
+                be.attention(q[0], out[0], G, full, stream, scale)
+                e1.record()
+            cache.update_streaming_kv(li, sk, sv)
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    t_prefill = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+    prefill = {"flops": float(sum(sum(r) for r in pf)), "seconds": t_prefill, "launches": len(evs)}
+
+    # ---- decode split kernel at context N ------------------------------------------------------
+    db = decode_bytes(counts_local, N)
+    evs = []
+    _hip.set_debug_flags(2)   # bit 1: no merge launch -> events bracket the split kernel only
+    try:
+        q = hp.q_1
+        out = torch.empty_like(q)
+        for rep in range(n_rep + 1):
+            for li, nf in enumerate(counts_local):
+                ns = HKV - nf
+                pk, pv = cache.full_key_states_list[li], cache.full_value_states_list[li]
+                sk, sv = cache.streaming_key_states_list[li], cache.streaming_value_states_list[li]
+                W = SINK + RECENT
+                full = (nf, 0, (pk[0, :N], pv[0, :N]), (pk[0, N:N + 1], pv[0, N:N + 1])) if nf else None
+                stream = (ns, nf * G, (sk[0, :W], sv[0, :W]), (hp.k_1[0, :, nf:], hp.v_1[0, :, nf:])) if ns else None
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                be.attention(q[0], out[0], G, full, stream, scale)
+                e1.record()
+                if rep > 0:
+                    evs.append((e0, e1))
+        torch.cuda.synchronize()
+    finally:
+        _hip.set_debug_flags(0)
+    t_dec = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / n_rep
+    decode = {"bytes": float(sum(db)), "seconds": t_dec, "launches": len(counts_local)}
+    return prefill, decode
+
+
+def cpu_baseline(counts, ctx, chunk, n_decode):
+    """Oracle (torch CPU restatement of the reference semantics, fp32 math) timed on this host's
+    cores on a bounded sample, scaled to the job by algorithmic work."""
+    from oracle.duo_oracle import flash_attn_func_ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    nf = 4
+    # decode sample: one layer with 4 retrieval kv heads at the full context
+    N = ctx
+    q = torch.randn(1, 1, nf * 4, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, N + 1, nf, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, N + 1, nf, D, generator=g).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    flash_attn_func_ref(q, k, v)
+    t_dec = time.perf_counter() - t0
+    bytes_sample = nf * (N + 1) * 2 * D * 2
+    dec_tok_s = 1.0 / (t_dec * sum(decode_bytes(counts, ctx)) / bytes_sample)
+    # prefill sample: 128 query rows of one retrieval kv-head group against a 32768-token past
+    Sq, past = 128, min(32768, ctx)
+    q = torch.randn(1, Sq, 4, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, past + Sq, 1, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, past + Sq, 1, D, generator=g).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    flash_attn_func_ref(q, k, v)
+    t_pre = time.perf_counter() - t0
+    flops_sample = 4 * 4 * D * (Sq * past + Sq * (Sq + 1) / 2)
+    total_flops = sum(sum(r) for r in prefill_flops(counts, ctx, chunk))
+    pre_tok_s = ctx / (t_pre * total_flops / flops_sample)
+    job_tok_s = (ctx + n_decode) / (ctx / pre_tok_s + n_decode / dec_tok_s)
+    return {
+        "value": job_tok_s,
+        "unit": "tokens/s",
+        "cores": cores,
+        "kind": "port",
+        "prefill_tok_s": pre_tok_s,
+        "decode_tok_s": dec_tok_s,
+        "sample": (f"oracle/duo_oracle.py flash_attn_func_ref on {cores} threads: decode = 1 layer, 4 retrieval kv "
+                   f"heads x {N + 1} keys ({t_dec:.2f} s); prefill = 128 rows x 4 q heads vs {past + Sq} keys "
+                   f"({t_pre:.2f} s); scaled to the 32-layer job by algorithmic bytes / FLOPs"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ctx", type=int, default=131072)
+    ap.add_argument("--chunk", type=int, default=16384)
+    ap.add_argument("--decode-tokens", type=int, default=128)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--no-full-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from duo_attn.pipeline import LayerPipeline
+
+    counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
+    L = len(counts)
+    pipe = LayerPipeline(L, rank=rank, world_size=world)
+    lr = (pipe.first_layer, pipe.last_layer)
+    n_tok = args.ctx + args.decode_tokens
+
+    def timed(hp, steps, warmup):
+        for _ in range(warmup):
+            run_job(hp, pipe, args.decode_tokens, world, device)
+        sync_all(world)
+        t0 = time.perf_counter()
+        parts = [run_job(hp, pipe, args.decode_tokens, world, device) for _ in range(steps)]
+        sync_all(world)
+        t = torch.tensor([time.perf_counter() - t0, sum(p[1] for p in parts), sum(p[2] for p in parts)],
+                         device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return (t / steps).tolist()
+
+    hp = HotPath(counts, lr, args.ctx, args.chunk, device)
+    t_job, t_pre, t_dec = timed(hp, args.steps, args.warmup)
+
+    roof = roof_dec = None
+    if not args.no_kernel_roofline:
+        pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
+        tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
+        roof = {"kernel": "duo_prefill_kernel", "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
+                "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK, "traffic": None,
+                "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"]}
+        roof_dec = {"kernel": "duo_decode_split_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
+                    "unit": "GB/s", "frac": td / HBM_PEAK, "traffic": None,
+                    "avg_launch_ms": dec["seconds"] / dec["launches"] * 1e3, "launches": dec["launches"],
+                    "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"]}
+    kv_bytes = hp.cache.memory_usage
+    hp.free()
+
+    full = None
+    if not args.no_full_baseline:
+        hpf = HotPath([HKV] * L, lr, args.ctx, args.chunk, device)
+        f_job, f_pre, f_dec = timed(hpf, 1, 0)
+        full = {"job_tok_s": n_tok / f_job, "prefill_tok_s": args.ctx / f_pre,
+                "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": hpf.cache.memory_usage}
+        hpf.free()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(counts, args.ctx, args.chunk, args.decode_tokens)
+
+    if rank == 0:
+        line = {
+            "metric": "prefill tok/s + decode tok/s @128K ctx, Llama-3-8B 50% streaming, 1 MI355X",
+            "value": n_tok / t_job,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_job * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": (f"Llama-3-8B-Instruct-Gradient-1048k shape, attention hot path only (op level): "
+                             f"{args.ctx}-token chunked prefill (chunk {args.chunk}) + {args.decode_tokens} decode "
+                             f"steps at {args.ctx} ctx, {L} layers, 50% streaming kv heads, sink {SINK} recent {RECENT}, B=1"),
+                "global_batch": 1,
+                "seq_len": args.ctx,
+                "prefill_chunk": args.chunk,
+                "decode_tokens": args.decode_tokens,
+                "parallelism": f"layer-pipeline pp{world}" if world > 1 else "single GPU",
+            },
+            "prefill_tok_s": args.ctx / t_pre,
+            "decode_tok_s": args.decode_tokens / t_dec,
+            "decode_ms_per_token": t_dec / args.decode_tokens * 1e3,
+            "kv_cache_bytes": kv_bytes,
+            "full_attention": full,
+            "speedup_vs_full_attention": None if full is None else {
+                "prefill": (args.ctx / t_pre) / full["prefill_tok_s"],
+                "decode": (args.decode_tokens / t_dec) / full["decode_tok_s"],
+                "kv_memory": full["kv_cache_bytes"] / kv_bytes,
+            },
+            "roofline": roof,
+            "roofline_decode": roof_dec,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

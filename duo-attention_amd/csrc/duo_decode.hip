@@ -1,0 +1,430 @@
+// duo_decode.hip — single-token decode attention for both DuoAttention head
+// classes in one launch (gfx950).
+//
+// Replaces the two flash_attn_func calls of the decode branch of the reference
+// (duo_attn/patch/llama.py:392-421 with q_len == 1): retrieval heads scan the
+// whole full-KV pool, streaming heads scan sink+recent pool rows plus the new
+// row.  The step is HBM-bound (512 B of K+V per token per kv head against
+// ~2 KFLOP), so the design is a split-KV stream:
+//
+//   * one 256-thread workgroup per (kv head, token chunk); the G q heads of the
+//     GQA group share every K/V row that is fetched;
+//   * 16 lanes per token row, 16 B per lane -> every global_load_dwordx4 of a
+//     wave covers 4 whole 256-B rows (full-line coalescing on either pool
+//     layout), 8 such loads (4 K + 4 V) in flight per wave and the next 8
+//     prefetched behind the current compute;
+//   * fp32 scalar FMA for q.k and p.v, DPP row all-reduce for the 16-lane dot
+//     product (no LDS), exp2-domain online softmax per 16-lane token group;
+//   * per-workgroup partial (m, l, acc[128]) per q head -> fp32 workspace,
+//     merged by duo_decode_merge_kernel (or written straight to `out` when a
+//     class needs a single split).
+#include <algorithm>
+#include "duo_common.h"
+
+namespace {
+
+constexpr float kNegSentinel = -1.0e30f;
+constexpr int kTokPerIter = 16;  // tokens per wave per iteration (4 loads x 4 rows)
+
+struct DecodeParams {
+    const bf16_t *q;
+    int64_t q_head_stride;
+    bf16_t *out;
+    int64_t out_head_stride;
+    DuoClassDev cls[2];      // 0 = retrieval (full), 1 = streaming
+    int32_t splits[2];       // token chunks per kv head
+    int32_t chunk[2];        // tokens per chunk (multiple of 64)
+    int32_t nblk_full;       // cls[0].n_kv_heads * splits[0]
+    int32_t group;           // q heads per kv head
+    float scale_log2e;
+    float *ws_ml;            // [n_q_heads][max_splits][2]
+    float *ws_acc;           // [n_q_heads][max_splits][128]
+    int32_t max_splits;
+};
+
+__device__ __forceinline__ void unpack8(const u32x4 &w, float (&f)[8]) {
+    f[0] = bf16_lo(w.x); f[1] = bf16_hi(w.x);
+    f[2] = bf16_lo(w.y); f[3] = bf16_hi(w.y);
+    f[4] = bf16_lo(w.z); f[5] = bf16_hi(w.z);
+    f[6] = bf16_lo(w.w); f[7] = bf16_hi(w.w);
+}
+
+struct RowSrc {
+    const bf16_t *ka, *va;   // segment A base for this kv head (+ lane dim offset)
+    const bf16_t *kb, *vb;   // segment B base
+    int64_t tsa, tsb;
+    int32_t lenA;
+};
+
+__device__ __forceinline__ void load_rows(const RowSrc &src, int tok0, int tg, int tok_end,
+                                          u32x4 (&kbuf)[4], u32x4 (&vbuf)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int tok = tok0 + 4 * u + tg;
+        tok = tok < tok_end ? tok : tok_end - 1;  // clamp: masked later, never OOB
+        const bool inA = tok < src.lenA;
+        const int64_t off = inA ? (int64_t)tok * src.tsa : (int64_t)(tok - src.lenA) * src.tsb;
+        const bf16_t *kp = (inA ? src.ka : src.kb) + off;
+        const bf16_t *vp = (inA ? src.va : src.vb) + off;
+        kbuf[u] = *reinterpret_cast<const u32x4 *>(kp);
+        vbuf[u] = *reinterpret_cast<const u32x4 *>(vp);
+    }
+}
+
+template <int GT>
+__device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4 (&vbuf)[4],
+                                             int tok0, int tg, int tok_end,
+                                             const float (&qf)[GT][8], float (&m)[GT],
+                                             float (&l)[GT], float (&acc)[GT][8]) {
+    float s[4][GT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float kf[8];
+        unpack8(kbuf[u], kf);
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            float d = qf[g][0] * kf[0];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) d = fmaf(qf[g][e], kf[e], d);
+            s[u][g] = d;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < GT; ++g) s[u][g] = row16_allreduce_sum(s[u][g]);
+
+    bool valid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) valid[u] = (tok0 + 4 * u + tg) < tok_end;
+
+    float p[4][GT];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        float mn = m[g];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mn = fmaxf(mn, valid[u] ? s[u][g] : kNegSentinel);
+        const float alpha = fast_exp2(m[g] - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p[u][g] = valid[u] ? fast_exp2(s[u][g] - mn) : 0.f;
+            psum += p[u][g];
+        }
+        l[g] = fmaf(l[g], alpha, psum);
+        m[g] = mn;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] *= alpha;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float vf[8];
+        unpack8(vbuf[u], vf);
+#pragma unroll
+        for (int g = 0; g < GT; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p[u][g], vf[e], acc[g][e]);
+    }
+}
+
+// grid.x = (kv head, split) pairs of the full class then of the streaming class
+// grid.y = group / GT
+template <int GT>
+__global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
+    const int tg = lane >> 4;    // which of the 4 rows a wave-load covers
+
+    int b = blockIdx.x;
+    const int ci = b < P.nblk_full ? 0 : 1;
+    if (ci) b -= P.nblk_full;
+    const DuoClassDev &C = P.cls[ci];
+    const int splits = P.splits[ci];
+    const int chunk = P.chunk[ci];
+    const int kvh = b / splits;
+    const int split = b - kvh * splits;
+    const int qh0 = C.q_head_offset + kvh * P.group + blockIdx.y * GT;
+
+    const int L = C.a.len + C.b.len;
+    const int c0 = split * chunk;
+    const int c1 = min(c0 + chunk, L);
+    const int per_wave = chunk >> 2;  // multiple of 16
+    const int w0 = c0 + wave * per_wave;
+    const int w1 = min(w0 + per_wave, c1);
+
+    RowSrc src;
+    src.ka = C.a.k + kvh * C.a.head_stride + sub * 8;
+    src.va = C.a.v + kvh * C.a.head_stride + sub * 8;
+    src.kb = C.b.k + kvh * C.b.head_stride + sub * 8;
+    src.vb = C.b.v + kvh * C.b.head_stride + sub * 8;
+    src.tsa = C.a.token_stride;
+    src.tsb = C.b.token_stride;
+    src.lenA = C.a.len;
+
+    float qf[GT][8];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)(qh0 + g) * P.q_head_stride + sub * 8);
+        unpack8(w, qf[g]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[g][e] *= P.scale_log2e;
+    }
+
+    float m[GT], l[GT], acc[GT][8];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        m[g] = kNegSentinel;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+
+    if (w0 < w1) {
+        u32x4 k0[4], v0[4], k1[4], v1[4];
+        load_rows(src, w0, tg, w1, k0, v0);
+        for (int t = w0; t < w1; t += 2 * kTokPerIter) {
+            const bool more1 = t + kTokPerIter < w1;
+            if (more1) load_rows(src, t + kTokPerIter, tg, w1, k1, v1);
+            consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
+            if (more1) {
+                if (t + 2 * kTokPerIter < w1) load_rows(src, t + 2 * kTokPerIter, tg, w1, k0, v0);
+                consume_rows<GT>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
+            }
+        }
+    }
+
+    // ---- combine the 4 token groups of the wave (lanes l, l^16, l^32, l^48 hold
+    //      the same dim slice), then the 4 waves through LDS -------------------
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        float mm = m[g];
+        mm = fmaxf(mm, __shfl_xor(mm, 16));
+        mm = fmaxf(mm, __shfl_xor(mm, 32));
+        const float sc = fast_exp2(m[g] - mm);
+        float ll = l[g] * sc;
+        ll += __shfl_xor(ll, 16);
+        ll += __shfl_xor(ll, 32);
+        m[g] = mm;
+        l[g] = ll;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float a = acc[g][e] * sc;
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            acc[g][e] = a;
+        }
+    }
+
+    __shared__ float s_ml[4][GT][2];
+    __shared__ float s_acc[4][GT][DUO_HEAD_DIM];
+    if (tg == 0) {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            if (sub == 0) {
+                s_ml[wave][g][0] = m[g];
+                s_ml[wave][g][1] = l[g];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_acc[wave][g][sub * 8 + e] = acc[g][e];
+        }
+    }
+    __syncthreads();
+
+    for (int idx = threadIdx.x; idx < GT * DUO_HEAD_DIM; idx += 256) {
+        const int g = idx >> 7;
+        const int d = idx & 127;
+        float M = s_ml[0][g][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
+        float Lsum = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = fast_exp2(s_ml[w][g][0] - M);
+            Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
+            o = fmaf(s_acc[w][g][d], sc, o);
+        }
+        const int qh = qh0 + g;
+        if (splits == 1) {
+            // single split: this workgroup saw every key of the head
+            P.out[(int64_t)qh * P.out_head_stride + d] = (bf16_t)f32_to_bf16_bits(o / Lsum);
+        } else {
+            const int64_t slot = (int64_t)qh * P.max_splits + split;
+            P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
+            if (d == 0) {
+                P.ws_ml[slot * 2 + 0] = M;
+                P.ws_ml[slot * 2 + 1] = Lsum;
+            }
+        }
+    }
+}
+
+struct MergeParams {
+    const float *ws_ml;
+    const float *ws_acc;
+    bf16_t *out;
+    int64_t out_head_stride;
+    int32_t max_splits;
+    // q-head ranges [begin,end) with their split counts; ranges with <=1 split are skipped
+    int32_t qh_begin[2], qh_end[2], splits[2];
+};
+
+// one workgroup (256 threads) per q head: 8 split lanes x 32 dim quads
+__global__ __launch_bounds__(256) void duo_decode_merge_kernel(const MergeParams P) {
+    int qh = blockIdx.x;
+    int splits;
+    {
+        const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
+        if (qh < n0) {
+            qh += P.qh_begin[0];
+            splits = P.splits[0];
+        } else {
+            qh = qh - n0 + P.qh_begin[1];
+            splits = P.splits[1];
+        }
+    }
+    const int sl = threadIdx.x >> 5;  // 0..7
+    const int dq = threadIdx.x & 31;  // dims 4dq..4dq+3
+    const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
+    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + dq * 4;
+
+    float M = kNegSentinel, Lsum = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int s = sl; s < splits; s += 8) {
+        const float ms = ml[s * 2], ls = ml[s * 2 + 1];
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM);
+        const float mn = fmaxf(M, ms);
+        const float s_old = fast_exp2(M - mn), s_new = fast_exp2(ms - mn);
+        Lsum = Lsum * s_old + ls * s_new;
+        o = o * s_old + a * s_new;
+        M = mn;
+    }
+    __shared__ float sm[8][32];
+    __shared__ float slm[8][32];
+    __shared__ f32x4 so[8][32];
+    sm[sl][dq] = M;
+    slm[sl][dq] = Lsum;
+    so[sl][dq] = o;
+    __syncthreads();
+    if (sl == 0) {
+        float MM = sm[0][dq];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) MM = fmaxf(MM, sm[i][dq]);
+        float LL = 0.f;
+        f32x4 oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sc = fast_exp2(sm[i][dq] - MM);
+            LL = fmaf(slm[i][dq], sc, LL);
+            oo = oo + so[i][dq] * sc;
+        }
+        const float inv = 1.f / LL;
+        u32x2 w;
+        w.x = pack_bf16x2(oo.x * inv, oo.y * inv);
+        w.y = pack_bf16x2(oo.z * inv, oo.w * inv);
+        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + dq * 4) = w;
+    }
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+extern "C" int64_t duo_attn_decode_workspace_bytes(int32_t n_q_heads, int32_t max_splits) {
+    if (n_q_heads <= 0 || max_splits <= 0) return 0;
+    return (int64_t)n_q_heads * max_splits * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
+}
+
+// Split policy: enough (kv head, chunk) workgroups to put ~4 on every one of the
+// 256 CUs, chunks of at least 256 tokens so the per-workgroup epilogue stays
+// small, and no more splits per head than the workspace was sized for.
+static void choose_splits(int n_kv_heads, int L, int max_splits, int &chunk, int &splits) {
+    if (n_kv_heads <= 0 || L <= 0) {
+        chunk = 256;
+        splits = 0;
+        return;
+    }
+    const int64_t total = (int64_t)n_kv_heads * L;
+    int c = (int)((total + 1023) / 1024);
+    c = round_up(c < 256 ? 256 : c, 64);
+    int s = (L + c - 1) / c;
+    if (s > max_splits) {
+        c = round_up((L + max_splits - 1) / max_splits, 64);
+        s = (L + c - 1) / c;
+    }
+    chunk = c;
+    splits = s;
+}
+
+extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
+                                    int64_t out_head_stride, int32_t group,
+                                    const duo_head_class *full, const duo_head_class *stream_cls,
+                                    float scale, int32_t head_dim, void *workspace,
+                                    int64_t workspace_bytes, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (q == nullptr || out == nullptr || group <= 0) return DUO_EINVAL;
+    DecodeParams P;
+    P.q = (const bf16_t *)q;
+    P.q_head_stride = q_head_stride;
+    P.out = (bf16_t *)out;
+    P.out_head_stride = out_head_stride;
+    P.cls[0] = duo_class_dev(full);
+    P.cls[1] = duo_class_dev(stream_cls);
+    P.group = group;
+    P.scale_log2e = scale * 1.4426950408889634f;
+    const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
+    if (n_q_heads <= 0) return 0;
+    for (int c = 0; c < 2; ++c) {
+        const DuoClassDev &C = P.cls[c];
+        if (C.n_kv_heads <= 0) continue;
+        if (C.a.len < 0 || C.b.len < 0 || C.a.len + C.b.len <= 0) return DUO_EINVAL;
+        if ((C.a.len > 0 && (!C.a.k || !C.a.v)) || (C.b.len > 0 && (!C.b.k || !C.b.v))) return DUO_EINVAL;
+        if (C.a.len == 0) { P.cls[c].a = P.cls[c].b; P.cls[c].a.len = 0; }  // valid base for clamped loads
+        if (C.b.len == 0) { P.cls[c].b = P.cls[c].a; P.cls[c].b.len = 0; }
+    }
+    // workspace capacity -> max splits per head
+    const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
+    int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
+    for (int c = 0; c < 2; ++c) {
+        const int L = P.cls[c].a.len + P.cls[c].b.len;
+        choose_splits(P.cls[c].n_kv_heads, L, max_splits > 0 ? max_splits : 1, P.chunk[c], P.splits[c]);
+    }
+    const int need = std::max(P.splits[0], P.splits[1]);
+    if (need > 1 && max_splits < need) return DUO_EWORKSPC;
+    P.max_splits = need > 1 ? need : 1;
+    P.ws_ml = (float *)workspace;
+    P.ws_acc = P.ws_ml ? P.ws_ml + (int64_t)n_q_heads * P.max_splits * 2 : nullptr;
+    P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
+    const int nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
+
+    const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
+    dim3 grid(nblk, group / gt), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (gt == 4)
+        hipLaunchKernelGGL(duo_decode_split_kernel<4>, grid, block, 0, st, P);
+    else if (gt == 2)
+        hipLaunchKernelGGL(duo_decode_split_kernel<2>, grid, block, 0, st, P);
+    else
+        hipLaunchKernelGGL(duo_decode_split_kernel<1>, grid, block, 0, st, P);
+    DUO_HIP_CHECK_LAUNCH();
+
+    MergeParams M;
+    M.ws_ml = P.ws_ml;
+    M.ws_acc = P.ws_acc;
+    M.out = P.out;
+    M.out_head_stride = out_head_stride;
+    M.max_splits = P.max_splits;
+    int n_merge = 0;
+    for (int c = 0; c < 2; ++c) {
+        M.qh_begin[c] = P.cls[c].q_head_offset;
+        M.qh_end[c] = P.cls[c].q_head_offset + P.cls[c].n_kv_heads * group;
+        M.splits[c] = P.splits[c];
+        if (P.splits[c] > 1) n_merge += P.cls[c].n_kv_heads * group;
+    }
+    // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
+    if (n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
+        hipLaunchKernelGGL(duo_decode_merge_kernel, dim3(n_merge), dim3(256), 0, st, M);
+        DUO_HIP_CHECK_LAUNCH();
+    }
+    return 0;
+}

@@ -1,0 +1,286 @@
+// duo_rope_kv.hip — the small HBM-bound kernels either side of the attention
+// kernels (gfx950): RoPE in place, KV append into a pool, the streaming-pool
+// sink+recent compaction, and RMSNorm.  All of them move 16 B per lane.
+#include <math.h>
+#include <algorithm>
+#include "duo_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8f(const u32x4 &w, float (&f)[8]) {
+    f[0] = bf16_lo(w.x); f[1] = bf16_hi(w.x);
+    f[2] = bf16_lo(w.y); f[3] = bf16_hi(w.y);
+    f[4] = bf16_lo(w.z); f[5] = bf16_hi(w.z);
+    f[6] = bf16_lo(w.w); f[7] = bf16_hi(w.w);
+}
+__device__ __forceinline__ u32x4 pack8f(const float (&f)[8]) {
+    u32x4 w;
+    w.x = pack_bf16x2(f[0], f[1]);
+    w.y = pack_bf16x2(f[2], f[3]);
+    w.z = pack_bf16x2(f[4], f[5]);
+    w.w = pack_bf16x2(f[6], f[7]);
+    return w;
+}
+
+// ---------------------------------------------------------------------------
+// RoPE, rotate-half convention (flashinfer interleave=False; reference call
+// site duo_attn/patch/flashinfer_utils.py:48-56):
+//   x'[i]      = x[i]      * cos(a_i) - x[i+64] * sin(a_i)
+//   x'[i+64]   = x[i+64]   * cos(a_i) + x[i]    * sin(a_i),   i in [0,64)
+//   a_i = float(pos) * inv_freq[i],  inv_freq[i] = theta^(-2i/128) / rope_scale
+// inv_freq is computed on the host in double and rounded once to fp32, so the
+// fp32 angle is a single IEEE multiply and is reproducible bit-for-bit by the
+// oracle (at position 1e6 one fp32 ulp of the angle is already 0.06 rad).
+// ---------------------------------------------------------------------------
+struct RopeParams {
+    bf16_t *q;
+    int64_t q_ts, q_hs;
+    int32_t n_q_heads;
+    bf16_t *k;
+    int64_t k_ts, k_hs;
+    int32_t n_kv_heads;
+    int32_t n_tokens;
+    int64_t pos0;
+    float inv_freq[64];
+};
+
+// 64 threads per token: c = tid&7 picks dims [8c,8c+8) and [64+8c,64+8c+8),
+// hs = (tid>>3)&7 strides over the heads 8 at a time.  4 tokens per block.
+__global__ __launch_bounds__(256) void duo_rope_kernel(const RopeParams P) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= P.n_tokens) return;
+    const int c = threadIdx.x & 7;
+    const int hs = (threadIdx.x >> 3) & 7;
+    const float pos = (float)(P.pos0 + tok);
+    float cs[8], sn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = pos * P.inv_freq[c * 8 + e];
+        sincosf(a, &sn[e], &cs[e]);
+    }
+    const int n_heads = P.n_q_heads + P.n_kv_heads;
+    for (int h = hs; h < n_heads; h += 8) {
+        bf16_t *row = h < P.n_q_heads
+                          ? P.q + (int64_t)tok * P.q_ts + (int64_t)h * P.q_hs
+                          : P.k + (int64_t)tok * P.k_ts + (int64_t)(h - P.n_q_heads) * P.k_hs;
+        u32x4 *plo = reinterpret_cast<u32x4 *>(row + c * 8);
+        u32x4 *phi = reinterpret_cast<u32x4 *>(row + 64 + c * 8);
+        float lo[8], hi[8], olo[8], ohi[8];
+        unpack8f(*plo, lo);
+        unpack8f(*phi, hi);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            olo[e] = lo[e] * cs[e] - hi[e] * sn[e];
+            ohi[e] = hi[e] * cs[e] + lo[e] * sn[e];
+        }
+        *plo = pack8f(olo);
+        *phi = pack8f(ohi);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// KV append: pool[dst_row0 + t, h, :] = src[t, h, :] for K and V
+// (DuoAttentionStaticKVCache.put_full_kv, static_kv_cache.py:109-125)
+// ---------------------------------------------------------------------------
+struct AppendParams {
+    const bf16_t *ks, *vs;
+    int64_t s_ts, s_hs;
+    bf16_t *kp, *vp;
+    int64_t p_ts, p_hs;
+    int32_t n_heads, n_tokens, dst_row0;
+};
+
+__global__ __launch_bounds__(256) void duo_kv_append_kernel(const AppendParams P) {
+    const int64_t total = (int64_t)P.n_tokens * P.n_heads * 16;   // 16-B chunks per (token, head)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i & 15);
+        const int64_t th = i >> 4;
+        const int h = (int)(th % P.n_heads);
+        const int64_t t = th / P.n_heads;
+        const int64_t so = t * P.s_ts + (int64_t)h * P.s_hs + ch * 8;
+        const int64_t po = (P.dst_row0 + t) * P.p_ts + (int64_t)h * P.p_hs + ch * 8;
+        *reinterpret_cast<u32x4 *>(P.kp + po) = *reinterpret_cast<const u32x4 *>(P.ks + so);
+        *reinterpret_cast<u32x4 *>(P.vp + po) = *reinterpret_cast<const u32x4 *>(P.vs + so);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Streaming pool update (compress_and_replace_streaming_kv,
+// static_kv_cache.py:127-167, input = torch.cat([pool[:cur], new]) of
+// llama.py:385-390).  X = pool[:cur] ++ new[:n_new], T = cur + n_new.
+//   T <= W : pool[cur:T] = new
+//   T >  W : pool[r] = X[r] (r < sink);  pool[sink+j] = X[T-recent+j] (j < recent)
+// Every source row index is >= its destination row index, so one workgroup per
+// (head, K|V) walks the destination rows upward in batches: load a batch into
+// registers, barrier, store.  A later batch only reads rows above anything
+// already written.
+// ---------------------------------------------------------------------------
+struct CompressParams {
+    bf16_t *kp, *vp;
+    int64_t p_ts, p_hs;
+    const bf16_t *kn, *vn;
+    int64_t n_ts, n_hs;
+    int32_t n_heads, cur, n_new, sink, recent;
+};
+
+constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
+
+__global__ __launch_bounds__(256) void duo_stream_compress_kernel(const CompressParams P) {
+    const int h = blockIdx.x >> 1;
+    const bool is_v = blockIdx.x & 1;
+    bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs;
+    const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs;
+    const int T = P.cur + P.n_new;
+    const int W = P.sink + P.recent;
+    const int ch = threadIdx.x & 15;
+    const int r_in = threadIdx.x >> 4;   // 0..15
+
+    int d_begin, d_end;
+    if (T <= W) { d_begin = P.cur; d_end = T; }
+    else { d_begin = 0; d_end = W; }
+
+    for (int d0 = d_begin; d0 < d_end; d0 += CMP_ROWS) {
+        u32x4 buf[4];
+        bool act[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + r_in + 16 * j;
+            act[j] = d < d_end;
+            int x = d;                                   // source index in X
+            if (T > W && d >= P.sink) x = T - P.recent + (d - P.sink);
+            // rows that stay where they are need no traffic
+            if (act[j] && x == d && x < P.cur) act[j] = false;
+            if (act[j]) {
+                const bf16_t *src = x < P.cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - P.cur) * P.n_ts;
+                buf[j] = *reinterpret_cast<const u32x4 *>(src + ch * 8);
+            }
+        }
+        __syncthreads();   // all loads of this batch complete before any store of it
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + r_in + 16 * j;
+            if (act[j]) *reinterpret_cast<u32x4 *>(pool + (int64_t)d * P.p_ts + ch * 8) = buf[j];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// RMSNorm (flashinfer.norm.rmsnorm semantics, flashinfer_utils.py:9-16):
+// fp32 throughout, one rounding to bf16.  One workgroup per row.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void duo_rmsnorm_kernel(const bf16_t *x, const bf16_t *w, bf16_t *y,
+                                                         int hidden, float eps) {
+    const int64_t row = blockIdx.x;
+    const bf16_t *xr = x + row * hidden;
+    bf16_t *yr = y + row * hidden;
+    const int nchunk = hidden >> 3;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        float f[8];
+        unpack8f(*reinterpret_cast<const u32x4 *>(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float rs = rsqrtf(tot / (float)hidden + eps);
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        float f[8], g[8];
+        unpack8f(*reinterpret_cast<const u32x4 *>(xr + c * 8), f);
+        unpack8f(*reinterpret_cast<const u32x4 *>(w + c * 8), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * rs * g[e];
+        *reinterpret_cast<u32x4 *>(yr + c * 8) = pack8f(f);
+    }
+}
+
+}  // namespace
+
+extern "C" int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                     int32_t n_q_heads, void *k, int64_t k_token_stride,
+                                     int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                                     int64_t pos0, float rope_scale, float rope_theta,
+                                     int32_t head_dim, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (n_tokens <= 0) return 0;
+    if ((n_q_heads > 0 && !q) || (n_kv_heads > 0 && !k) || rope_scale <= 0.f || rope_theta <= 0.f)
+        return DUO_EINVAL;
+    if (((q_token_stride | q_head_stride | k_token_stride | k_head_stride) & 7) != 0) return DUO_EINVAL;
+    RopeParams P;
+    P.q = (bf16_t *)q; P.q_ts = q_token_stride; P.q_hs = q_head_stride; P.n_q_heads = n_q_heads;
+    P.k = (bf16_t *)k; P.k_ts = k_token_stride; P.k_hs = k_head_stride; P.n_kv_heads = n_kv_heads;
+    P.n_tokens = n_tokens;
+    P.pos0 = pos0;
+    for (int i = 0; i < 64; ++i)
+        P.inv_freq[i] = (float)(pow((double)rope_theta, -2.0 * i / 128.0) / (double)rope_scale);
+    hipLaunchKernelGGL(duo_rope_kernel, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, P);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_kv_append_bf16(const void *k_src, const void *v_src, int64_t src_token_stride,
+                                  int64_t src_head_stride, void *k_pool, void *v_pool,
+                                  int64_t pool_token_stride, int64_t pool_head_stride,
+                                  int32_t n_heads, int32_t n_tokens, int32_t dst_row0,
+                                  int32_t head_dim, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (n_heads <= 0 || n_tokens <= 0) return 0;
+    if (!k_src || !v_src || !k_pool || !v_pool || dst_row0 < 0) return DUO_EINVAL;
+    if (((src_token_stride | src_head_stride | pool_token_stride | pool_head_stride) & 7) != 0) return DUO_EINVAL;
+    AppendParams P{(const bf16_t *)k_src, (const bf16_t *)v_src, src_token_stride, src_head_stride,
+                   (bf16_t *)k_pool, (bf16_t *)v_pool, pool_token_stride, pool_head_stride,
+                   n_heads, n_tokens, dst_row0};
+    const int64_t total = (int64_t)n_tokens * n_heads * 16;
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(duo_kv_append_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_stream_compress_bf16(void *k_pool, void *v_pool, int64_t pool_token_stride,
+                                        int64_t pool_head_stride, const void *k_new, const void *v_new,
+                                        int64_t new_token_stride, int64_t new_head_stride,
+                                        int32_t n_heads, int32_t cur_len, int32_t n_new, int32_t sink,
+                                        int32_t recent, int32_t head_dim, int32_t *new_len, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (cur_len < 0 || n_new < 0 || sink < 0 || recent < 0 || cur_len > sink + recent) return DUO_EINVAL;
+    const int T = cur_len + n_new, W = sink + recent;
+    if (new_len) *new_len = T <= W ? T : W;
+    if (n_heads <= 0 || n_new == 0) return 0;
+    if (!k_pool || !v_pool || !k_new || !v_new) return DUO_EINVAL;
+    if (((pool_token_stride | pool_head_stride | new_token_stride | new_head_stride) & 7) != 0) return DUO_EINVAL;
+    CompressParams P{(bf16_t *)k_pool, (bf16_t *)v_pool, pool_token_stride, pool_head_stride,
+                     (const bf16_t *)k_new, (const bf16_t *)v_new, new_token_stride, new_head_stride,
+                     n_heads, cur_len, n_new, sink, recent};
+    hipLaunchKernelGGL(duo_stream_compress_kernel, dim3(n_heads * 2), dim3(256), 0, (hipStream_t)stream, P);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows, int32_t hidden,
+                                float eps, void *stream) {
+    if (n_rows <= 0) return 0;
+    if (!x || !w || !y || hidden <= 0 || (hidden & 7)) return DUO_EINVAL;
+    hipLaunchKernelGGL(duo_rmsnorm_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t *)x, (const bf16_t *)w, (bf16_t *)y, hidden, eps);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_abi_version(void) { return DUO_ABI_VERSION; }
+extern "C" const char *duo_target_arch(void) { return "gfx950"; }
+extern "C" const char *duo_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case DUO_EINVAL: return "DUO_EINVAL: bad pointer, size or stride";
+        case DUO_EHEADDIM: return "DUO_EHEADDIM: head_dim must be 128";
+        case DUO_EGROUP: return "DUO_EGROUP: unsupported GQA group size";
+        case DUO_EWORKSPC: return "DUO_EWORKSPC: decode workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown duo error";
+    }
+}

@@ -1,0 +1,291 @@
+"""ctypes binding of the C-ABI library ``libduoattn_hip.so`` (include/duo_attn_hip.h).
+
+This is the only place the Python host touches native code.  Tensors cross the
+boundary as raw device pointers + element strides + the current HIP stream;
+PyTorch is used for device memory and streams only.  There is NO CPU fallback:
+a missing library, a non-GPU tensor or a non-zero return code raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+from typing import Optional
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
+ABI_VERSION = 1
+HEAD_DIM = 128
+
+
+class DuoHipError(RuntimeError):
+    pass
+
+
+class KVSeg(Structure):
+    """``duo_kv_seg``"""
+
+    _fields_ = [
+        ("k", c_void_p),
+        ("v", c_void_p),
+        ("token_stride", c_int64),
+        ("head_stride", c_int64),
+        ("len", c_int32),
+        ("_pad", c_int32),
+    ]
+
+
+class HeadClass(Structure):
+    """``duo_head_class``"""
+
+    _fields_ = [
+        ("n_kv_heads", c_int32),
+        ("q_head_offset", c_int32),
+        ("segA", KVSeg),
+        ("segB", KVSeg),
+    ]
+
+
+_SIGNATURES = {
+    "duo_abi_version": (ctypes.c_int, []),
+    "duo_target_arch": (c_char_p, []),
+    "duo_error_string": (c_char_p, [ctypes.c_int]),
+    "duo_set_debug_flags": (None, [c_uint32]),
+    "duo_get_debug_flags": (c_uint32, []),
+    "duo_rope_inplace_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64,
+         c_float, c_float, c_int32, c_void_p],
+    ),
+    "duo_kv_append_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_void_p],
+    ),
+    "duo_stream_compress_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_void_p],
+    ),
+    "duo_attn_decode_workspace_bytes": (c_int64, [c_int32, c_int32]),
+    "duo_attn_decode_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_int32, POINTER(HeadClass), POINTER(HeadClass), c_float,
+         c_int32, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_attn_prefill_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
+         POINTER(HeadClass), c_float, c_int32, c_void_p],
+    ),
+    "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load (once) and type the C-ABI library.  Raises DuoHipError if it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("DUO_ATTN_HIP_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise DuoHipError(
+            f"DuoAttention HIP library not found at {p}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C duo-attention_amd/csrc`. "
+            "There is no CPU fallback for the attention hot path."
+        )
+    lib = ctypes.CDLL(p)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => symbol missing from the build
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.duo_abi_version() != ABI_VERSION:
+        raise DuoHipError(f"ABI mismatch: library {lib.duo_abi_version()} vs binding {ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(code: int, what: str):
+    if code != 0:
+        msg = load_library().duo_error_string(code).decode()
+        raise DuoHipError(f"{what} failed: [{code}] {msg}")
+
+
+def _require_gpu_bf16(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise DuoHipError(
+            f"{name} is on {t.device}; the DuoAttention hot path only runs on an MI355X (HIP) device — "
+            "there is no CPU fallback."
+        )
+    if t.dtype != torch.bfloat16:
+        raise DuoHipError(f"{name} must be bfloat16, got {t.dtype}")
+    if t.stride(-1) != 1:
+        raise DuoHipError(f"{name}: last (head_dim) dimension must be contiguous")
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def make_seg(k: Optional[torch.Tensor], v: Optional[torch.Tensor]) -> KVSeg:
+    """k, v: views [T, h, D] (any token/head stride, D contiguous) or None for an empty segment."""
+    s = KVSeg()
+    if k is None or k.shape[0] == 0 or k.shape[1] == 0:
+        s.k = None
+        s.v = None
+        s.token_stride = 0
+        s.head_stride = 0
+        s.len = 0
+        return s
+    _require_gpu_bf16(k, "k segment")
+    _require_gpu_bf16(v, "v segment")
+    assert k.dim() == 3 and v.shape == k.shape and k.stride() == v.stride() and k.shape[2] == HEAD_DIM
+    s.k = k.data_ptr()
+    s.v = v.data_ptr()
+    s.token_stride = k.stride(0)
+    s.head_stride = k.stride(1)
+    s.len = k.shape[0]
+    return s
+
+
+def make_class(n_kv_heads: int, q_head_offset: int, segA: KVSeg, segB: KVSeg) -> HeadClass:
+    c = HeadClass()
+    c.n_kv_heads = int(n_kv_heads)
+    c.q_head_offset = int(q_head_offset)
+    c.segA = segA
+    c.segB = segB
+    return c
+
+
+# ----------------------------------------------------------------------------- ops
+def rope_inplace(q: torch.Tensor, k: torch.Tensor, pos0: int, rope_scale: float, rope_theta: float):
+    """q: [S, Hq, D], k: [S, Hkv, D] views, rotated in place (flashinfer apply_rope_inplace semantics)."""
+    lib = load_library()
+    _require_gpu_bf16(q, "q")
+    _require_gpu_bf16(k, "k")
+    assert q.dim() == 3 and k.dim() == 3 and q.shape[0] == k.shape[0]
+    _check(
+        lib.duo_rope_inplace_bf16(
+            q.data_ptr(), q.stride(0), q.stride(1), q.shape[1], k.data_ptr(), k.stride(0), k.stride(1),
+            k.shape[1], q.shape[0], int(pos0), float(rope_scale), float(rope_theta), q.shape[2], _stream_ptr(),
+        ),
+        "duo_rope_inplace_bf16",
+    )
+
+
+def kv_append(k_src, v_src, k_pool, v_pool, dst_row0: int):
+    """src: [S, h, D] views; pools: [T, h, D] views.  pool[dst_row0:dst_row0+S] = src."""
+    lib = load_library()
+    if k_src.shape[0] == 0 or k_src.shape[1] == 0:
+        return
+    for t, n in ((k_src, "k_src"), (v_src, "v_src"), (k_pool, "k_pool"), (v_pool, "v_pool")):
+        _require_gpu_bf16(t, n)
+    assert k_src.stride() == v_src.stride() and k_pool.stride() == v_pool.stride()
+    assert dst_row0 + k_src.shape[0] <= k_pool.shape[0]
+    _check(
+        lib.duo_kv_append_bf16(
+            k_src.data_ptr(), v_src.data_ptr(), k_src.stride(0), k_src.stride(1), k_pool.data_ptr(),
+            v_pool.data_ptr(), k_pool.stride(0), k_pool.stride(1), k_src.shape[1], k_src.shape[0],
+            int(dst_row0), k_src.shape[2], _stream_ptr(),
+        ),
+        "duo_kv_append_bf16",
+    )
+
+
+def stream_compress(k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recent: int) -> int:
+    """In-place sink+recent update of a streaming pool [W, h, D] with new rows [S, h, D]; returns new length."""
+    lib = load_library()
+    new_len = c_int32(0)
+    n_heads = k_pool.shape[1]
+    if n_heads > 0 and k_new.shape[0] > 0:
+        for t, n in ((k_pool, "k_pool"), (v_pool, "v_pool"), (k_new, "k_new"), (v_new, "v_new")):
+            _require_gpu_bf16(t, n)
+        assert k_new.stride() == v_new.stride() and k_pool.stride() == v_pool.stride()
+        assert k_pool.shape[0] >= sink + recent
+    _check(
+        lib.duo_stream_compress_bf16(
+            k_pool.data_ptr() if n_heads else None, v_pool.data_ptr() if n_heads else None,
+            k_pool.stride(0), k_pool.stride(1), k_new.data_ptr() if n_heads else None,
+            v_new.data_ptr() if n_heads else None, k_new.stride(0), k_new.stride(1), n_heads, int(cur_len),
+            k_new.shape[0], int(sink), int(recent), HEAD_DIM, byref(new_len), _stream_ptr(),
+        ),
+        "duo_stream_compress_bf16",
+    )
+    return int(new_len.value)
+
+
+_DECODE_MAX_SPLITS = 512
+_workspaces = {}
+
+
+def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
+    """Per-device fp32 scratch for the split-KV partials (allocated once, reused every layer)."""
+    lib = load_library()
+    need = lib.duo_attn_decode_workspace_bytes(int(n_q_heads), _DECODE_MAX_SPLITS)
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def attn_decode(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
+                stream: Optional[HeadClass], scale: float):
+    """q, out: [Hq, D] views (one token).  Split-KV decode over both head classes."""
+    lib = load_library()
+    _require_gpu_bf16(q, "q")
+    _require_gpu_bf16(out, "out")
+    assert q.dim() == 2 and out.shape == q.shape
+    ws = decode_workspace(q.device, q.shape[0])
+    _check(
+        lib.duo_attn_decode_bf16(
+            q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), int(group),
+            byref(full) if full is not None else None, byref(stream) if stream is not None else None,
+            float(scale), q.shape[1], ws.data_ptr(), ws.numel() * 4, _stream_ptr(),
+        ),
+        "duo_attn_decode_bf16",
+    )
+
+
+def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
+                 stream: Optional[HeadClass], scale: float):
+    """q, out: [S, Hq, D] views.  MFMA flash attention over both head classes."""
+    lib = load_library()
+    _require_gpu_bf16(q, "q")
+    _require_gpu_bf16(out, "out")
+    assert q.dim() == 3 and out.shape == q.shape
+    _check(
+        lib.duo_attn_prefill_bf16(
+            q.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(), out.stride(0), out.stride(1), q.shape[0],
+            int(group), byref(full) if full is not None else None,
+            byref(stream) if stream is not None else None, float(scale), q.shape[2], _stream_ptr(),
+        ),
+        "duo_attn_prefill_bf16",
+    )
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """flashinfer.norm.rmsnorm semantics on [rows, hidden] bf16."""
+    lib = load_library()
+    _require_gpu_bf16(x, "x")
+    _require_gpu_bf16(weight, "weight")
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    y = torch.empty_like(x2)
+    _check(
+        lib.duo_rmsnorm_bf16(x2.data_ptr(), weight.contiguous().data_ptr(), y.data_ptr(), x2.shape[0],
+                             x2.shape[1], float(eps), _stream_ptr()),
+        "duo_rmsnorm_bf16",
+    )
+    return y.view(x.shape)
+
+
+def set_debug_flags(flags: int):
+    load_library().duo_set_debug_flags(int(flags))

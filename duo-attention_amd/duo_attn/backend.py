@@ -1,0 +1,81 @@
+"""Device backend of the DuoAttention hot path.
+
+The product ships exactly ONE backend: :class:`HipBackend`, a thin adapter from
+torch tensor views to the C-ABI library (``_hip.py``).  It refuses CPU tensors
+and raises if the library is missing — there is no CPU fallback.
+
+``_set_backend_for_testing`` exists so that the CPU test-suite can drive the
+*host plumbing* (patch API, cache bookkeeping, weight reordering, pipeline
+schedule) with the oracle from ``oracle/`` plugged in.  Nothing in this package
+imports ``oracle``.
+
+Tensor conventions (B = 1 slice already taken by the caller):
+    q, out          [S, Hq, D]   bf16 views, D contiguous
+    K/V segment     ([T, h, D], [T, h, D]) views or None
+    class desc      (n_kv_heads, q_head_offset, segA, segB)
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+Seg = Optional[Tuple[torch.Tensor, torch.Tensor]]
+ClassDesc = Optional[Tuple[int, int, Seg, Seg]]
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        from . import _hip
+
+        self._hip = _hip
+        _hip.load_library()  # fail loudly, now
+
+    # -- RoPE (flashinfer.rope.apply_rope_inplace; reference flashinfer_utils.py:29-59)
+    def rope_inplace(self, q, k, pos0: int, rope_scale: float, rope_theta: float):
+        self._hip.rope_inplace(q, k, pos0, rope_scale, rope_theta)
+
+    # -- pool[dst_row0 : dst_row0+S] = src   (reference static_kv_cache.py:109-125)
+    def kv_append(self, k_src, v_src, k_pool, v_pool, dst_row0: int):
+        self._hip.kv_append(k_src, v_src, k_pool, v_pool, dst_row0)
+
+    # -- sink+recent update in place (reference static_kv_cache.py:127-167); returns new length
+    def stream_compress(self, k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recent: int) -> int:
+        return self._hip.stream_compress(k_pool, v_pool, k_new, v_new, cur_len, sink, recent)
+
+    def _cls(self, desc: ClassDesc):
+        if desc is None or desc[0] <= 0:
+            return None
+        n_kv, q_off, a, b = desc
+        h = self._hip
+        return h.make_class(n_kv, q_off, h.make_seg(*(a or (None, None))), h.make_seg(*(b or (None, None))))
+
+    # -- the flash_attn_func calls of reference llama.py:364-421
+    def attention(self, q, out, group: int, full: ClassDesc, stream: ClassDesc, scale: float):
+        fc, sc = self._cls(full), self._cls(stream)
+        if q.shape[0] == 1:
+            self._hip.attn_decode(q[0], out[0], group, fc, sc, scale)
+        else:
+            self._hip.attn_prefill(q, out, group, fc, sc, scale)
+
+    # -- flashinfer.norm.rmsnorm (reference flashinfer_utils.py:9-16)
+    def rmsnorm(self, x, weight, eps: float):
+        return self._hip.rmsnorm(x, weight, eps)
+
+
+_backend = None
+
+
+def get_backend():
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def _set_backend_for_testing(backend):
+    """Test hook: plug a checker backend (the CPU oracle) in; ``None`` restores HIP."""
+    global _backend
+    _backend = backend

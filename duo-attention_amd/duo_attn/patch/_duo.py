@@ -1,0 +1,309 @@
+"""Family-agnostic DuoAttention forwards and enablers (Llama == Mistral).
+
+The reference keeps two 693-line copies (``duo_attn/patch/llama.py`` and
+``mistral.py``) that differ only by ``s/llama/mistral/``; here one
+implementation is parameterised by the HF module classes and re-exported under
+both names by ``llama.py`` / ``mistral.py``.
+
+Every attention call goes through ``backend.get_backend()`` — the HIP C-ABI
+library.  The projections (``nn.Linear`` -> hipBLASLt) are HF's own.
+
+Written against transformers 5.x: the attention module no longer has
+``num_heads`` / ``rotary_emb`` / ``rope_theta`` (reference llama.py:65,68,87,
+132,351) — shapes come from ``module.config`` and the tuple path's cos/sin are
+computed once per forward by ``model.rotary_emb``.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional, Tuple
+
+import torch
+
+from ..backend import get_backend
+from .flashinfer_utils import apply_rope_inplace, enable_flashinfer_rmsnorm
+from .static_kv_cache import DuoAttentionStaticKVCache, enable_duo_attention_static_kv_cache
+from .tuple_kv_cache import enable_tuple_kv_cache_for_model, hf_apply_rotary_pos_emb
+from .utils import reorder_full_attn_heads, reorder_linear_weights
+
+
+def _dims(module):
+    cfg = module.config
+    num_heads = cfg.num_attention_heads
+    num_kv = cfg.num_key_value_heads
+    head_dim = getattr(module, "head_dim", cfg.hidden_size // num_heads)
+    return num_heads, num_kv, head_dim, num_heads // num_kv
+
+
+def rope_scale_and_theta(config) -> Tuple[float, float]:
+    """rope_scale / rope_theta exactly as the static path reads them (reference llama.py:347-352):
+    ``rope_scaling["factor"]`` whatever the rope_type (linear scaling — a quirk that is part of the
+    contract), ``rope_theta`` from the config.  transformers 5.x folds both into ``rope_parameters``."""
+    rp = getattr(config, "rope_parameters", None) or {}
+    theta = rp.get("rope_theta", None)
+    if theta is None:
+        theta = getattr(config, "rope_theta", 10000.0)
+    scaling = getattr(config, "rope_scaling", None)
+    if scaling is None:
+        scaling = rp
+    scale = 1.0
+    if scaling:
+        f = scaling.get("factor", 1.0)
+        scale = 1.0 if f is None else float(f)
+    return scale, float(theta)
+
+
+def duo_static_attention_core(query_states, key_states, value_states, kv_cache, layer_idx, pos0,
+                              rope_scale, rope_theta):
+    """The hot path proper: everything between the q/k/v projections and o_proj in reference
+    llama.py:332-425 — RoPE in place, head split, full-pool append, split-head attention,
+    streaming-pool update.  q [B,S,Hq,D], k/v [B,S,Hkv,D] bf16; returns [B,S,Hq,D]."""
+    bsz, q_len, num_heads, head_dim = query_states.shape
+    num_kv = key_states.shape[2]
+    groups = num_heads // num_kv
+
+    past = kv_cache.kv_seq_len  # last layer's counter, as the reference reads it (:105-107)
+    kv_seq_len = q_len + past
+    if pos0 is None:
+        pos0 = past
+    apply_rope_inplace(query_states, key_states, pos0, rope_scale, rope_theta)
+
+    fk, fv, sk, sv = kv_cache.split_kv(layer_idx, key_states, value_states)
+    past_l = kv_cache.kv_seq_len_list[layer_idx]
+    kv_cache.put_full_kv(layer_idx, fk, fv)
+
+    be = get_backend()
+    attn_output = torch.empty_like(query_states)
+    scale = head_dim ** -0.5
+    if q_len == kv_seq_len:
+        # initial pre-filling: every head is causal over the chunk (:364-372)
+        for b in range(bsz):
+            be.attention(query_states[b], attn_output[b], groups,
+                         (num_kv, 0, None, (key_states[b], value_states[b])), None, scale)
+    else:
+        # decoding or continued filling (:374-421): retrieval heads over the full pool,
+        # streaming heads over [pool ++ new rows]; the concat is two kernel segments.
+        nf = kv_cache.num_full_kv_head_list[layer_idx]
+        ns = num_kv - nf
+        pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
+        ck, cv = kv_cache.get_streaming_kv(layer_idx)
+        for b in range(bsz):
+            full = (nf, 0, (pk[b, :past_l], pv[b, :past_l]),
+                    (pk[b, past_l:past_l + q_len], pv[b, past_l:past_l + q_len])) if nf > 0 else None
+            stream = (ns, nf * groups, (ck[b], cv[b]), (sk[b], sv[b])) if ns > 0 else None
+            be.attention(query_states[b], attn_output[b], groups, full, stream, scale)
+
+    kv_cache.update_streaming_kv(layer_idx, sk, sv)
+    return attn_output
+
+
+
+# =============================================================================
+# static dual-cache forward  (reference llama.py:309-434)
+# =============================================================================
+def duo_attention_forward_one_way_reordered_static(
+    self,
+    hidden_states: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    kv_cache: Optional[DuoAttentionStaticKVCache] = None,
+    layer_idx: int = None,
+    output_attentions: bool = False,
+    use_cache: bool = False,
+    pos0: Optional[int] = None,
+    **kwargs,
+):
+    bsz, q_len, _ = hidden_states.size()
+    num_heads, num_kv, head_dim, groups = _dims(self)
+
+    query_states = self.q_proj(hidden_states).view(bsz, q_len, num_heads, head_dim)
+    key_states = self.k_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
+    value_states = self.v_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
+
+    if pos0 is None and position_ids is not None:
+        pos0 = int(position_ids[0, 0])
+    rope_scale, rope_theta = rope_scale_and_theta(self.config)
+    attn_output = duo_static_attention_core(query_states, key_states, value_states, kv_cache, layer_idx,
+                                            pos0, rope_scale, rope_theta)
+
+    attn_output = attn_output.reshape(bsz, q_len, num_heads * head_dim)
+    attn_output = self.o_proj(attn_output)
+    return attn_output, None
+
+
+# =============================================================================
+# tuple-cache forward  (reference llama.py:146-306)
+#   past_key_value = (full_KV [2B, nf, N, D], streaming_KV [2B, ns, <=W, D])
+# =============================================================================
+def duo_attention_forward_one_way_reordered(
+    self,
+    hidden_states: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    past_key_value: Optional[Tuple[torch.Tensor]] = None,
+    output_attentions: bool = False,
+    use_cache: bool = False,
+    position_embeddings: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+    **kwargs,
+):
+    bsz, q_len, _ = hidden_states.size()
+    num_heads, num_kv, head_dim, groups = _dims(self)
+
+    query_states = self.q_proj(hidden_states).view(bsz, q_len, num_heads, head_dim)
+    key_states = self.k_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
+    value_states = self.v_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
+
+    kv_seq_len = q_len
+    if past_key_value is not None:
+        kv_seq_len += past_key_value[0].shape[2]
+
+    # HF rotary, as the reference's tuple path (:177-184)
+    cos, sin = position_embeddings
+    query_states, key_states = hf_apply_rotary_pos_emb(query_states, key_states, cos, sin, unsqueeze_dim=2)
+
+    if not hasattr(self, "full_attn_head_mask") or self.full_attn_head_mask is None:
+        self.full_attn_head_mask = self.full_attention_heads > 0.5
+        self.num_full_attn_head = int(self.full_attn_head_mask.sum().item())
+        self.num_streaming_attn_head = num_kv - self.num_full_attn_head
+        self.num_full_query_head = self.num_full_attn_head * groups
+        self.num_streaming_query_head = num_heads - self.num_full_query_head
+    nf, ns = self.num_full_attn_head, self.num_streaming_attn_head
+
+    full_key_states = key_states[:, :, :nf, :]
+    full_value_states = value_states[:, :, :nf, :]
+    streaming_key_states = key_states[:, :, nf:, :]
+    streaming_value_states = value_states[:, :, nf:, :]
+
+    be = get_backend()
+    attn_output = torch.empty_like(query_states)
+    scale = head_dim ** -0.5
+    if past_key_value is None or q_len == kv_seq_len:
+        for b in range(bsz):
+            be.attention(query_states[b], attn_output[b], groups,
+                         (num_kv, 0, None, (key_states[b], value_states[b])), None, scale)
+        if past_key_value is not None:  # zero-length past: keep the concatenations well-formed
+            past_full_KV = past_key_value[0].transpose(1, 2)
+            past_streaming_KV = past_key_value[1].transpose(1, 2)
+        else:
+            past_full_KV = past_streaming_KV = None
+    else:
+        past_full_KV = past_key_value[0].transpose(1, 2)        # [2B, N, nf, D]
+        past_streaming_KV = past_key_value[1].transpose(1, 2)   # [2B, n, ns, D]
+        for b in range(bsz):
+            full = (nf, 0, (past_full_KV[b], past_full_KV[bsz + b]),
+                    (full_key_states[b], full_value_states[b])) if nf > 0 else None
+            stream = (ns, nf * groups, (past_streaming_KV[b], past_streaming_KV[bsz + b]),
+                      (streaming_key_states[b], streaming_value_states[b])) if ns > 0 else None
+            be.attention(query_states[b], attn_output[b], groups, full, stream, scale)
+
+    # the tuple format's contract: the returned cache holds past ++ new (:202-223)
+    if past_full_KV is not None:
+        full_key_states = torch.cat([past_full_KV[:bsz], full_key_states], dim=1)
+        full_value_states = torch.cat([past_full_KV[bsz:], full_value_states], dim=1)
+        streaming_key_states = torch.cat([past_streaming_KV[:bsz], streaming_key_states], dim=1)
+        streaming_value_states = torch.cat([past_streaming_KV[bsz:], streaming_value_states], dim=1)
+
+    attn_output = attn_output.reshape(bsz, q_len, num_heads * head_dim)
+    attn_output = self.o_proj(attn_output)
+
+    # sink + recent truncation (:273-290)
+    if streaming_key_states.shape[1] > self.recent_size + self.sink_size:
+        W = self.sink_size + self.recent_size
+        streaming_key_states = torch.cat(
+            [streaming_key_states[:, : self.sink_size], streaming_key_states[:, -self.recent_size:]], dim=1
+        )[:, :W]
+        streaming_value_states = torch.cat(
+            [streaming_value_states[:, : self.sink_size], streaming_value_states[:, -self.recent_size:]], dim=1
+        )[:, :W]
+
+    past_key_value = (
+        (
+            torch.cat([full_key_states, full_value_states], dim=0).transpose(1, 2),
+            torch.cat([streaming_key_states, streaming_value_states], dim=0).transpose(1, 2),
+        )
+        if use_cache
+        else None
+    )
+    return attn_output, None, past_key_value
+
+
+# =============================================================================
+# enablers
+# =============================================================================
+def _reorder_layer(module, layer_full_attention_heads):
+    """q/k/v rows and o_proj columns permuted so retrieval heads come first (reference llama.py:523-546)."""
+    _, _, head_dim, groups = _dims(module)
+    module.q_proj = reorder_linear_weights(module.q_proj, layer_full_attention_heads, groups * head_dim, "out")
+    module.k_proj = reorder_linear_weights(module.k_proj, layer_full_attention_heads, head_dim, "out")
+    module.v_proj = reorder_linear_weights(module.v_proj, layer_full_attention_heads, head_dim, "out")
+    module.o_proj = reorder_linear_weights(module.o_proj, layer_full_attention_heads, groups * head_dim, "in")
+
+
+def enable_duo_attention_eval(model, full_attention_heads, sink_size, recent_size):
+    """Tuple-cache eval patch (reference llama.py:504-554)."""
+    enable_tuple_kv_cache_for_model(model)
+    device = next(model.parameters()).device
+    dtype = next(model.parameters()).dtype
+    for idx, layer in enumerate(model.model.layers):
+        module = layer.self_attn
+        layer_heads = torch.as_tensor(full_attention_heads[idx]).to(device=device, dtype=dtype)
+        module.forward = types.MethodType(duo_attention_forward_one_way_reordered, module)
+        _reorder_layer(module, layer_heads)
+        layer_heads = reorder_full_attn_heads(layer_heads)
+        module.sink_size = sink_size
+        module.recent_size = recent_size
+        module.full_attn_head_mask = None
+        module.register_buffer("full_attention_heads", layer_heads)
+
+
+def enable_duo_attention_static_kv_cache_eval(model, full_attention_heads):
+    """Static-cache eval patch (reference llama.py:557-598)."""
+    enable_duo_attention_static_kv_cache(model)
+    enable_flashinfer_rmsnorm(model)
+    device = next(model.parameters()).device
+    dtype = next(model.parameters()).dtype
+    for idx, layer in enumerate(model.model.layers):
+        module = layer.self_attn
+        layer_heads = torch.as_tensor(full_attention_heads[idx]).to(device=device, dtype=dtype)
+        module.forward = types.MethodType(duo_attention_forward_one_way_reordered_static, module)
+        _reorder_layer(module, layer_heads)
+
+
+def enable_duo_attention_training(model, sink_size, recent_size, max_length, initial_value=1.0,
+                                  enable_ulysses_attention=False, streaming_attn_implementation="blocksparse"):
+    raise NotImplementedError(
+        "Retrieval-head identification (training, reference llama.py:437-501) is outside the MI355X "
+        "hot-path scope; use the shipped attn_patterns."
+    )
+
+
+def _attn_modules(model):
+    inner = model.model if hasattr(model, "model") and hasattr(model.model, "layers") else model
+    if not hasattr(inner, "layers"):
+        raise ValueError("Model type not supported")
+    for layer in inner.layers:
+        yield layer.self_attn
+
+
+def get_full_attention_heads(model):
+    """reference llama.py:601-640 (single-process models; tensor_parallel wrappers are out of scope)."""
+    return [m.full_attention_heads for m in _attn_modules(model) if hasattr(m, "full_attention_heads")]
+
+
+def set_full_attention_heads(model, full_attention_heads):
+    """reference llama.py:643-672"""
+    for layer_idx, m in enumerate(_attn_modules(model)):
+        if not hasattr(m, "full_attention_heads"):
+            continue
+        m.full_attention_heads.data = full_attention_heads[layer_idx].to(
+            m.full_attention_heads.device, m.full_attention_heads.dtype
+        )
+        m.full_attn_head_mask = None
+    return model
+
+
+def map_full_attention_heads(model, func):
+    """reference llama.py:675-693"""
+    for m in _attn_modules(model):
+        if hasattr(m, "full_attention_heads"):
+            func(m.full_attention_heads)

@@ -1,0 +1,315 @@
+"""Static dual KV cache + the static-cache model forwards.
+
+Host-side mirror of the reference's ``duo_attn/patch/static_kv_cache.py``
+(``DuoAttentionStaticKVCache`` :18-315, model/layer/LM forwards :318-567 for
+llama and :570-820 for mistral — the two families are textually identical
+there, so one implementation serves both).
+
+MI355X-first differences that do not change the interface:
+  * pools are allocated HEAD-major ``[B, h, T, D]`` in HBM and exposed as the
+    reference's token-major *shape* ``[B, T, h, D]`` through a strided view, so
+    each kv head is one contiguous 256-B-row stream for the decode scan and one
+    contiguous 16-KiB block per 64-key MFMA tile; every slicing / ``copy_`` the
+    reference's callers do on these tensors still works;
+  * ``put_full_kv`` / ``compress_and_replace_streaming_kv`` move rows with HIP
+    kernels (``duo_kv_append_bf16`` / ``duo_stream_compress_bf16``) instead of
+    chains of ``copy_``; the streaming update takes the *new* rows and the pool
+    (two segments) — the reference's ``torch.cat`` is never materialised.
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import torch
+from transformers.modeling_outputs import BaseModelOutputWithPast, CausalLMOutputWithPast
+
+from ..backend import get_backend
+
+
+class DuoAttentionStaticKVCache:
+    """Same constructor, attributes and methods as reference static_kv_cache.py:18-315."""
+
+    def __init__(self, model, full_attention_heads, batch_size, max_size, sink_size, recent_size):
+        self.batch_size = batch_size
+        self.max_size = max_size
+        self.sink_size = sink_size
+        self.recent_size = recent_size
+
+        self.device = next(model.parameters()).device
+        self.dtype = next(model.parameters()).dtype
+        self.num_layers = model.config.num_hidden_layers
+        self.num_heads = model.config.num_attention_heads
+        self.num_kv_heads = model.config.num_key_value_heads
+        self.num_kv_groups = self.num_heads // self.num_kv_heads
+        self.head_dim = model.config.hidden_size // self.num_heads
+
+        self.num_full_kv_head_list = [0] * self.num_layers
+        self.num_streaming_kv_head_list = [0] * self.num_layers
+        self.kv_seq_len_list = [0] * self.num_layers
+        self.streaming_kv_seq_len_list = [0] * self.num_layers
+
+        self.streaming_key_states_list = []
+        self.streaming_value_states_list = []
+        self.full_key_states_list = []
+        self.full_value_states_list = []
+
+        W = self.sink_size + self.recent_size
+        for idx, layer_heads in enumerate(full_attention_heads):
+            mask = torch.as_tensor(layer_heads) > 0.5
+            nf = int(mask.sum().item())
+            ns = self.num_kv_heads - nf
+            self.num_full_kv_head_list[idx] = nf
+            self.num_streaming_kv_head_list[idx] = ns
+            self.streaming_key_states_list.append(self._alloc(W, ns))
+            self.streaming_value_states_list.append(self._alloc(W, ns))
+            self.full_key_states_list.append(self._alloc(self.max_size, nf))
+            self.full_value_states_list.append(self._alloc(self.max_size, nf))
+
+    def _alloc(self, rows, heads):
+        # physical [B, h, T, D]; logical (reference) shape [B, T, h, D]
+        buf = torch.zeros(self.batch_size, heads, rows, self.head_dim, device=self.device, dtype=self.dtype)
+        return buf.permute(0, 2, 1, 3)
+
+    # ------------------------------------------------------------------ counters
+    @property
+    def streaming_kv_seq_len(self):
+        return self.streaming_kv_seq_len_list[-1]
+
+    @property
+    def kv_seq_len(self):
+        return self.kv_seq_len_list[-1]
+
+    # ------------------------------------------------------------------ full pool
+    def put_full_kv(self, layer_idx, full_key_states, full_value_states):
+        incoming = full_key_states.shape[1]
+        cur = self.kv_seq_len_list[layer_idx]
+        if incoming + cur > self.max_size:
+            raise ValueError(
+                f"Trying to put {incoming} KVs into a cache with max size {self.max_size}, current size: {cur}."
+            )
+        be = get_backend()
+        kp, vp = self.full_key_states_list[layer_idx], self.full_value_states_list[layer_idx]
+        for b in range(full_key_states.shape[0]):
+            be.kv_append(full_key_states[b], full_value_states[b], kp[b], vp[b], cur)
+        self.kv_seq_len_list[layer_idx] += incoming
+        return self.get_full_kv(layer_idx)
+
+    def get_full_kv(self, layer_idx):
+        n = self.kv_seq_len_list[layer_idx]
+        return self.full_key_states_list[layer_idx][:, :n], self.full_value_states_list[layer_idx][:, :n]
+
+    # ------------------------------------------------------------------ streaming pool
+    def get_streaming_kv(self, layer_idx):
+        n = self.streaming_kv_seq_len_list[layer_idx]
+        return self.streaming_key_states_list[layer_idx][:, :n], self.streaming_value_states_list[layer_idx][:, :n]
+
+    def compress_and_replace_streaming_kv(self, layer_idx, streaming_key_states, streaming_value_states):
+        """Reference signature (static_kv_cache.py:127-167): the argument is the FULL logical
+        streaming sequence (``torch.cat([cached, new])``).  Kept for drop-in callers; the patched
+        forward uses :meth:`update_streaming_kv`, which never builds that concatenation."""
+        incoming = streaming_key_states.shape[1]
+        W = self.sink_size + self.recent_size
+        be = get_backend()
+        kp, vp = self.streaming_key_states_list[layer_idx], self.streaming_value_states_list[layer_idx]
+        if kp.shape[2] > 0:
+            # the input may alias the pool (the reference passes views of a fresh cat, never the
+            # pool itself); treat it as an independent tensor: pool := compress(input)
+            for b in range(streaming_key_states.shape[0]):
+                be.stream_compress(kp[b], vp[b], streaming_key_states[b], streaming_value_states[b], 0,
+                                   self.sink_size, self.recent_size)
+        self.streaming_kv_seq_len_list[layer_idx] = min(incoming, W)
+
+    def update_streaming_kv(self, layer_idx, new_key_states, new_value_states):
+        """pool := compress(pool[:len] ++ new) in one in-place kernel; same result as the reference's
+        cat + compress_and_replace_streaming_kv pair (llama.py:385-390,423-425)."""
+        cur = self.streaming_kv_seq_len_list[layer_idx]
+        W = self.sink_size + self.recent_size
+        be = get_backend()
+        kp, vp = self.streaming_key_states_list[layer_idx], self.streaming_value_states_list[layer_idx]
+        if kp.shape[2] > 0:
+            for b in range(new_key_states.shape[0]):
+                be.stream_compress(kp[b], vp[b], new_key_states[b], new_value_states[b], cur,
+                                   self.sink_size, self.recent_size)
+        self.streaming_kv_seq_len_list[layer_idx] = min(cur + new_key_states.shape[1], W)
+
+    # ------------------------------------------------------------------ views
+    def get(self, layer_idx):
+        return (*self.get_full_kv(layer_idx), *self.get_streaming_kv(layer_idx))
+
+    def get_unsliced(self, layer_idx):
+        return (
+            self.kv_seq_len_list[layer_idx],
+            self.full_key_states_list[layer_idx],
+            self.full_value_states_list[layer_idx],
+            self.streaming_kv_seq_len_list[layer_idx],
+            self.streaming_key_states_list[layer_idx],
+            self.streaming_value_states_list[layer_idx],
+        )
+
+    def split_kv(self, layer_idx, key_states, value_states):
+        nf = self.num_full_kv_head_list[layer_idx]
+        return (
+            key_states[:, :, :nf, :],
+            value_states[:, :, :nf, :],
+            key_states[:, :, nf:, :],
+            value_states[:, :, nf:, :],
+        )
+
+    def update_seq_len(self, layer_idx, incoming_kv_seq_len):
+        self.kv_seq_len_list[layer_idx] += incoming_kv_seq_len
+        self.streaming_kv_seq_len_list[layer_idx] += incoming_kv_seq_len
+
+    def clear(self):
+        for i in range(self.num_layers):
+            self.kv_seq_len_list[i] = 0
+            self.streaming_kv_seq_len_list[i] = 0
+
+    def evict_last(self, num_tokens):
+        for i in range(self.num_layers):
+            self.kv_seq_len_list[i] = max(0, self.kv_seq_len_list[i] - num_tokens)
+            self.streaming_kv_seq_len_list[i] = max(0, self.streaming_kv_seq_len_list[i] - num_tokens)
+
+    @property
+    def memory_usage(self):
+        total = 0
+        for lists in (self.full_key_states_list, self.full_value_states_list,
+                      self.streaming_key_states_list, self.streaming_value_states_list):
+            for t in lists:
+                total += t.element_size() * t.numel()
+        return total
+
+
+# =============================================================================
+# Static-cache forwards (reference static_kv_cache.py:318-567; llama == mistral)
+# =============================================================================
+def duo_attn_static_kv_cache_for_causal_lm_forward(
+    self,
+    input_ids: torch.LongTensor = None,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    past_key_values: Optional[DuoAttentionStaticKVCache] = None,
+    inputs_embeds: Optional[torch.FloatTensor] = None,
+    labels: Optional[torch.LongTensor] = None,
+    use_cache: Optional[bool] = None,
+    output_attentions: Optional[bool] = None,
+    output_hidden_states: Optional[bool] = None,
+    return_dict: Optional[bool] = None,
+    **kwargs,
+):
+    outputs = self.model(
+        input_ids=input_ids,
+        attention_mask=attention_mask,
+        position_ids=position_ids,
+        past_key_values=past_key_values,
+        inputs_embeds=inputs_embeds,
+        use_cache=use_cache,
+    )
+    hidden_states = outputs.last_hidden_state
+    if self.training:
+        logits = self.lm_head(hidden_states).float()
+    else:
+        # eval: logits for the last position only (reference :360-364)
+        logits = self.lm_head(hidden_states[:, -1:, :])
+    loss = None
+    if labels is not None:
+        shift_logits = logits[..., :-1, :].contiguous().view(-1, self.config.vocab_size)
+        shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
+        loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels)
+    return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=outputs.past_key_values)
+
+
+def duo_attn_static_kv_cache_model_forward(
+    self,
+    input_ids: torch.LongTensor = None,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    past_key_values: Optional[DuoAttentionStaticKVCache] = None,
+    inputs_embeds: Optional[torch.FloatTensor] = None,
+    use_cache: Optional[bool] = None,
+    **kwargs,
+):
+    if input_ids is not None and inputs_embeds is not None:
+        raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+    if input_ids is not None:
+        _, seq_length = input_ids.shape
+    elif inputs_embeds is not None:
+        _, seq_length, _ = inputs_embeds.shape
+    else:
+        raise ValueError("You have to specify either input_ids or inputs_embeds")
+
+    past_len = past_key_values.kv_seq_len if past_key_values is not None else 0
+    # The RoPE kernel takes the first position by value (the reference hands
+    # position_ids[:, 0] to flashinfer, llama.py:350-352).  With implicit positions
+    # that is just the cache length: no device read-back on the hot path.
+    if position_ids is None:
+        device = input_ids.device if input_ids is not None else inputs_embeds.device
+        position_ids = torch.arange(past_len, seq_length + past_len, dtype=torch.long, device=device)
+        position_ids = position_ids.unsqueeze(0).view(-1, seq_length)
+        pos0 = past_len
+    else:
+        position_ids = position_ids.view(-1, seq_length).long()
+        pos0 = int(position_ids[0, 0])
+
+    if inputs_embeds is None:
+        inputs_embeds = self.embed_tokens(input_ids)
+    hidden_states = inputs_embeds
+    for idx, decoder_layer in enumerate(self.layers):
+        hidden_states = decoder_layer(
+            hidden_states,
+            position_ids=position_ids,
+            kv_cache=past_key_values,
+            layer_idx=idx,
+            use_cache=use_cache,
+            pos0=pos0,
+        )[0]
+    hidden_states = self.norm(hidden_states)
+    return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
+
+
+def duo_attn_static_kv_cache_decoder_layer_forward(
+    self,
+    hidden_states: torch.Tensor,
+    attention_mask: Optional[torch.Tensor] = None,
+    position_ids: Optional[torch.LongTensor] = None,
+    kv_cache: Optional[DuoAttentionStaticKVCache] = None,
+    layer_idx: int = None,
+    output_attentions: Optional[bool] = False,
+    use_cache: Optional[bool] = False,
+    **kwargs,
+):
+    residual = hidden_states
+    hidden_states = self.input_layernorm(hidden_states)
+    hidden_states, _ = self.self_attn(
+        hidden_states=hidden_states,
+        position_ids=position_ids,
+        kv_cache=kv_cache,
+        layer_idx=layer_idx,
+        use_cache=use_cache,
+        **kwargs,
+    )
+    hidden_states = residual + hidden_states
+    residual = hidden_states
+    hidden_states = self.post_attention_layernorm(hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    hidden_states = residual + hidden_states
+    return (hidden_states,)
+
+
+def enable_duo_attention_static_kv_cache(model):
+    """Rebind LM / model / layer forwards (reference :554-567)."""
+    model.model.forward = types.MethodType(duo_attn_static_kv_cache_model_forward, model.model)
+    for layer in model.model.layers:
+        layer.forward = types.MethodType(duo_attn_static_kv_cache_decoder_layer_forward, layer)
+    model.forward = types.MethodType(duo_attn_static_kv_cache_for_causal_lm_forward, model)
+
+
+# family-named aliases, as imported by reference call sites
+enable_duo_attention_static_kv_cache_for_llama = enable_duo_attention_static_kv_cache
+enable_duo_attention_static_kv_cache_for_mistral = enable_duo_attention_static_kv_cache
+duo_attn_static_kv_cache_llama_for_causal_lm_forward = duo_attn_static_kv_cache_for_causal_lm_forward
+duo_attn_static_kv_cache_llama_model_forward = duo_attn_static_kv_cache_model_forward
+duo_attn_static_kv_cache_llama_decoder_layer_forward = duo_attn_static_kv_cache_decoder_layer_forward
+duo_attn_static_kv_cache_mistral_for_causal_lm_forward = duo_attn_static_kv_cache_for_causal_lm_forward
+duo_attn_static_kv_cache_mistral_model_forward = duo_attn_static_kv_cache_model_forward
+duo_attn_static_kv_cache_mistral_decoder_layer_forward = duo_attn_static_kv_cache_decoder_layer_forward

@@ -1,0 +1,93 @@
+"""Layer pipeline across the GPUs of one node: one process per GPU, RCCL point-to-point.
+
+The reference shards layers inside ONE process with accelerate hooks that copy hidden
+states device-to-device (``duo_attn/utils.py:228-283``: even contiguous split of the decoder
+layers, no collectives).  On MI355X the idiomatic form is one rank per GPU
+(``torch.distributed`` backend "nccl" == RCCL) and the only exchange the path has: the hidden
+state ``[B, S, hidden]`` crossing each stage boundary, sent point-to-point over a single xGMI
+link (no all-reduce / all-to-all anywhere on the inference path).
+
+Chunk-level pipelining is what makes prefill scale: chunk c on stage s depends only on chunk c
+from stage s-1 and chunk c-1 on stage s, so with n chunks and P stages the makespan is
+(n + P - 1) chunk-stage slots instead of n*P.  Receives are posted one item ahead and sends are
+asynchronous (double-buffered), so a stage computes item i while item i+1 arrives and item i-1
+leaves.  Decode at batch 1 is strictly sequential across stages (latency = sum of stages + hops);
+sharding it only multiplies KV capacity — this is reported as is.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .utils import even_layer_split
+
+
+class LayerPipeline:
+    def __init__(self, num_layers: int, rank: Optional[int] = None, world_size: Optional[int] = None,
+                 group=None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world_size = dist.get_world_size(group) if world_size is None else world_size
+        if self.world_size > num_layers:
+            raise ValueError(f"{self.world_size} stages for {num_layers} layers")
+        self.bounds: List[Tuple[int, int]] = even_layer_split(num_layers, self.world_size)
+        self.first_layer, self.last_layer = self.bounds[self.rank]
+
+    @property
+    def is_first(self):
+        return self.rank == 0
+
+    @property
+    def is_last(self):
+        return self.rank == self.world_size - 1
+
+    @property
+    def layers(self):
+        return range(self.first_layer, self.last_layer)
+
+    def run(self, shapes: Sequence[Tuple[int, ...]], stage_fn: Callable[[int, Optional[torch.Tensor]], torch.Tensor],
+            device, dtype=torch.bfloat16) -> List[Optional[torch.Tensor]]:
+        """Stream ``len(shapes)`` items (prefill chunks or decode tokens) through this rank's stage.
+
+        ``shapes[i]`` is the hand-off tensor shape of item i.  ``stage_fn(i, x)`` gets the hidden state
+        received from the previous stage (``None`` on the first stage, which owns the inputs) and
+        returns the hidden state for the next stage.  Returns the outputs of the LAST stage (a list
+        of ``None`` elsewhere)."""
+        n = len(shapes)
+        prev_rank, next_rank = self.rank - 1, self.rank + 1
+        recv_bufs = [None, None]
+        recv_work = [None, None]
+        send_work = [None, None]
+        keep_alive = [None, None]   # tensors of in-flight sends
+        outs: List[Optional[torch.Tensor]] = []
+
+        def post_recv(i):
+            if self.is_first or i >= n:
+                return
+            slot = i & 1
+            recv_bufs[slot] = torch.empty(shapes[i], device=device, dtype=dtype)
+            recv_work[slot] = dist.irecv(recv_bufs[slot], src=prev_rank, group=self.group)
+
+        post_recv(0)
+        for i in range(n):
+            slot = i & 1
+            x = None
+            if not self.is_first:
+                recv_work[slot].wait()
+                x = recv_bufs[slot]
+                post_recv(i + 1)          # next item's transfer overlaps this item's compute
+            y = stage_fn(i, x)
+            if self.is_last:
+                outs.append(y)
+            else:
+                if send_work[slot] is not None:
+                    send_work[slot].wait()   # the buffer of item i-2 has left
+                keep_alive[slot] = y.contiguous()
+                send_work[slot] = dist.isend(keep_alive[slot], dst=next_rank, group=self.group)
+                outs.append(None)
+        for w in send_work:
+            if w is not None:
+                w.wait()
+        return outs

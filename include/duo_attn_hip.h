@@ -1,0 +1,156 @@
+/*
+ * duo_attn_hip.h — C ABI of the MI355X (gfx950) DuoAttention hot path.
+ *
+ * This is the drop-in boundary below the Python patch API.  Every entry point
+ * takes plain device pointers, element strides and a hipStream_t (passed as
+ * void*); there are no torch types.  All tensors are bf16 unless stated.
+ * Return value: 0 on success, a hipError_t (>0) for a HIP failure, or a
+ * negative DUO_E* code for an argument error.  Nothing here falls back to the
+ * CPU: if the shared library is missing the Python host raises.
+ *
+ * What each entry point replaces in the reference (mit-han-lab/duo-attention):
+ *
+ *   duo_rope_inplace_bf16     flashinfer.rope.apply_rope_inplace as called from
+ *                             duo_attn/patch/flashinfer_utils.py:29-59
+ *                             (<- duo_attn/patch/llama.py:347-352)
+ *   duo_kv_append_bf16        DuoAttentionStaticKVCache.put_full_kv copy_ pair,
+ *                             duo_attn/patch/static_kv_cache.py:109-125
+ *   duo_stream_compress_bf16  DuoAttentionStaticKVCache
+ *                             .compress_and_replace_streaming_kv,
+ *                             duo_attn/patch/static_kv_cache.py:127-167
+ *                             (fed by the torch.cat at llama.py:385-390)
+ *   duo_attn_decode_bf16      the two flash_attn_func calls of the decode
+ *                             branch, duo_attn/patch/llama.py:392-421 (q_len==1)
+ *   duo_attn_prefill_bf16     flash_attn_func at llama.py:366-372 (first chunk,
+ *                             all heads causal) and llama.py:392-421 (later
+ *                             chunks, one call per head class)
+ *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
+ *   duo_int4_quantize_f16 / duo_int4_dequantize_f16
+ *                             demo/quantize_int4.cu:73-178 / :9-71
+ *
+ * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
+ * bottom-right aligned): a query at row i of the S new rows sees every key of
+ * segment A (the cached pool, lenA rows) and keys j <= i of segment B (the S
+ * new rows).  softmax scale = `scale`, fp32 softmax/accumulate, P rounded to
+ * bf16 before P.V, bf16 output.  GQA: q head h uses kv head h / group.
+ */
+#ifndef DUO_ATTN_HIP_H
+#define DUO_ATTN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DUO_ABI_VERSION 1
+
+/* argument errors (negative so they never collide with hipError_t) */
+#define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
+#define DUO_EHEADDIM (-2)  /* head_dim other than 128                         */
+#define DUO_EGROUP   (-3)  /* unsupported q-heads-per-kv-head group size      */
+#define DUO_EWORKSPC (-4)  /* workspace too small                             */
+
+/*
+ * One key/value source for one head class.  `k`/`v` point at (token 0, first
+ * kv head of the class, dim 0); element (t, h, d) lives at
+ * base + t*token_stride + h*head_stride + d   (strides in ELEMENTS, d
+ * contiguous).  This covers the reference's token-major [B, T, h, D] pools
+ * (static_kv_cache.py:60-99), head-major pools, and the freshly projected
+ * k/v activations [B, S, Hkv, D] alike.
+ */
+typedef struct duo_kv_seg {
+    const void *k;
+    const void *v;
+    int64_t token_stride;
+    int64_t head_stride;
+    int32_t len;   /* rows in this segment                                    */
+    int32_t _pad;
+} duo_kv_seg;
+
+/*
+ * One head class (retrieval = "full", or streaming) of one layer.
+ * Keys visible to the class are segA (entirely) then segB (causally).
+ * For the retrieval class after put_full_kv the pool already holds the new
+ * rows: pass segA = pool[:past], segB = pool[past:past+S].
+ * For the streaming class: segA = streaming pool[:len], segB = new k/v rows.
+ */
+typedef struct duo_head_class {
+    int32_t n_kv_heads;      /* 0 => class absent in this layer               */
+    int32_t q_head_offset;   /* first q head of the class (full heads first)  */
+    duo_kv_seg segA;
+    duo_kv_seg segB;
+} duo_head_class;
+
+int duo_abi_version(void);
+/* "gfx950" — the only architecture this library is built for */
+const char *duo_target_arch(void);
+const char *duo_error_string(int code);
+
+/* bit 0: prefill uses scalar LDS gathers instead of ds_read_b64_tr_b16 for V
+ *        (slow, debugging aid for the transpose-read layout);
+ * bit 1: decode skips the merge launch (output invalid; lets a profiler or a
+ *        HIP-event pair bracket the split-KV kernel alone).                   */
+void duo_set_debug_flags(uint32_t flags);
+uint32_t duo_get_debug_flags(void);
+
+/* ---- RoPE (NeoX / rotate-half, interleave=False) in place on q and k -------
+ * q: [n_tokens, n_q_heads, 128], k: [n_tokens, n_kv_heads, 128];
+ * position of token t = pos0 + t; angle = pos / rope_scale * theta^(-2i/128);
+ * fp32 trig, result rounded to bf16.                                          */
+int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride,
+                          int32_t n_q_heads, void *k, int64_t k_token_stride,
+                          int64_t k_head_stride, int32_t n_kv_heads,
+                          int32_t n_tokens, int64_t pos0, float rope_scale,
+                          float rope_theta, int32_t head_dim, void *stream);
+
+/* ---- copy S new rows of n_heads kv heads into a pool at row `dst_row0` ----- */
+int duo_kv_append_bf16(const void *k_src, const void *v_src,
+                       int64_t src_token_stride, int64_t src_head_stride,
+                       void *k_pool, void *v_pool, int64_t pool_token_stride,
+                       int64_t pool_head_stride, int32_t n_heads,
+                       int32_t n_tokens, int32_t dst_row0, int32_t head_dim,
+                       void *stream);
+
+/* ---- streaming pool update ------------------------------------------------
+ * Logical input = pool[:cur_len] ++ new[:n_new] (the torch.cat of
+ * llama.py:385-390).  If cur_len + n_new <= sink + recent the new rows are
+ * appended; otherwise the pool becomes  first `sink` rows ++ last `recent`
+ * rows of the logical input.  In place (overlap-safe).  Returns the new
+ * length through *new_len (host int).                                         */
+int duo_stream_compress_bf16(void *k_pool, void *v_pool,
+                             int64_t pool_token_stride, int64_t pool_head_stride,
+                             const void *k_new, const void *v_new,
+                             int64_t new_token_stride, int64_t new_head_stride,
+                             int32_t n_heads, int32_t cur_len, int32_t n_new,
+                             int32_t sink, int32_t recent, int32_t head_dim,
+                             int32_t *new_len, void *stream);
+
+/* ---- decode (S == 1): split-KV scan of both head classes in ONE launch,
+ *      followed by the merge launch.  q/out: [n_q_heads, 128] (row stride
+ *      q_head_stride / out_head_stride).  `workspace` holds fp32 partials;
+ *      duo_attn_decode_workspace_bytes() bounds the size needed.              */
+int64_t duo_attn_decode_workspace_bytes(int32_t n_q_heads, int32_t max_splits);
+int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
+                         int64_t out_head_stride, int32_t group,
+                         const duo_head_class *full, const duo_head_class *stream_cls,
+                         float scale, int32_t head_dim, void *workspace,
+                         int64_t workspace_bytes, void *stream);
+
+/* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
+ * q/out: [S, n_q_heads, 128] with the given token/head strides.               */
+int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride,
+                          int64_t q_head_stride, void *out,
+                          int64_t out_token_stride, int64_t out_head_stride,
+                          int32_t n_tokens, int32_t group,
+                          const duo_head_class *full, const duo_head_class *stream_cls,
+                          float scale, int32_t head_dim, void *stream);
+
+/* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
+int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,
+                     int32_t hidden, float eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUO_ATTN_HIP_H */

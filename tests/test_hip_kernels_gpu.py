@@ -1,0 +1,301 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes), against the CPU oracle.
+
+Tolerances (floating point path):
+  * data movement (append / compress): bit-exact;
+  * RoPE / RMSNorm: bf16 outputs equal to the oracle's up to 1 bf16 ulp on < 1 % of elements
+    (device sincos / rsqrt may differ from the host's by an fp32 ulp before the bf16 rounding);
+  * attention: helpers.attn_close — 1e-3 relative + one bf16 ulp of the value (+1e-3*rms floor).
+"""
+import itertools
+
+import pytest
+import torch
+
+from helpers import ShapeModel, attn_close, heads_from_counts
+from oracle.duo_oracle import (
+    StaticCacheRef,
+    flash_attn_func_ref,
+    rmsnorm_ref,
+    rope_ref,
+    static_forward_ref,
+)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+D = 128
+
+
+def _hip():
+    from duo_attn import _hip
+
+    _hip.load_library()
+    return _hip
+
+
+def _rand(shape, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(torch.bfloat16)
+
+
+def _ulp_close(ours, ref, what, max_frac=0.01):
+    """bf16 tensors equal except <= max_frac of elements, those off by at most one bf16 ulp."""
+    o, r = ours.cpu().float(), ref.cpu().float()
+    assert o.shape == r.shape, (o.shape, r.shape)
+    diff = (o - r).abs()
+    tol = torch.clamp(r.abs() * 2.0 ** -7, min=1e-5)
+    assert (diff <= tol).all(), f"{what}: max diff {diff.max():.3e} exceeds one bf16 ulp"
+    frac = (diff > 0).float().mean().item()
+    assert frac <= max_frac, f"{what}: {frac:.4%} elements differ"
+
+
+# ----------------------------------------------------------------------------- library
+def test_library_is_hip_gfx950():
+    h = _hip()
+    lib = h.load_library()
+    assert lib.duo_target_arch() == b"gfx950"
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+# ----------------------------------------------------------------------------- RoPE
+@pytest.mark.parametrize("pos0,scale,theta", [(0, 1.0, 1e4), (1000, 8.0, 1e4), (131072, 1.0, 3580165449.0),
+                                              (1_000_000, 1.0, 1e6)])
+def test_rope(pos0, scale, theta):
+    h = _hip()
+    g = torch.Generator().manual_seed(pos0 + 1)
+    S, Hq, Hkv = 37, 8, 2
+    q, k = _rand((S, Hq, D), g), _rand((S, Hkv, D), g)
+    # strided views like the projections' [S, H*D] outputs
+    qd, kd = q.to(DEV), k.to(DEV)
+    h.rope_inplace(qd, kd, pos0, scale, theta)
+    _ulp_close(qd, rope_ref(q, pos0, scale, theta), "rope q")
+    _ulp_close(kd, rope_ref(k, pos0, scale, theta), "rope k")
+
+
+# ----------------------------------------------------------------------------- append / compress
+@pytest.mark.parametrize("head_major", [True, False])
+def test_kv_append(head_major):
+    h = _hip()
+    g = torch.Generator().manual_seed(3)
+    T, nh, S, row0 = 300, 3, 70, 123
+    ks, vs = _rand((S, 5, D), g), _rand((S, 5, D), g)        # source has 5 heads, we append heads 1..3
+    if head_major:
+        kp = torch.zeros(nh, T, D, dtype=torch.bfloat16, device=DEV).permute(1, 0, 2)
+        vp = torch.zeros(nh, T, D, dtype=torch.bfloat16, device=DEV).permute(1, 0, 2)
+    else:
+        kp = torch.zeros(T, nh, D, dtype=torch.bfloat16, device=DEV)
+        vp = torch.zeros(T, nh, D, dtype=torch.bfloat16, device=DEV)
+    h.kv_append(ks.to(DEV)[:, 1:4], vs.to(DEV)[:, 1:4], kp, vp, row0)
+    ek = torch.zeros(T, nh, D, dtype=torch.bfloat16)
+    ev = torch.zeros(T, nh, D, dtype=torch.bfloat16)
+    ek[row0:row0 + S] = ks[:, 1:4]
+    ev[row0:row0 + S] = vs[:, 1:4]
+    assert torch.equal(kp.cpu(), ek) and torch.equal(vp.cpu(), ev)
+
+
+@pytest.mark.parametrize(
+    "sink,recent,cur,n_new",
+    [(128, 256, 0, 1), (128, 256, 0, 300), (128, 256, 0, 1000), (128, 256, 10, 5), (128, 256, 383, 1),
+     (128, 256, 384, 1), (128, 256, 384, 300), (128, 256, 200, 4096), (4, 8, 12, 1), (4, 8, 3, 2),
+     (16, 64, 80, 7), (64, 256, 100, 400), (0, 8, 8, 3), (4, 300, 304, 1), (4, 300, 304, 777)],
+)
+@pytest.mark.parametrize("head_major", [True, False])
+def test_stream_compress(sink, recent, cur, n_new, head_major):
+    from oracle.duo_oracle import OracleBackend
+
+    h = _hip()
+    g = torch.Generator().manual_seed(cur * 7 + n_new)
+    W, nh = sink + recent, 3
+    pool_k, pool_v = _rand((W, nh, D), g), _rand((W, nh, D), g)
+    new_k, new_v = _rand((n_new, nh, D), g), _rand((n_new, nh, D), g)
+    if head_major:
+        kp = pool_k.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+        vp = pool_v.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+    else:
+        kp, vp = pool_k.to(DEV), pool_v.to(DEV)
+    n = h.stream_compress(kp, vp, new_k.to(DEV), new_v.to(DEV), cur, sink, recent)
+    ek, ev = pool_k.clone(), pool_v.clone()
+    en = OracleBackend().stream_compress(ek, ev, new_k, new_v, cur, sink, recent)
+    assert n == en
+    assert torch.equal(kp.cpu()[:n], ek[:n]) and torch.equal(vp.cpu()[:n], ev[:n])
+    # rows past the live length are untouched
+    assert torch.equal(kp.cpu()[n:], pool_k[n:])
+
+
+# ----------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("rows,hidden", [(1, 4096), (33, 4096), (5, 512), (7, 1024 + 8)])
+def test_rmsnorm(rows, hidden):
+    h = _hip()
+    g = torch.Generator().manual_seed(rows)
+    x, w = _rand((rows, hidden), g, 3.0), _rand((hidden,), g)
+    y = h.rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
+    _ulp_close(y, rmsnorm_ref(x, w, 1e-5), "rmsnorm", max_frac=0.02)
+
+
+# ----------------------------------------------------------------------------- attention
+def _make_pool(T, nh, gen, head_major):
+    k, v = _rand((T, nh, D), gen), _rand((T, nh, D), gen)
+    if head_major:
+        kd = k.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+        vd = v.permute(1, 0, 2).contiguous().to(DEV).permute(1, 0, 2)
+    else:
+        kd, vd = k.to(DEV), v.to(DEV)
+    return k, v, kd, vd
+
+
+def _attention_case(S, group, nf, ns, lenA_full, lenA_stream, head_major, seed, first_chunk=False):
+    """Build inputs, run the HIP path through the backend adapter, return (ours, oracle fp32)."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(seed)
+    Hq = (nf + ns) * group
+    q = _rand((S, Hq, D), g)
+    k_new, v_new = _rand((S, nf + ns, D), g), _rand((S, nf + ns, D), g)
+    qd, knd, vnd = q.to(DEV), k_new.to(DEV), v_new.to(DEV)
+    out = torch.full((S, Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    be = HipBackend()
+    scale = D ** -0.5
+    ref = torch.empty(S, Hq, D, dtype=torch.float32)
+    if first_chunk:
+        be.attention(qd, out, group, (nf + ns, 0, None, (knd, vnd)), None, scale)
+        ref = flash_attn_func_ref(q[None], k_new[None], v_new[None], out_dtype=torch.float32)[0]
+        return out, ref
+    full = stream = None
+    if nf:
+        fk, fv, fkd, fvd = _make_pool(lenA_full, nf, g, head_major)
+        full = (nf, 0, (fkd, fvd) if lenA_full else None, (knd[:, :nf], vnd[:, :nf]))
+        kk = torch.cat([fk, k_new[:, :nf]], 0)
+        vv = torch.cat([fv, v_new[:, :nf]], 0)
+        ref[:, :nf * group] = flash_attn_func_ref(q[None, :, :nf * group], kk[None], vv[None],
+                                                   out_dtype=torch.float32)[0]
+    if ns:
+        sk, sv, skd, svd = _make_pool(lenA_stream, ns, g, head_major)
+        stream = (ns, nf * group, (skd, svd) if lenA_stream else None, (knd[:, nf:], vnd[:, nf:]))
+        kk = torch.cat([sk, k_new[:, nf:]], 0)
+        vv = torch.cat([sv, v_new[:, nf:]], 0)
+        ref[:, nf * group:] = flash_attn_func_ref(q[None, :, nf * group:], kk[None], vv[None],
+                                                   out_dtype=torch.float32)[0]
+    be.attention(qd, out, group, full, stream, scale)
+    return out, ref
+
+
+DECODE_CASES = [
+    # group, nf, ns, N_full, n_stream
+    (4, 1, 1, 1, 1), (4, 2, 6, 17, 5), (4, 4, 4, 255, 384), (4, 8, 0, 256, 0), (4, 0, 8, 0, 383),
+    (4, 3, 5, 257, 384), (4, 1, 7, 1000, 384), (4, 5, 3, 5000, 384), (4, 2, 2, 40000, 384),
+    (1, 8, 24, 3000, 384), (2, 3, 1, 777, 100), (8, 1, 1, 2049, 50), (3, 2, 2, 515, 30), (6, 1, 1, 300, 7),
+]
+
+
+@pytest.mark.parametrize("case", DECODE_CASES)
+@pytest.mark.parametrize("head_major", [True, False])
+def test_decode(case, head_major):
+    group, nf, ns, n_full, n_stream = case
+    out, ref = _attention_case(1, group, nf, ns, n_full, n_stream, head_major, seed=hash(case) % 1000)
+    attn_close(out, ref, f"decode {case} hm={head_major}")
+
+
+PREFILL_CASES = [
+    # S, group, nf, ns, lenA_full, lenA_stream
+    (2, 4, 1, 1, 3, 2), (31, 4, 1, 1, 64, 100), (64, 4, 2, 2, 5, 384), (100, 4, 1, 3, 1000, 384),
+    (256, 4, 1, 1, 256, 384), (257, 4, 2, 0, 300, 0), (300, 4, 0, 2, 0, 384), (513, 1, 2, 2, 77, 10),
+    (1000, 4, 1, 1, 1000, 384), (129, 2, 1, 1, 63, 65), (700, 8, 1, 0, 129, 0),
+]
+
+
+@pytest.mark.parametrize("case", PREFILL_CASES)
+@pytest.mark.parametrize("head_major", [True, False])
+def test_prefill_later_chunk(case, head_major):
+    S, group, nf, ns, la, ls = case
+    out, ref = _attention_case(S, group, nf, ns, la, ls, head_major, seed=hash(case) % 1000)
+    attn_close(out, ref, f"prefill {case} hm={head_major}")
+
+
+@pytest.mark.parametrize("S,group,nkv", [(2, 4, 2), (65, 4, 2), (256, 4, 1), (300, 1, 4), (1025, 4, 2)])
+def test_prefill_first_chunk(S, group, nkv):
+    out, ref = _attention_case(S, group, nkv, 0, 0, 0, True, seed=S, first_chunk=True)
+    attn_close(out, ref, f"first chunk S={S}")
+
+
+def test_prefill_without_transpose_read_matches():
+    """ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
+    h = _hip()
+    case = (300, 4, 1, 1, 200, 384)
+    out_tr, ref = _attention_case(*case, True, seed=5)
+    h.set_debug_flags(1)
+    try:
+        out_gather, _ = _attention_case(*case, True, seed=5)
+    finally:
+        h.set_debug_flags(0)
+    attn_close(out_gather, ref, "prefill (gather V path)")
+    assert torch.equal(out_tr.cpu(), out_gather.cpu())
+
+
+def test_softmax_rescale_branch_spike():
+    """A key late in the sequence that dominates every earlier score forces the online-softmax
+    rescale path (m jumps by >> 8 in the last tiles)."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(11)
+    S, group = 320, 4
+    q = _rand((S, group, D), g)
+    k, v = _rand((S, 1, D), g), _rand((S, 1, D), g)
+    k[300, 0] = (q[310, 1].float() * 4).to(torch.bfloat16)    # spike for (row 310, head 1) at key 300
+    out = torch.empty(S, group, D, dtype=torch.bfloat16, device=DEV)
+    HipBackend().attention(q.to(DEV), out, group, (1, 0, None, (k.to(DEV), v.to(DEV))), None, D ** -0.5)
+    ref = flash_attn_func_ref(q[None], k[None], v[None], out_dtype=torch.float32)[0]
+    attn_close(out, ref, "spike")
+
+
+# ----------------------------------------------------------------------------- whole hot path
+@pytest.mark.parametrize(
+    "counts,Hq,Hkv,chunks,sink,recent",
+    [
+        ([1, 2, 0, 4], 16, 4, (300, 129, 64), 16, 48),
+        ([2, 6], 32, 8, (520, 520), 128, 256),
+        ([3], 4, 4, (100, 300, 77), 4, 8),
+    ],
+)
+def test_static_hot_path_chunked_prefill_then_decode(counts, Hq, Hkv, chunks, sink, recent):
+    """duo_static_attention_core on the GPU (RoPE -> append -> split-head attention -> streaming update)
+    vs the oracle's restatement of reference llama.py:309-434, chunk after chunk, then 4 decode steps
+    with the benchmark's evict_last(1) protocol (reference benchmark_static.py:96-105)."""
+    from duo_attn.patch._duo import duo_static_attention_core
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    L = len(counts)
+    heads = heads_from_counts(counts, Hkv)
+    total = sum(chunks) + 8
+    cache = DuoAttentionStaticKVCache(ShapeModel(L, Hq, Hkv, D, device=DEV), heads, 1, total, sink, recent)
+    ref = StaticCacheRef(L, Hkv, D, heads, 1, total, sink, recent)
+    g = torch.Generator().manual_seed(42)
+    theta, rscale = 3580165449.0, 1.0
+    pos = 0
+    steps = [(S, False) for S in chunks] + [(1, True)] * 4
+    for S, evict in steps:
+        for l in range(L):
+            q, k, v = _rand((1, S, Hq, D), g), _rand((1, S, Hkv, D), g), _rand((1, S, Hkv, D), g)
+            out = duo_static_attention_core(q.to(DEV), k.to(DEV), v.to(DEV), cache, l, pos, rscale, theta)
+            exp = static_forward_ref(q, k, v, ref, l, pos, rscale, theta, out_dtype=torch.float32)
+            attn_close(out, exp, f"S={S} layer={l} pos={pos}")
+            n, m = ref.kv_seq_len_list[l], ref.streaming_kv_seq_len_list[l]
+            assert cache.kv_seq_len_list[l] == n and cache.streaming_kv_seq_len_list[l] == m
+            _ulp_close(cache.full_key_states_list[l][:, :n], ref.full_key_states_list[l][:, :n], "full K pool")
+            assert torch.equal(cache.full_value_states_list[l][:, :n].cpu(), ref.full_value_states_list[l][:, :n])
+            _ulp_close(cache.streaming_key_states_list[l][:, :m], ref.streaming_key_states_list[l][:, :m],
+                       "stream K pool")
+            assert torch.equal(cache.streaming_value_states_list[l][:, :m].cpu(),
+                               ref.streaming_value_states_list[l][:, :m])
+            # keep both sides on identical pool contents so later steps compare attention only
+            ref.full_key_states_list[l][:, :n].copy_(cache.full_key_states_list[l][:, :n].cpu())
+            ref.streaming_key_states_list[l][:, :m].copy_(cache.streaming_key_states_list[l][:, :m].cpu())
+        if evict:
+            cache.evict_last(1)
+            ref.evict_last(1)
+        else:
+            pos += S
+
+
+def test_cpu_tensor_is_refused():
+    h = _hip()
+    q = torch.zeros(4, 4, D, dtype=torch.bfloat16)
+    with pytest.raises(h.DuoHipError, match="no CPU fallback"):
+        h.rope_inplace(q, q, 0, 1.0, 1e4)

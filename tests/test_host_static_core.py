@@ -1,0 +1,120 @@
+"""Host plumbing of the static dual-cache path on CPU, with the oracle plugged in as backend.
+
+Checks the product's control flow (duo_static_attention_core + DuoAttentionStaticKVCache with its
+head-major pools, two-segment attention descriptors and in-place streaming update) against the
+oracle's procedural restatement of reference llama.py:309-434 — bit-exact, both use the same math.
+"""
+import pytest
+import torch
+
+from helpers import ShapeModel, heads_from_counts
+from oracle.duo_oracle import StaticCacheRef, duo_visible_mask, flash_attn_func_ref, static_forward_ref
+
+
+def _run(counts, Hq, Hkv, chunks, sink, recent, seed=0, decode_steps=3):
+    from duo_attn.patch._duo import duo_static_attention_core
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    D = 128
+    L = len(counts)
+    heads = heads_from_counts(counts, Hkv)
+    total = sum(chunks) + decode_steps
+    model = ShapeModel(L, Hq, Hkv, D)
+    cache = DuoAttentionStaticKVCache(model, heads, 1, total + 5, sink, recent)
+    ref = StaticCacheRef(L, Hkv, D, heads, 1, total + 5, sink, recent)
+    g = torch.Generator().manual_seed(seed)
+    pos = 0
+    for S in list(chunks) + [1] * decode_steps:
+        for l in range(L):
+            q = torch.randn(1, S, Hq, D, generator=g).to(torch.bfloat16)
+            k = torch.randn(1, S, Hkv, D, generator=g).to(torch.bfloat16)
+            v = torch.randn(1, S, Hkv, D, generator=g).to(torch.bfloat16)
+            out = duo_static_attention_core(q.clone(), k.clone(), v.clone(), cache, l, pos, 1.0, 10000.0)
+            exp = static_forward_ref(q.clone(), k.clone(), v.clone(), ref, l, pos, 1.0, 10000.0)
+            assert torch.equal(out, exp), (S, l)
+            n, ns_len = ref.kv_seq_len_list[l], ref.streaming_kv_seq_len_list[l]
+            assert cache.kv_seq_len_list[l] == n and cache.streaming_kv_seq_len_list[l] == ns_len
+            assert torch.equal(cache.full_key_states_list[l][:, :n], ref.full_key_states_list[l][:, :n])
+            assert torch.equal(cache.full_value_states_list[l][:, :n], ref.full_value_states_list[l][:, :n])
+            assert torch.equal(cache.streaming_key_states_list[l][:, :ns_len],
+                               ref.streaming_key_states_list[l][:, :ns_len])
+            assert torch.equal(cache.streaming_value_states_list[l][:, :ns_len],
+                               ref.streaming_value_states_list[l][:, :ns_len])
+        pos += S
+    return cache, ref
+
+
+@pytest.mark.parametrize(
+    "counts,Hq,Hkv,chunks,sink,recent",
+    [
+        ([1, 2, 0, 4], 8, 4, (7, 9, 20), 4, 8),      # ragged split incl. nf=0 and nf=Hkv
+        ([2, 1], 4, 4, (30,), 8, 16),                # MHA, single-shot prefill
+        ([1, 3], 8, 4, (5, 5, 5, 5), 2, 3),          # pool saturates mid-way
+    ],
+)
+def test_core_matches_reference_control_flow(oracle_backend, counts, Hq, Hkv, chunks, sink, recent):
+    _run(counts, Hq, Hkv, chunks, sink, recent)
+
+
+def test_evict_last_and_clear(oracle_backend):
+    cache, ref = _run([1, 1], 4, 2, (12,), 2, 4, decode_steps=2)
+    cache.evict_last(1)
+    ref.evict_last(1)
+    assert cache.kv_seq_len_list == ref.kv_seq_len_list
+    assert cache.streaming_kv_seq_len_list == ref.streaming_kv_seq_len_list
+    cache.clear()
+    assert cache.kv_seq_len == 0 and cache.streaming_kv_seq_len == 0
+
+
+def test_overflow_raises(oracle_backend):
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    cache = DuoAttentionStaticKVCache(ShapeModel(1, 2, 2), [[1.0, 0.0]], 1, 4, 1, 2)
+    k = torch.zeros(1, 5, 1, 128, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="Trying to put 5 KVs into a cache with max size 4, current size: 0."):
+        cache.put_full_kv(0, k, k)
+
+
+def test_memory_usage_matches_reference_formula(oracle_backend):
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    counts, Hkv, max_size, sink, recent = [1, 3, 0], 4, 50, 4, 8
+    cache = DuoAttentionStaticKVCache(ShapeModel(3, 8, Hkv), heads_from_counts(counts, Hkv), 1, max_size,
+                                      sink, recent)
+    exp = sum(2 * 2 * 128 * (nf * max_size + (Hkv - nf) * (sink + recent)) for nf in counts)
+    assert cache.memory_usage == exp
+    # reference-visible shapes are token-major
+    assert tuple(cache.full_key_states_list[1].shape) == (1, max_size, 3, 128)
+    assert tuple(cache.streaming_key_states_list[1].shape) == (1, sink + recent, 1, 128)
+
+
+@pytest.mark.parametrize("N,S", [(0, 9), (5, 4), (12, 3), (40, 1), (13, 6)])
+def test_procedural_semantics_equal_closed_form_mask(N, S):
+    """static_forward_ref (procedural: cat, bottom-right causal, compress) == dense attention under the
+    closed-form visibility mask of SURVEY §8(a7), for a chunk of S tokens after N cached tokens fed in
+    ONE earlier call."""
+    D, sink, recent = 128, 4, 8
+    g = torch.Generator().manual_seed(1)
+    heads = [[1.0, 0.0]]
+    ref = StaticCacheRef(1, 2, D, heads, 1, N + S + 1, sink, recent)
+    allk, allv = [], []
+    outs = None
+    pos = 0
+    for n in ([N] if N else []) + [S]:
+        q = torch.randn(1, n, 4, D, generator=g).to(torch.bfloat16)
+        k = torch.randn(1, n, 2, D, generator=g).to(torch.bfloat16)
+        v = torch.randn(1, n, 2, D, generator=g).to(torch.bfloat16)
+        kk = k.clone()
+        outs = static_forward_ref(q, kk, v, ref, 0, pos, 1.0, 10000.0, round_p=False, out_dtype=torch.float32)
+        allk.append(kk)   # rotated in place
+        allv.append(v)
+        pos += n
+    K, V = torch.cat(allk, dim=1), torch.cat(allv, dim=1)
+    for h, kind in ((0, "full"), (1, "stream")):
+        vis = duo_visible_mask(kind, N, S, sink, recent)
+        for gq in range(2):
+            qh = q[0, :, 2 * h + gq].float()
+            s = (qh @ K[0, :, h].float().T) / (D ** 0.5)
+            s = s.masked_fill(~vis, float("-inf"))
+            exp = torch.softmax(s, -1) @ V[0, :, h].float()
+            torch.testing.assert_close(outs[0, :, 2 * h + gq], exp, rtol=1e-5, atol=1e-5)
