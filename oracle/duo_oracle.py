@@ -77,8 +77,12 @@ def apply_rope_inplace_ref(q: torch.Tensor, k: torch.Tensor, offsets, rope_scale
 
 # ----------------------------------------------------------------------------- attention
 def flash_attn_func_ref(q, k, v, causal=True, dropout_p=0.0, softmax_scale=None, round_p=True,
-                        out_dtype=None):
-    """Dense restatement of flash_attn_func.  q [B,Sq,Hq,D]; k,v [B,Sk,Hkv,D]."""
+                        out_dtype=None, return_budget=False):
+    """Dense restatement of flash_attn_func.  q [B,Sq,Hq,D]; k,v [B,Sk,Hkv,D].
+
+    ``return_budget``: also return A = softmax(S) . |V| (fp32, same shape as the output).  An
+    implementation that rounds P to bf16 before P.V (FA2, and this repo's MFMA kernel) may differ from
+    the exact result by at most 2^-9 * A per element (each p_j carries a relative error <= 2^-9)."""
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
     G = Hq // Hkv
@@ -99,8 +103,11 @@ def flash_attn_func_ref(q, k, v, causal=True, dropout_p=0.0, softmax_scale=None,
         o = torch.matmul(e.to(q.dtype).float(), vf) / l
     else:
         o = torch.matmul(torch.softmax(s, dim=-1), vf)
-    o = o.permute(0, 2, 1, 3)
-    return o.to(out_dtype or q.dtype)
+    o = o.permute(0, 2, 1, 3).to(out_dtype or q.dtype)
+    if return_budget:
+        a = torch.matmul(torch.softmax(s, dim=-1), vf.abs()).permute(0, 2, 1, 3)
+        return o, a
+    return o
 
 
 def duo_visible_mask(kind: str, N: int, S: int, sink: int, recent: int) -> torch.Tensor:
@@ -202,10 +209,11 @@ class StaticCacheRef:
 
 
 def static_forward_ref(q, k, v, cache: StaticCacheRef, layer_idx: int, pos0: int, rope_scale: float,
-                       rope_theta: float, round_p=True, out_dtype=None):
+                       rope_theta: float, round_p=True, out_dtype=None, return_budget=False):
     """Post-projection part of llama_duo_attention_forward_one_way_reordered_static
     (reference llama.py:309-434).  q [B,S,Hq,D], k/v [B,S,Hkv,D] (pre-RoPE; rotated in place like
-    the reference).  Returns attn_output [B,S,Hq,D] before o_proj."""
+    the reference).  Returns attn_output [B,S,Hq,D] before o_proj (and the P-rounding error budget
+    of flash_attn_func_ref when ``return_budget``)."""
     B, S, Hq, D = q.shape
     Hkv = k.shape[2]
     G = Hq // Hkv
@@ -213,8 +221,9 @@ def static_forward_ref(q, k, v, cache: StaticCacheRef, layer_idx: int, pos0: int
     apply_rope_inplace_ref(q, k, pos0, rope_scale, rope_theta)
     fk, fv, sk, sv = cache.split_kv(layer_idx, k, v)
     fk, fv = cache.put_full_kv(layer_idx, fk, fv)
+    kw = dict(causal=True, round_p=round_p, out_dtype=out_dtype, return_budget=True)
     if S == kv_seq_len:
-        out = flash_attn_func_ref(q, k, v, causal=True, round_p=round_p, out_dtype=out_dtype)
+        out, bud = flash_attn_func_ref(q, k, v, **kw)
     else:
         nfq = cache.num_full_kv_head_list[layer_idx] * G
         ck, cv = cache.get_streaming_kv(layer_idx)
@@ -222,14 +231,13 @@ def static_forward_ref(q, k, v, cache: StaticCacheRef, layer_idx: int, pos0: int
         sv = torch.cat([cv, sv], dim=1)
         outs = []
         if nfq > 0:
-            outs.append(flash_attn_func_ref(q[:, :, :nfq], fk, fv, causal=True, round_p=round_p,
-                                            out_dtype=out_dtype))
+            outs.append(flash_attn_func_ref(q[:, :, :nfq], fk, fv, **kw))
         if Hq - nfq > 0:
-            outs.append(flash_attn_func_ref(q[:, :, nfq:], sk, sv, causal=True, round_p=round_p,
-                                            out_dtype=out_dtype))
-        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
+            outs.append(flash_attn_func_ref(q[:, :, nfq:], sk, sv, **kw))
+        out = outs[0][0] if len(outs) == 1 else torch.cat([o[0] for o in outs], dim=2)
+        bud = outs[0][1] if len(outs) == 1 else torch.cat([o[1] for o in outs], dim=2)
     cache.compress_and_replace_streaming_kv(layer_idx, sk, sv)
-    return out
+    return (out, bud) if return_budget else out
 
 
 def tuple_forward_ref(q, k, v, past: Optional[Tuple[torch.Tensor, torch.Tensor]], nf: int, sink: int,
