@@ -1,0 +1,119 @@
+"""The C-ABI library loads without a GPU and exports every symbol the header declares; the Python
+package exposes the reference's public surface.  No compute calls here."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "duo_attn_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(duo_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported_and_typed():
+    from duo_attn import _hip
+
+    lib = _hip.load_library()
+    declared = _declared_functions()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/duo_attn_hip.h but not exported"
+    assert set(declared) == set(_hip.EXPORTED_SYMBOLS), "ctypes binding and header disagree"
+    assert lib.duo_abi_version() == _hip.ABI_VERSION
+    assert lib.duo_target_arch() == b"gfx950"
+    assert b"head_dim" in lib.duo_error_string(-2)
+
+
+def test_struct_layout_matches_header():
+    from duo_attn import _hip
+
+    assert ctypes.sizeof(_hip.KVSeg) == 40          # 2 ptr + 2 int64 + 2 int32
+    assert ctypes.sizeof(_hip.HeadClass) == 8 + 2 * 40
+    assert _hip.HeadClass.segA.offset == 8 and _hip.HeadClass.segB.offset == 48
+
+
+def test_argument_errors_without_gpu():
+    """argument validation happens on the host before any launch"""
+    from duo_attn import _hip
+
+    lib = _hip.load_library()
+    assert lib.duo_attn_decode_workspace_bytes(32, 512) == 32 * 512 * 130 * 4
+    rc = lib.duo_rope_inplace_bf16(None, 0, 0, 0, None, 0, 0, 0, 4, 0, 1.0, 1e4, 64, None)
+    assert rc == -2   # DUO_EHEADDIM
+    rc = lib.duo_attn_prefill_bf16(None, 0, 0, None, 0, 0, 4, 4, None, None, 1.0, 128, None)
+    assert rc == -1   # DUO_EINVAL (null q)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from duo_attn import _hip
+
+    with pytest.raises(_hip.DuoHipError, match="no CPU fallback"):
+        _hip.load_library(str(tmp_path / "nope.so"))
+
+
+def test_cpu_tensors_are_refused():
+    from duo_attn import _hip
+
+    q = torch.zeros(2, 4, 128, dtype=torch.bfloat16)
+    with pytest.raises(_hip.DuoHipError, match="no CPU fallback"):
+        _hip.rope_inplace(q, q, 0, 1.0, 1e4)
+    with pytest.raises(_hip.DuoHipError, match="no CPU fallback"):
+        _hip.attn_prefill(q, torch.empty_like(q), 1, None, None, 1.0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "duo-attention_amd", "duo_attn")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_public_api_surface():
+    import duo_attn.patch as P
+    import duo_attn.patch.llama as L
+    import duo_attn.patch.mistral as M
+    import duo_attn.patch.tuple_kv_cache as T
+    import duo_attn.utils as U
+
+    for n in ("enable_duo_attention_eval", "enable_duo_attention_training", "get_full_attention_heads",
+              "set_full_attention_heads", "map_full_attention_heads", "load_full_attention_heads"):
+        assert callable(getattr(P, n))
+    assert list(inspect.signature(P.enable_duo_attention_eval).parameters) == [
+        "model", "full_attention_heads", "sink_size", "recent_size"]
+    for mod, fam in ((L, "llama"), (M, "mistral")):
+        for n in (f"enable_{fam}_duo_attention_static_kv_cache_eval", f"enable_{fam}_duo_attention_eval",
+                  "DuoAttentionStaticKVCache", f"get_{fam}_full_attention_heads"):
+            assert hasattr(mod, n), n
+    assert list(inspect.signature(L.DuoAttentionStaticKVCache.__init__).parameters)[1:] == [
+        "model", "full_attention_heads", "batch_size", "max_size", "sink_size", "recent_size"]
+    for n in ("kv_seq_len", "streaming_kv_seq_len", "split_kv", "put_full_kv", "get_streaming_kv",
+              "compress_and_replace_streaming_kv", "clear", "evict_last", "memory_usage", "get_full_kv"):
+        assert hasattr(L.DuoAttentionStaticKVCache, n), n
+    assert callable(T.enable_tuple_kv_cache)
+    for n in ("load_attn_pattern", "sparsify_attention_heads", "seed_everything", "get_model", "get_tokenizer",
+              "to_device", "parse_args", "save_full_attention_heads"):
+        assert callable(getattr(U, n)), n
+    with pytest.raises(NotImplementedError):
+        P.enable_duo_attention_training(type("M", (), {"config": type("C", (), {"model_type": "llama"})})(), 1, 1, 1)
+    with pytest.raises(ValueError, match="not supported"):
+        P.enable_duo_attention_eval(type("M", (), {"config": type("C", (), {"model_type": "gpt2"})})(), [], 1, 1)
+
+
+def test_parse_args_keeps_reference_flags():
+    from duo_attn.utils import parse_args
+
+    a = parse_args(["--model_name", "m", "--attn_load_dir", "d", "--sparsity", "0.5", "--max_length", "100000",
+                    "--prefilling_chunk_size", "32000", "--device", "0", "--seed", "42"])
+    assert a.sparsity == 0.5 and a.prefilling_chunk_size == 32000 and a.device == "cuda:0"
+    assert a.sink_size == 64 and a.recent_size == 256

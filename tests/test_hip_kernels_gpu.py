@@ -43,7 +43,7 @@ def _ulp_close(ours, ref, what, max_frac=0.01):
     if o.numel() == 0:
         return
     diff = (o - r).abs()
-    tol = torch.clamp(r.abs() * 2.0 ** -7, min=1e-5)
+    tol = torch.clamp(torch.maximum(o.abs(), r.abs()) * 2.0 ** -7, min=1e-5)
     assert (diff <= tol).all(), f"{what}: max diff {diff.max():.3e} exceeds one bf16 ulp"
     frac = (diff > 0).float().mean().item()
     assert frac <= max_frac, f"{what}: {frac:.4%} elements differ"

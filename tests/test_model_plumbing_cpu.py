@@ -1,0 +1,169 @@
+"""BASELINE config[0] in miniature: the patch API on HuggingFace Llama / Mistral models on CPU
+(host plumbing only; the oracle is plugged in as the device backend — the product itself has no CPU
+path).  Property tests that need no golden data:
+  (i)   all heads retrieval heads  => patched model == unpatched HF model;
+  (ii)  weight reordering is invisible when sink+recent covers the whole context;
+  (iii) chunked prefill + decode == single-shot for retrieval heads;
+  (iv)  tuple path and static path agree.
+fp32 models so the comparisons are tight.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
+
+
+def tiny(family, seed=0):
+    torch.manual_seed(seed)
+    kw = dict(hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4,
+              num_key_value_heads=2, head_dim=128, vocab_size=97, max_position_embeddings=2048,
+              rope_theta=10000.0, attn_implementation="eager", tie_word_embeddings=False)
+    if family == "llama":
+        model = LlamaForCausalLM(LlamaConfig(**kw))
+    else:
+        model = MistralForCausalLM(MistralConfig(sliding_window=None, **kw))
+    return model.float().eval()
+
+
+@pytest.fixture
+def exact_backend():
+    from duo_attn import backend
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend(round_p=False))
+    yield
+    backend._set_backend_for_testing(None)
+
+
+def hf_last_logits(model, ids):
+    with torch.no_grad():
+        return model(input_ids=ids).logits[:, -1:, :]
+
+
+def run_chunks(model, ids, chunks, past=None):
+    outs = []
+    pos = 0
+    with torch.no_grad():
+        for c in chunks:
+            out = model(input_ids=ids[:, pos:pos + c], past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            outs.append(out.logits)
+            pos += c
+    return outs, past
+
+
+@pytest.mark.parametrize("family", ["llama", "mistral"])
+def test_tuple_path_all_full_equals_hf(family, exact_backend):
+    from duo_attn.patch import enable_duo_attention_eval, get_full_attention_heads
+
+    ref = tiny(family)
+    model = copy.deepcopy(ref)
+    heads = np.ones((2, 2))
+    enable_duo_attention_eval(model, heads, 4, 8)
+    ids = torch.randint(0, 97, (1, 33), generator=torch.Generator().manual_seed(1))
+    outs, past = run_chunks(model, ids, [20, 9, 1, 1, 1, 1])
+    for n, lg in zip(np.cumsum([20, 9, 1, 1, 1, 1]), outs):
+        assert lg.shape == (1, 1, 97) and lg.dtype == torch.float32
+        torch.testing.assert_close(lg, hf_last_logits(ref, ids[:, :n]), rtol=2e-4, atol=2e-4)
+    # tuple cache layout: (full_KV [2B, nf, N, D], streaming_KV [2B, ns, n, D]) per layer
+    assert len(past) == 2 and past[0][0].shape == (2, 2, 33, 128) and past[0][1].shape == (2, 0, 12, 128)
+    assert [h.tolist() for h in get_full_attention_heads(model)] == [[1.0, 1.0], [1.0, 1.0]]
+
+
+@pytest.mark.parametrize("family", ["llama", "mistral"])
+def test_reordering_is_invisible_when_window_covers_context(family, exact_backend):
+    """mixed retrieval/streaming heads with sink+recent >= context: streaming heads see everything, so any
+    difference from HF can only come from a wrong q/k/v/o permutation or a wrong head split."""
+    from duo_attn.patch import enable_duo_attention_eval
+
+    ref = tiny(family, seed=3)
+    model = copy.deepcopy(ref)
+    heads = np.array([[0.0, 1.0], [1.0, 0.0]])    # layer 0: head 1 retrieval; layer 1: head 0 retrieval
+    enable_duo_attention_eval(model, heads, 16, 64)
+    ids = torch.randint(0, 97, (1, 40), generator=torch.Generator().manual_seed(2))
+    outs, past = run_chunks(model, ids, [25, 10, 1, 1, 1, 1, 1])
+    for n, lg in zip(np.cumsum([25, 10, 1, 1, 1, 1, 1]), outs):
+        torch.testing.assert_close(lg, hf_last_logits(ref, ids[:, :n]), rtol=2e-4, atol=2e-4)
+    assert past[0][0].shape == (2, 1, 40, 128) and past[0][1].shape == (2, 1, 40, 128)
+
+
+def test_streaming_heads_truncate_and_change_logits(exact_backend):
+    from duo_attn.patch import enable_duo_attention_eval
+
+    ref = tiny("llama", seed=4)
+    model = copy.deepcopy(ref)
+    enable_duo_attention_eval(model, np.array([[0.0, 1.0], [1.0, 0.0]]), 2, 6)
+    ids = torch.randint(0, 97, (1, 30), generator=torch.Generator().manual_seed(5))
+    outs, past = run_chunks(model, ids, [12, 12, 1, 1, 1, 1, 1, 1])
+    assert past[0][1].shape == (2, 1, 8, 128)      # sink 2 + recent 6
+    assert past[0][0].shape == (2, 1, 30, 128)
+    assert not torch.allclose(outs[-1], hf_last_logits(ref, ids), atol=1e-3)
+
+
+@pytest.mark.parametrize("family", ["llama", "mistral"])
+def test_static_path_all_full_equals_hf_and_tuple_path(family, exact_backend):
+    mod = __import__(f"duo_attn.patch.{family}", fromlist=["x"])
+    enable_static = getattr(mod, f"enable_{family}_duo_attention_static_kv_cache_eval")
+    Cache = mod.DuoAttentionStaticKVCache
+
+    ref = tiny(family, seed=6)
+    model = copy.deepcopy(ref)
+    heads = np.ones((2, 2))
+    enable_static(model, heads)
+    ids = torch.randint(0, 97, (1, 30), generator=torch.Generator().manual_seed(7))
+    cache = Cache(model, heads, 1, 64, 4, 8)
+    outs, past = run_chunks(model, ids, [17, 10, 1, 1, 1], past=cache)
+    assert past is cache and cache.kv_seq_len == 30
+    for n, lg in zip(np.cumsum([17, 10, 1, 1, 1]), outs):
+        assert lg.shape == (1, 1, 97)
+        # static path: fp32 RoPE from (theta, factor) instead of HF's cos/sin tables -> tiny differences
+        torch.testing.assert_close(lg, hf_last_logits(ref, ids[:, :n]), rtol=1e-3, atol=1e-3)
+
+
+def test_static_path_mixed_heads_matches_tuple_path(exact_backend):
+    """same pattern through both cache formats (chunk sizes identical: streaming-head outputs depend on
+    the chunking, reference llama.py:385-412)."""
+    from duo_attn.patch import enable_duo_attention_eval
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+
+    base = tiny("llama", seed=8)
+    heads = np.array([[1.0, 0.0], [0.0, 1.0]])
+    m_tuple, m_static = copy.deepcopy(base), copy.deepcopy(base)
+    enable_duo_attention_eval(m_tuple, heads.copy(), 3, 5)
+    enable_llama_duo_attention_static_kv_cache_eval(m_static, heads.copy())
+    ids = torch.randint(0, 97, (1, 41), generator=torch.Generator().manual_seed(9))
+    chunks = [16, 16, 5, 1, 1, 1, 1]
+    o_t, _ = run_chunks(m_tuple, ids, chunks)
+    cache = DuoAttentionStaticKVCache(m_static, heads, 1, 50, 3, 5)
+    o_s, _ = run_chunks(m_static, ids, chunks, past=cache)
+    for a, b in zip(o_t, o_s):
+        torch.testing.assert_close(a, b.float(), rtol=1e-3, atol=1e-3)
+    assert cache.streaming_kv_seq_len == 8 and cache.kv_seq_len == 41
+
+
+def test_full_attention_tuple_baseline(exact_backend):
+    from duo_attn.patch.tuple_kv_cache import enable_tuple_kv_cache
+
+    ref = tiny("mistral", seed=10)
+    model = copy.deepcopy(ref)
+    enable_tuple_kv_cache(model)
+    ids = torch.randint(0, 97, (1, 21), generator=torch.Generator().manual_seed(11))
+    outs, past = run_chunks(model, ids, [13, 6, 1, 1])
+    for n, lg in zip(np.cumsum([13, 6, 1, 1]), outs):
+        torch.testing.assert_close(lg, hf_last_logits(ref, ids[:, :n]), rtol=2e-4, atol=2e-4)
+    assert past[1][0].shape == (1, 2, 21, 128)
+
+
+def test_without_a_backend_the_patched_model_refuses_cpu():
+    """no oracle plugged in: the product path must fail loudly on CPU tensors"""
+    from duo_attn import _hip, backend
+    from duo_attn.patch import enable_duo_attention_eval
+
+    backend._set_backend_for_testing(None)
+    model = tiny("llama")
+    model = model.to(torch.bfloat16)
+    enable_duo_attention_eval(model, np.ones((2, 2)), 4, 8)
+    with pytest.raises(_hip.DuoHipError, match="no CPU fallback"):
+        model(input_ids=torch.zeros(1, 4, dtype=torch.long), use_cache=True)
