@@ -25,8 +25,6 @@
  *                             all heads causal) and llama.py:392-421 (later
  *                             chunks, one call per head class)
  *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
- *   duo_int4_quantize_f16 / duo_int4_dequantize_f16
- *                             demo/quantize_int4.cu:73-178 / :9-71
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
