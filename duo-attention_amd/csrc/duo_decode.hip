@@ -19,7 +19,8 @@
 //     merged by duo_decode_merge_kernel (or written straight to `out` when a
 //     class needs a single split).
 #include <algorithm>
-#include "duo_common.h"
+#include <cstdlib>
+#include "duo_kv_ops.h"
 
 namespace {
 
@@ -56,6 +57,15 @@ struct RowSrc {
     int32_t lenA;
 };
 
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const bf16_t *p) {
+    // K/V rows are read exactly once per token: the non-temporal policy keeps them from
+    // displacing q / partials / the next kernel's working set in L2 and MALL
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    else return *reinterpret_cast<const u32x4 *>(p);
+}
+
+template <bool NT>
 __device__ __forceinline__ void load_rows(const RowSrc &src, int tok0, int tg, int tok_end,
                                           u32x4 (&kbuf)[4], u32x4 (&vbuf)[4]) {
 #pragma unroll
@@ -66,8 +76,8 @@ __device__ __forceinline__ void load_rows(const RowSrc &src, int tok0, int tg, i
         const int64_t off = inA ? (int64_t)tok * src.tsa : (int64_t)(tok - src.lenA) * src.tsb;
         const bf16_t *kp = (inA ? src.ka : src.kb) + off;
         const bf16_t *vp = (inA ? src.va : src.vb) + off;
-        kbuf[u] = *reinterpret_cast<const u32x4 *>(kp);
-        vbuf[u] = *reinterpret_cast<const u32x4 *>(vp);
+        kbuf[u] = ld16<NT>(kp);
+        vbuf[u] = ld16<NT>(vp);
     }
 }
 
@@ -129,7 +139,7 @@ __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4
 
 // grid.x = (kv head, split) pairs of the full class then of the streaming class
 // grid.y = group / GT
-template <int GT>
+template <int GT, bool NT, bool PREFETCH>
 __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -141,15 +151,20 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     if (ci) b -= P.nblk_full;
     const DuoClassDev &C = P.cls[ci];
     const int splits = P.splits[ci];
-    const int chunk = P.chunk[ci];
     const int kvh = b / splits;
     const int split = b - kvh * splits;
     const int qh0 = C.q_head_offset + kvh * P.group + blockIdx.y * GT;
 
+    // balanced static partition: the head's ceil(L/64) 64-token units are dealt to the splits as
+    // evenly as possible, so every workgroup of the (single-round) grid streams the same bytes
     const int L = C.a.len + C.b.len;
-    const int c0 = split * chunk;
-    const int c1 = min(c0 + chunk, L);
-    const int per_wave = chunk >> 2;  // multiple of 16
+    const int units = (L + 63) >> 6;
+    const int uq = units / splits, ur = units - uq * splits;
+    const int u0 = split * uq + min(split, ur);
+    const int un = uq + (split < ur ? 1 : 0);
+    const int c0 = u0 << 6;
+    const int c1 = min((u0 + un) << 6, L);
+    const int per_wave = (((c1 - c0 + 3) >> 2) + 15) & ~15;  // quarter of the chunk, multiple of 16
     const int w0 = c0 + wave * per_wave;
     const int w1 = min(w0 + per_wave, c1);
 
@@ -181,15 +196,23 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     }
 
     if (w0 < w1) {
-        u32x4 k0[4], v0[4], k1[4], v1[4];
-        load_rows(src, w0, tg, w1, k0, v0);
-        for (int t = w0; t < w1; t += 2 * kTokPerIter) {
-            const bool more1 = t + kTokPerIter < w1;
-            if (more1) load_rows(src, t + kTokPerIter, tg, w1, k1, v1);
-            consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
-            if (more1) {
-                if (t + 2 * kTokPerIter < w1) load_rows(src, t + 2 * kTokPerIter, tg, w1, k0, v0);
-                consume_rows<GT>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
+        if constexpr (PREFETCH) {
+            u32x4 k0[4], v0[4], k1[4], v1[4];
+            load_rows<NT>(src, w0, tg, w1, k0, v0);
+            for (int t = w0; t < w1; t += 2 * kTokPerIter) {
+                const bool more1 = t + kTokPerIter < w1;
+                if (more1) load_rows<NT>(src, t + kTokPerIter, tg, w1, k1, v1);
+                consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
+                if (more1) {
+                    if (t + 2 * kTokPerIter < w1) load_rows<NT>(src, t + 2 * kTokPerIter, tg, w1, k0, v0);
+                    consume_rows<GT>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
+                }
+            }
+        } else {
+            u32x4 k0[4], v0[4];
+            for (int t = w0; t < w1; t += kTokPerIter) {
+                load_rows<NT>(src, t, tg, w1, k0, v0);
+                consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
             }
         }
     }
@@ -270,8 +293,8 @@ struct MergeParams {
 };
 
 // one workgroup (256 threads) per q head: 8 split lanes x 32 dim quads
-__global__ __launch_bounds__(256) void duo_decode_merge_kernel(const MergeParams P) {
-    int qh = blockIdx.x;
+__device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
+    int qh = blk;
     int splits;
     {
         const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
@@ -326,7 +349,18 @@ __global__ __launch_bounds__(256) void duo_decode_merge_kernel(const MergeParams
     }
 }
 
-inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// Epilogue launch of a decode step: blocks [0, n_merge) merge the split-KV partials of one q head
+// each; blocks [n_merge, n_merge + n_compress) run the streaming-pool sink+recent update of one
+// (head, K|V) each (absent when the caller updates the pool separately).
+__global__ __launch_bounds__(256) void duo_decode_post_kernel(const MergeParams M, int n_merge,
+                                                             const CompressParams C) {
+    if ((int)blockIdx.x < n_merge) duo_decode_merge_block(M, blockIdx.x);
+    else duo_stream_compress_block(C, blockIdx.x - n_merge);
+}
+
+__global__ __launch_bounds__(64) void duo_decode_pre_kernel(const DecodePreParams P) {
+    duo_decode_pre_block(P, blockIdx.x, threadIdx.x);
+}
 
 }  // namespace
 
@@ -335,35 +369,47 @@ extern "C" int64_t duo_attn_decode_workspace_bytes(int32_t n_q_heads, int32_t ma
     return (int64_t)n_q_heads * max_splits * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
 }
 
-// Split policy: enough (kv head, chunk) workgroups to put ~4 on every one of the
-// 256 CUs, chunks of at least 256 tokens so the per-workgroup epilogue stays
-// small, and no more splits per head than the workspace was sized for.
-static void choose_splits(int n_kv_heads, int L, int max_splits, int &chunk, int &splits) {
+static int decode_target_wgs() {
+    // workgroups the split kernel aims for across both classes (tuning knob, read once)
+    static int v = [] {
+        const char *e = getenv("DUO_DECODE_TARGET_WGS");
+        const int x = e ? atoi(e) : 0;
+        return x > 0 ? x : 512;
+    }();
+    return v;
+}
+
+// Split policy: one resident round.  The kernel runs 2 workgroups per CU (register-limited), so the
+// grid aims at 2 x 256 workgroups in total; each kv head's 64-token units are dealt evenly to its
+// splits (balanced partition in the kernel).  Never more splits than units or than the workspace holds.
+static void choose_splits(int n_kv_heads, int L, int max_splits, int budget_wgs, int &splits) {
     if (n_kv_heads <= 0 || L <= 0) {
-        chunk = 256;
         splits = 0;
         return;
     }
-    const int64_t total = (int64_t)n_kv_heads * L;
-    int c = (int)((total + 1023) / 1024);
-    c = round_up(c < 256 ? 256 : c, 64);
-    int s = (L + c - 1) / c;
-    if (s > max_splits) {
-        c = round_up((L + max_splits - 1) / max_splits, 64);
-        s = (L + c - 1) / c;
-    }
-    chunk = c;
+    const int units = (L + 63) / 64;
+    int s = budget_wgs / n_kv_heads;
+    // keep at least 256 tokens per workgroup so its epilogue stays small
+    s = std::min(s, std::max(1, units / 4));
+    s = std::max(1, std::min(s, std::min(units, max_splits)));
     splits = s;
 }
 
-extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
-                                    int64_t out_head_stride, int32_t group,
-                                    const duo_head_class *full, const duo_head_class *stream_cls,
-                                    float scale, int32_t head_dim, void *workspace,
-                                    int64_t workspace_bytes, void *stream) {
-    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
-    if (q == nullptr || out == nullptr || group <= 0) return DUO_EINVAL;
+namespace {
+struct DecodePlan {
     DecodeParams P;
+    MergeParams M;
+    int n_merge;
+    int nblk;
+    int gt;
+};
+}  // namespace
+
+// validates the two head classes, sizes the splits and fills the kernel parameter blocks
+static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
+                       int32_t group, const duo_head_class *full, const duo_head_class *stream_cls,
+                       float scale, void *workspace, int64_t workspace_bytes, DecodePlan &D) {
+    DecodeParams &P = D.P;
     P.q = (const bf16_t *)q;
     P.q_head_stride = q_head_stride;
     P.out = (bf16_t *)out;
@@ -373,10 +419,12 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     P.group = group;
     P.scale_log2e = scale * 1.4426950408889634f;
     const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
+    D.nblk = 0;
+    D.n_merge = 0;
     if (n_q_heads <= 0) return 0;
     for (int c = 0; c < 2; ++c) {
         const DuoClassDev &C = P.cls[c];
-        if (C.n_kv_heads <= 0) continue;
+        if (C.n_kv_heads <= 0) { P.cls[c].n_kv_heads = 0; continue; }
         if (C.a.len < 0 || C.b.len < 0 || C.a.len + C.b.len <= 0) return DUO_EINVAL;
         if ((C.a.len > 0 && (!C.a.k || !C.a.v)) || (C.b.len > 0 && (!C.b.k || !C.b.v))) return DUO_EINVAL;
         if (C.a.len == 0) { P.cls[c].a = P.cls[c].b; P.cls[c].a.len = 0; }  // valid base for clamped loads
@@ -384,10 +432,16 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     }
     // workspace capacity -> max splits per head
     const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
-    int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
-    for (int c = 0; c < 2; ++c) {
-        const int L = P.cls[c].a.len + P.cls[c].b.len;
-        choose_splits(P.cls[c].n_kv_heads, L, max_splits > 0 ? max_splits : 1, P.chunk[c], P.splits[c]);
+    const int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
+    {
+        const int target = decode_target_wgs();
+        const int ms = max_splits > 0 ? max_splits : 1;
+        const int Ls = P.cls[1].a.len + P.cls[1].b.len, Lf = P.cls[0].a.len + P.cls[0].b.len;
+        // the streaming class is a few hundred rows per head: one workgroup each unless it is alone
+        choose_splits(P.cls[1].n_kv_heads, Ls, ms, P.cls[0].n_kv_heads > 0 ? P.cls[1].n_kv_heads : target, P.splits[1]);
+        const int used = P.cls[1].n_kv_heads * P.splits[1];
+        choose_splits(P.cls[0].n_kv_heads, Lf, ms, std::max(target - used, P.cls[0].n_kv_heads), P.splits[0]);
+        P.chunk[0] = P.chunk[1] = 0;
     }
     const int need = std::max(P.splits[0], P.splits[1]);
     if (need > 1 && max_splits < need) return DUO_EWORKSPC;
@@ -395,35 +449,138 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     P.ws_ml = (float *)workspace;
     P.ws_acc = P.ws_ml ? P.ws_ml + (int64_t)n_q_heads * P.max_splits * 2 : nullptr;
     P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
-    const int nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
+    D.nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
+    D.gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
 
-    const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
-    dim3 grid(nblk, group / gt), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (gt == 4)
-        hipLaunchKernelGGL(duo_decode_split_kernel<4>, grid, block, 0, st, P);
-    else if (gt == 2)
-        hipLaunchKernelGGL(duo_decode_split_kernel<2>, grid, block, 0, st, P);
-    else
-        hipLaunchKernelGGL(duo_decode_split_kernel<1>, grid, block, 0, st, P);
-    DUO_HIP_CHECK_LAUNCH();
-
-    MergeParams M;
+    MergeParams &M = D.M;
     M.ws_ml = P.ws_ml;
     M.ws_acc = P.ws_acc;
     M.out = P.out;
     M.out_head_stride = out_head_stride;
     M.max_splits = P.max_splits;
-    int n_merge = 0;
     for (int c = 0; c < 2; ++c) {
         M.qh_begin[c] = P.cls[c].q_head_offset;
         M.qh_end[c] = P.cls[c].q_head_offset + P.cls[c].n_kv_heads * group;
         M.splits[c] = P.splits[c];
-        if (P.splits[c] > 1) n_merge += P.cls[c].n_kv_heads * group;
+        if (P.splits[c] > 1) D.n_merge += P.cls[c].n_kv_heads * group;
     }
+    return 0;
+}
+
+static int decode_launch_split(const DecodePlan &D, hipStream_t st) {
+    if (D.nblk <= 0) return 0;
+    const DecodeParams &P = D.P;
+    dim3 grid(D.nblk, P.group / D.gt), block(256);
+    const uint32_t fl = duo_get_debug_flags();
+    const bool nt = !(fl & 4u);        // debug bit 2: plain (temporal) K/V loads
+    const bool pf = !(fl & 8u);        // debug bit 3: no register prefetch of the next 16 tokens
+#define DUO_LAUNCH_DECODE(GT_)                                                                               \
+    do {                                                                                                     \
+        if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true>), grid, block, 0, st, P);   \
+        else if (nt) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, false>), grid, block, 0, st, P);   \
+        else if (pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, true>), grid, block, 0, st, P);   \
+        else hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, false>), grid, block, 0, st, P);          \
+    } while (0)
+    if (D.gt == 4) DUO_LAUNCH_DECODE(4);
+    else if (D.gt == 2) DUO_LAUNCH_DECODE(2);
+    else DUO_LAUNCH_DECODE(1);
+#undef DUO_LAUNCH_DECODE
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
+                                    int64_t out_head_stride, int32_t group,
+                                    const duo_head_class *full, const duo_head_class *stream_cls,
+                                    float scale, int32_t head_dim, void *workspace,
+                                    int64_t workspace_bytes, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (q == nullptr || out == nullptr || group <= 0) return DUO_EINVAL;
+    DecodePlan D;
+    int rc = decode_plan(q, q_head_stride, out, out_head_stride, group, full, stream_cls, scale, workspace,
+                         workspace_bytes, D);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    rc = decode_launch_split(D, st);
+    if (rc) return rc;
     // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
-    if (n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
-        hipLaunchKernelGGL(duo_decode_merge_kernel, dim3(n_merge), dim3(256), 0, st, M);
+    if (D.n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
+        CompressParams none{};
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(D.n_merge), dim3(256), 0, st, D.M, D.n_merge, none);
+        DUO_HIP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// One decode step of one layer of the static dual-cache path in three launches
+// (prologue: RoPE + full-pool append; split-KV scan of both head classes; epilogue: merge +
+// streaming-pool update).  See include/duo_attn_hip.h.
+extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!a) return DUO_EINVAL;
+    if (a->head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    const int nf = a->n_full, nkv = a->n_kv_heads, ns = nkv - nf;
+    if (!a->q || !a->k || !a->v || !a->out || nkv <= 0 || nf < 0 || ns < 0 || a->n_q_heads % nkv != 0)
+        return DUO_EINVAL;
+    if (a->rope_scale <= 0.f || a->rope_theta <= 0.f) return DUO_EINVAL;
+    if (nf > 0 && (!a->full_k || !a->full_v || a->full_len < 0 || a->full_len + 1 > a->full_capacity)) return DUO_EINVAL;
+    const int W = a->sink + a->recent;
+    if (a->str_len < 0 || a->str_len > W) return DUO_EINVAL;
+    if (ns > 0 && (!a->str_k || !a->str_v)) return DUO_EINVAL;
+    if (((a->q_head_stride | a->kv_head_stride | a->out_head_stride | a->full_token_stride | a->full_head_stride |
+          a->str_token_stride | a->str_head_stride) & 7) != 0)
+        return DUO_EINVAL;
+    const int group = a->n_q_heads / nkv;
+    hipStream_t st = (hipStream_t)stream;
+
+    // ---- launch 1: RoPE(q, k) in place + append of the retrieval rows ---------------------------
+    DecodePreParams R;
+    R.q = (bf16_t *)a->q; R.q_hs = a->q_head_stride; R.n_q_heads = a->n_q_heads;
+    R.k = (bf16_t *)a->k; R.v = (const bf16_t *)a->v; R.kv_hs = a->kv_head_stride; R.n_kv_heads = nkv;
+    R.n_full = nf;
+    R.kp = (bf16_t *)a->full_k; R.vp = (bf16_t *)a->full_v;
+    R.p_ts = a->full_token_stride; R.p_hs = a->full_head_stride;
+    R.dst_row = a->full_len;
+    R.pos = (float)a->pos;
+    for (int i = 0; i < 64; ++i)
+        R.inv_freq[i] = (float)(pow((double)a->rope_theta, -2.0 * i / 128.0) / (double)a->rope_scale);
+    hipLaunchKernelGGL(duo_decode_pre_kernel, dim3(a->n_q_heads + nkv), dim3(64), 0, st, R);
+    DUO_HIP_CHECK_LAUNCH();
+
+    // ---- launch 2: split-KV scan ---------------------------------------------------------------
+    duo_head_class fc{}, sc{};
+    fc.n_kv_heads = nf;
+    fc.q_head_offset = 0;
+    fc.segA = duo_kv_seg{a->full_k, a->full_v, a->full_token_stride, a->full_head_stride, a->full_len + 1, 0};
+    fc.segB = duo_kv_seg{nullptr, nullptr, 0, 0, 0, 0};
+    sc.n_kv_heads = ns;
+    sc.q_head_offset = nf * group;
+    sc.segA = duo_kv_seg{a->str_k, a->str_v, a->str_token_stride, a->str_head_stride, a->str_len, 0};
+    sc.segB = duo_kv_seg{(const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
+                         (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride, 1, 0};
+    DecodePlan D;
+    int rc = decode_plan(a->q, a->q_head_stride, a->out, a->out_head_stride, group, nf ? &fc : nullptr,
+                         ns ? &sc : nullptr, a->scale, workspace, workspace_bytes, D);
+    if (rc) return rc;
+    rc = decode_launch_split(D, st);
+    if (rc) return rc;
+
+    // ---- launch 3: merge + streaming-pool update -------------------------------------------------
+    CompressParams C{};
+    int n_compress = 0;
+    const int T = a->str_len + 1;
+    // the counter advances even for a layer without streaming heads, as the reference's
+    // compress_and_replace_streaming_kv does on its zero-head tensors (static_kv_cache.py:127-167)
+    if (new_stream_len) *new_stream_len = T <= W ? T : W;
+    if (ns > 0) {
+        C = CompressParams{(bf16_t *)a->str_k, (bf16_t *)a->str_v, a->str_token_stride, a->str_head_stride,
+                           (const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
+                           (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride,
+                           ns, a->str_len, 1, a->sink, a->recent};
+        n_compress = 2 * ns;
+    }
+    if (D.n_merge + n_compress > 0) {
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(D.n_merge + n_compress), dim3(256), 0, st, D.M, D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;

@@ -1,0 +1,145 @@
+// Small shared device pieces of the KV-pool kernels (included by duo_rope_kv.hip and
+// duo_decode.hip; everything is inline / internal linkage).
+#pragma once
+#include "duo_common.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8f(const u32x4 &w, float (&f)[8]) {
+    f[0] = bf16_lo(w.x); f[1] = bf16_hi(w.x);
+    f[2] = bf16_lo(w.y); f[3] = bf16_hi(w.y);
+    f[4] = bf16_lo(w.z); f[5] = bf16_hi(w.z);
+    f[6] = bf16_lo(w.w); f[7] = bf16_hi(w.w);
+}
+__device__ __forceinline__ u32x4 pack8f(const float (&f)[8]) {
+    u32x4 w;
+    w.x = pack_bf16x2(f[0], f[1]);
+    w.y = pack_bf16x2(f[2], f[3]);
+    w.z = pack_bf16x2(f[4], f[5]);
+    w.w = pack_bf16x2(f[6], f[7]);
+    return w;
+}
+
+// sin/cos of an fp32 angle: the reduction to [-0.5, 0.5) revolutions is done in fp64 (exact to
+// ~1e-16 of a revolution even at angle 1e6), then the hardware v_sin/v_cos (input in revolutions,
+// abs error ~1e-6 — three orders below a bf16 ulp).  ~10x cheaper than the libm sincosf slow path
+// that large positions take.
+__device__ __forceinline__ void sincos_rev(float angle, float &s, float &c) {
+    double r = (double)angle * 0.15915494309189535;   // 1 / (2 pi)
+    r -= rint(r);
+    const float rf = (float)r;
+    s = __builtin_amdgcn_sinf(rf);
+    c = __builtin_amdgcn_cosf(rf);
+}
+
+// ---------------------------------------------------------------------------
+// Decode-step prologue, one launch: RoPE of the single new token's q and k heads
+// in place, and the append of the retrieval heads' new K (rotated) and V rows to
+// the full pool at row `dst_row`.  One wave per head; lane i owns the rotation
+// pair (i, i+64).  Replaces duo_rope_kernel + duo_kv_append_kernel for S == 1.
+// ---------------------------------------------------------------------------
+struct DecodePreParams {
+    bf16_t *q;
+    int64_t q_hs;
+    int32_t n_q_heads;
+    bf16_t *k;
+    const bf16_t *v;
+    int64_t kv_hs;
+    int32_t n_kv_heads;
+    int32_t n_full;          // kv heads [0, n_full) are appended to the pool
+    bf16_t *kp, *vp;         // pool bases (row 0, head 0)
+    int64_t p_ts, p_hs;
+    int32_t dst_row;
+    float pos;
+    float inv_freq[64];
+};
+
+__device__ __forceinline__ void duo_decode_pre_block(const DecodePreParams &P, int h, int i) {
+    float sn, cs;
+    sincos_rev(P.pos * P.inv_freq[i], sn, cs);
+    if (h < P.n_q_heads) {
+        bf16_t *row = P.q + (int64_t)h * P.q_hs;
+        const float lo = __uint_as_float((uint32_t)row[i] << 16), hi = __uint_as_float((uint32_t)row[i + 64] << 16);
+        row[i] = (bf16_t)f32_to_bf16_bits(lo * cs - hi * sn);
+        row[i + 64] = (bf16_t)f32_to_bf16_bits(hi * cs + lo * sn);
+    } else {
+        const int kh = h - P.n_q_heads;
+        bf16_t *row = P.k + (int64_t)kh * P.kv_hs;
+        const float lo = __uint_as_float((uint32_t)row[i] << 16), hi = __uint_as_float((uint32_t)row[i + 64] << 16);
+        const bf16_t olo = (bf16_t)f32_to_bf16_bits(lo * cs - hi * sn);
+        const bf16_t ohi = (bf16_t)f32_to_bf16_bits(hi * cs + lo * sn);
+        row[i] = olo;
+        row[i + 64] = ohi;
+        if (kh < P.n_full) {
+            const int64_t po = (int64_t)P.dst_row * P.p_ts + (int64_t)kh * P.p_hs;
+            P.kp[po + i] = olo;
+            P.kp[po + i + 64] = ohi;
+            const uint32_t vv = reinterpret_cast<const uint32_t *>(P.v + (int64_t)kh * P.kv_hs)[i];
+            reinterpret_cast<uint32_t *>(P.vp + po)[i] = vv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Streaming pool update (compress_and_replace_streaming_kv,
+// static_kv_cache.py:127-167, input = torch.cat([pool[:cur], new]) of
+// llama.py:385-390).  X = pool[:cur] ++ new[:n_new], T = cur + n_new.
+//   T <= W : pool[cur:T] = new
+//   T >  W : pool[r] = X[r] (r < sink);  pool[sink+j] = X[T-recent+j] (j < recent)
+// Every source row index is >= its destination row index, so one workgroup per
+// (head, K|V) walks the destination rows upward in batches: load a batch into
+// registers, barrier, store.  A later batch only reads rows above anything
+// already written.
+// ---------------------------------------------------------------------------
+struct CompressParams {
+    bf16_t *kp, *vp;
+    int64_t p_ts, p_hs;
+    const bf16_t *kn, *vn;
+    int64_t n_ts, n_hs;
+    int32_t n_heads, cur, n_new, sink, recent;
+};
+
+constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
+
+__device__ __forceinline__ void duo_stream_compress_block(const CompressParams &P, int blk) {
+    const int h = blk >> 1;
+    const bool is_v = blk & 1;
+    bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs;
+    const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs;
+    const int T = P.cur + P.n_new;
+    const int W = P.sink + P.recent;
+    const int ch = threadIdx.x & 15;
+    const int r_in = threadIdx.x >> 4;   // 0..15
+
+    int d_begin, d_end;
+    if (T <= W) { d_begin = P.cur; d_end = T; }
+    else { d_begin = 0; d_end = W; }
+
+    for (int d0 = d_begin; d0 < d_end; d0 += CMP_ROWS) {
+        u32x4 buf[4];
+        bool act[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + r_in + 16 * j;
+            act[j] = d < d_end;
+            int x = d;                                   // source index in X
+            if (T > W && d >= P.sink) x = T - P.recent + (d - P.sink);
+            // rows that stay where they are need no traffic
+            if (act[j] && x == d && x < P.cur) act[j] = false;
+            if (act[j]) {
+                const bf16_t *src = x < P.cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - P.cur) * P.n_ts;
+                buf[j] = *reinterpret_cast<const u32x4 *>(src + ch * 8);
+            }
+        }
+        __syncthreads();   // all loads of this batch complete before any store of it
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int d = d0 + r_in + 16 * j;
+            if (act[j]) *reinterpret_cast<u32x4 *>(pool + (int64_t)d * P.p_ts + ch * 8) = buf[j];
+        }
+        __syncthreads();
+    }
+}
+
+
+}  // namespace

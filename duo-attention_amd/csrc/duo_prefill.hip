@@ -37,6 +37,7 @@ constexpr int K_TILE_BYTES = KVBLK * DUO_HEAD_DIM * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = K_TILE_BYTES;
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 constexpr int LDS_BYTES = 2 * STAGE_BYTES;               // 64 KiB
+constexpr float kDeferLog2 = 8.0f;   // deferred-rescale threshold in the exp2 domain
 
 struct PrefillParams {
     const bf16_t *q;
@@ -89,7 +90,15 @@ __device__ __forceinline__ TileSrc tile_src(const DuoClassDev &C, int kvh, int t
     return s;
 }
 
-// 512 threads fetch one 64x128 K tile and one V tile: 2 x 16 B of each per thread
+// 512 threads fetch one 64x128 K tile and one V tile: 2 x 16 B of each per thread.
+// K: thread -> (row = idx/16, 16-B chunk = idx%16): 16 lanes read one 256-B row.
+// V: within each wave the lanes are permuted so that 8 consecutive lanes hold one 128-B LDS block
+//    ([4 keys][16 dims]) -> conflict-free ds_write_b128; a wave still reads 4 whole rows.
+__device__ __forceinline__ void v_stage_coord(int idx, int &row, int &ch) {
+    const int l = idx & 63;
+    row = ((idx >> 6) << 2) + ((l & 7) >> 1);     // 4 rows per wave-load
+    ch = ((l >> 3) << 1) + (l & 1);               // dim block (l>>3), half (l&1)
+}
 __device__ __forceinline__ void stage_load(const TileSrc &s, int tid, u32x4 (&kr)[2], u32x4 (&vr)[2]) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -97,9 +106,11 @@ __device__ __forceinline__ void stage_load(const TileSrc &s, int tid, u32x4 (&kr
         const int row = idx >> 4;
         const int ch = idx & 15;
         const int r = s.row0 + min(row, s.cnt - 1);
-        const int64_t off = (int64_t)r * s.ts + ch * 8;
-        kr[j] = *reinterpret_cast<const u32x4 *>(s.k + off);
-        vr[j] = *reinterpret_cast<const u32x4 *>(s.v + off);
+        kr[j] = *reinterpret_cast<const u32x4 *>(s.k + (int64_t)r * s.ts + ch * 8);
+        int vrow, vch;
+        v_stage_coord(idx, vrow, vch);
+        const int rv = s.row0 + min(vrow, s.cnt - 1);
+        vr[j] = *reinterpret_cast<const u32x4 *>(s.v + (int64_t)rv * s.ts + vch * 8);
     }
 }
 
@@ -116,7 +127,9 @@ __device__ __forceinline__ void stage_write(char *stage, int tid, const u32x4 (&
         const int row = idx >> 4;
         const int ch = idx & 15;
         *reinterpret_cast<u32x4 *>(stage + k_lds_off(row, ch)) = kr[j];
-        *reinterpret_cast<u32x4 *>(stage + K_TILE_BYTES + v_lds_off(row, ch * 8)) = vr[j];
+        int vrow, vch;
+        v_stage_coord(idx, vrow, vch);
+        *reinterpret_cast<u32x4 *>(stage + K_TILE_BYTES + v_lds_off(vrow, vch * 8)) = vr[j];
     }
 }
 
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
         if (!skip) {
             // ---- S^T = K . Q^T  (two 32-key blocks) ---------------------------
             f32x16 sc[2];
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
 #pragma unroll
@@ -230,6 +244,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     sc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[kk], sc[bb], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             // ---- mask ----------------------------------------------------------
             const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0) : (cnt < KVBLK);
             if (need_mask) {
@@ -243,15 +258,29 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     }
             }
             // ---- online softmax (lane = one query row; partner lane^32 holds the other keys)
-            float tmax = sc[0][0];
+            float t0 = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
+            float t1 = fmaxf(fmaxf(sc[1][0], sc[1][1]), sc[1][2]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sc[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[1][r]);
+            for (int r = 3; r < 15; r += 2) {
+                t0 = fmaxf(fmaxf(t0, sc[0][r]), sc[0][r + 1]);
+                t1 = fmaxf(fmaxf(t1, sc[1][r]), sc[1][r + 1]);
+            }
+            float tmax = fmaxf(fmaxf(t0, t1), fmaxf(sc[0][15], sc[1][15]));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            const float mnew = fmaxf(mrow, tmax);
-            const float alpha = fast_exp2((mrow - mnew) * c);
-            const float mc = mnew * c;
+            // Deferred rescale: while no row of the wave grows its max by more than 2^kDeferLog2 the
+            // old reference point is kept (P <= 2^kDeferLog2, exact in fp32/bf16 ranges) and the
+            // 64-register O rescale is skipped.  First tile: mrow = -inf forces the rescale path.
+            if (!__all((tmax - mrow) * c <= kDeferLog2)) {
+                const float mnew = fmaxf(mrow, tmax);
+                const float alpha = fast_exp2((mrow - mnew) * c);
+                lsum *= alpha;
+                mrow = mnew;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
+            const float mc = mrow * c;
             float psum = 0.f;
             bf16x8 pf[2][2];
 #pragma unroll
@@ -272,15 +301,11 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     pf[bb][s] = *reinterpret_cast<bf16x8 *>(&w);
                 }
             }
-            lsum = fmaf(lsum, alpha, psum);
-            mrow = mnew;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            lsum += psum;
 
             // ---- O^T += V^T . P^T ----------------------------------------------
             const char *vst = stage + K_TILE_BYTES;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
                 const int blk16 = 2 * db + (l31 >> 4);
@@ -293,6 +318,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                         o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[bb][s], o[db], 0, 0, 0);
                     }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
 
         if (has_next) stage_write(smem + ((t + 1) & 1) * STAGE_BYTES, tid, kr, vr);

@@ -3,24 +3,9 @@
 // sink+recent compaction, and RMSNorm.  All of them move 16 B per lane.
 #include <math.h>
 #include <algorithm>
-#include "duo_common.h"
+#include "duo_kv_ops.h"
 
 namespace {
-
-__device__ __forceinline__ void unpack8f(const u32x4 &w, float (&f)[8]) {
-    f[0] = bf16_lo(w.x); f[1] = bf16_hi(w.x);
-    f[2] = bf16_lo(w.y); f[3] = bf16_hi(w.y);
-    f[4] = bf16_lo(w.z); f[5] = bf16_hi(w.z);
-    f[6] = bf16_lo(w.w); f[7] = bf16_hi(w.w);
-}
-__device__ __forceinline__ u32x4 pack8f(const float (&f)[8]) {
-    u32x4 w;
-    w.x = pack_bf16x2(f[0], f[1]);
-    w.y = pack_bf16x2(f[2], f[3]);
-    w.z = pack_bf16x2(f[4], f[5]);
-    w.w = pack_bf16x2(f[6], f[7]);
-    return w;
-}
 
 // ---------------------------------------------------------------------------
 // RoPE, rotate-half convention (flashinfer interleave=False; reference call
@@ -56,7 +41,7 @@ __global__ __launch_bounds__(256) void duo_rope_kernel(const RopeParams P) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float a = pos * P.inv_freq[c * 8 + e];
-        sincosf(a, &sn[e], &cs[e]);
+        sincos_rev(a, sn[e], cs[e]);
     }
     const int n_heads = P.n_q_heads + P.n_kv_heads;
     for (int h = hs; h < n_heads; h += 8) {
@@ -104,65 +89,8 @@ __global__ __launch_bounds__(256) void duo_kv_append_kernel(const AppendParams P
     }
 }
 
-// ---------------------------------------------------------------------------
-// Streaming pool update (compress_and_replace_streaming_kv,
-// static_kv_cache.py:127-167, input = torch.cat([pool[:cur], new]) of
-// llama.py:385-390).  X = pool[:cur] ++ new[:n_new], T = cur + n_new.
-//   T <= W : pool[cur:T] = new
-//   T >  W : pool[r] = X[r] (r < sink);  pool[sink+j] = X[T-recent+j] (j < recent)
-// Every source row index is >= its destination row index, so one workgroup per
-// (head, K|V) walks the destination rows upward in batches: load a batch into
-// registers, barrier, store.  A later batch only reads rows above anything
-// already written.
-// ---------------------------------------------------------------------------
-struct CompressParams {
-    bf16_t *kp, *vp;
-    int64_t p_ts, p_hs;
-    const bf16_t *kn, *vn;
-    int64_t n_ts, n_hs;
-    int32_t n_heads, cur, n_new, sink, recent;
-};
-
-constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
-
 __global__ __launch_bounds__(256) void duo_stream_compress_kernel(const CompressParams P) {
-    const int h = blockIdx.x >> 1;
-    const bool is_v = blockIdx.x & 1;
-    bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs;
-    const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs;
-    const int T = P.cur + P.n_new;
-    const int W = P.sink + P.recent;
-    const int ch = threadIdx.x & 15;
-    const int r_in = threadIdx.x >> 4;   // 0..15
-
-    int d_begin, d_end;
-    if (T <= W) { d_begin = P.cur; d_end = T; }
-    else { d_begin = 0; d_end = W; }
-
-    for (int d0 = d_begin; d0 < d_end; d0 += CMP_ROWS) {
-        u32x4 buf[4];
-        bool act[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = d0 + r_in + 16 * j;
-            act[j] = d < d_end;
-            int x = d;                                   // source index in X
-            if (T > W && d >= P.sink) x = T - P.recent + (d - P.sink);
-            // rows that stay where they are need no traffic
-            if (act[j] && x == d && x < P.cur) act[j] = false;
-            if (act[j]) {
-                const bf16_t *src = x < P.cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - P.cur) * P.n_ts;
-                buf[j] = *reinterpret_cast<const u32x4 *>(src + ch * 8);
-            }
-        }
-        __syncthreads();   // all loads of this batch complete before any store of it
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int d = d0 + r_in + 16 * j;
-            if (act[j]) *reinterpret_cast<u32x4 *>(pool + (int64_t)d * P.p_ts + ch * 8) = buf[j];
-        }
-        __syncthreads();
-    }
+    duo_stream_compress_block(P, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

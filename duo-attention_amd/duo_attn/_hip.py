@@ -48,6 +48,22 @@ class HeadClass(Structure):
     ]
 
 
+class DecodeLayerArgs(Structure):
+    """``duo_decode_layer_args``"""
+
+    _fields_ = [
+        ("q", c_void_p), ("q_head_stride", c_int64), ("n_q_heads", c_int32), ("n_kv_heads", c_int32),
+        ("k", c_void_p), ("v", c_void_p), ("kv_head_stride", c_int64),
+        ("out", c_void_p), ("out_head_stride", c_int64),
+        ("n_full", c_int32), ("head_dim", c_int32),
+        ("full_k", c_void_p), ("full_v", c_void_p), ("full_token_stride", c_int64), ("full_head_stride", c_int64),
+        ("full_len", c_int32), ("full_capacity", c_int32),
+        ("str_k", c_void_p), ("str_v", c_void_p), ("str_token_stride", c_int64), ("str_head_stride", c_int64),
+        ("str_len", c_int32), ("sink", c_int32), ("recent", c_int32), ("_pad", c_int32),
+        ("pos", c_int64), ("rope_scale", c_float), ("rope_theta", c_float), ("scale", c_float), ("_pad2", c_float),
+    ]
+
+
 _SIGNATURES = {
     "duo_abi_version": (ctypes.c_int, []),
     "duo_target_arch": (c_char_p, []),
@@ -74,6 +90,9 @@ _SIGNATURES = {
         ctypes.c_int,
         [c_void_p, c_int64, c_void_p, c_int64, c_int32, POINTER(HeadClass), POINTER(HeadClass), c_float,
          c_int32, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_decode_layer_bf16": (
+        ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(c_int32), c_void_p, c_int64, c_void_p],
     ),
     "duo_attn_prefill_bf16": (
         ctypes.c_int,
@@ -253,6 +272,41 @@ def attn_decode(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[H
         ),
         "duo_attn_decode_bf16",
     )
+
+
+def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
+                 rope_scale, rope_theta, scale) -> int:
+    """Fused decode step of one layer (one batch row).  q/out [Hq, D]; k/v [Hkv, D] new rows;
+    full_k/full_v [T, nf, D] and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
+    lib = load_library()
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _require_gpu_bf16(t, n)
+    assert k.stride(0) == v.stride(0)
+    a = DecodeLayerArgs()
+    a.q, a.q_head_stride, a.n_q_heads, a.n_kv_heads = q.data_ptr(), q.stride(0), q.shape[0], k.shape[0]
+    a.k, a.v, a.kv_head_stride = k.data_ptr(), v.data_ptr(), k.stride(0)
+    a.out, a.out_head_stride = out.data_ptr(), out.stride(0)
+    a.n_full, a.head_dim = int(n_full), q.shape[1]
+    ns = k.shape[0] - n_full
+    if n_full > 0:
+        _require_gpu_bf16(full_k, "full_k")
+        assert full_k.stride() == full_v.stride()
+        a.full_k, a.full_v = full_k.data_ptr(), full_v.data_ptr()
+        a.full_token_stride, a.full_head_stride = full_k.stride(0), full_k.stride(1)
+        a.full_capacity = full_k.shape[0]
+    a.full_len = int(full_len)
+    if ns > 0:
+        _require_gpu_bf16(str_k, "str_k")
+        assert str_k.stride() == str_v.stride() and str_k.shape[0] >= sink + recent
+        a.str_k, a.str_v = str_k.data_ptr(), str_v.data_ptr()
+        a.str_token_stride, a.str_head_stride = str_k.stride(0), str_k.stride(1)
+    a.str_len, a.sink, a.recent = int(str_len), int(sink), int(recent)
+    a.pos, a.rope_scale, a.rope_theta, a.scale = int(pos), float(rope_scale), float(rope_theta), float(scale)
+    ws = decode_workspace(q.device, q.shape[0])
+    new_len = c_int32(0)
+    _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+           "duo_decode_layer_bf16")
+    return int(new_len.value)
 
 
 def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],

@@ -66,13 +66,16 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
     kv_seq_len = q_len + past
     if pos0 is None:
         pos0 = past
+    be = get_backend()
+    if q_len == 1 and past > 0 and hasattr(be, "decode_layer"):
+        return _decode_step_fused(be, query_states, key_states, value_states, kv_cache, layer_idx, pos0,
+                                  rope_scale, rope_theta)
     apply_rope_inplace(query_states, key_states, pos0, rope_scale, rope_theta)
 
     fk, fv, sk, sv = kv_cache.split_kv(layer_idx, key_states, value_states)
     past_l = kv_cache.kv_seq_len_list[layer_idx]
     kv_cache.put_full_kv(layer_idx, fk, fv)
 
-    be = get_backend()
     attn_output = torch.empty_like(query_states)
     scale = head_dim ** -0.5
     if q_len == kv_seq_len:
@@ -96,6 +99,30 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
     kv_cache.update_streaming_kv(layer_idx, sk, sv)
     return attn_output
 
+def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, layer_idx, pos0, rope_scale,
+                       rope_theta):
+    """q_len == 1 after a prefill: the same steps as the general path below (RoPE, put_full_kv, the two
+    head-class attentions, the streaming update) issued as ONE backend call = three kernel launches,
+    with the cache counters updated exactly as put_full_kv / compress_and_replace_streaming_kv do."""
+    bsz, _, num_heads, head_dim = query_states.shape
+    nf = kv_cache.num_full_kv_head_list[layer_idx]
+    cur = kv_cache.kv_seq_len_list[layer_idx]
+    if nf > 0 and cur + 1 > kv_cache.max_size:
+        raise ValueError(
+            f"Trying to put 1 KVs into a cache with max size {kv_cache.max_size}, current size: {cur}."
+        )
+    str_len = kv_cache.streaming_kv_seq_len_list[layer_idx]
+    pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
+    sk, sv = kv_cache.streaming_key_states_list[layer_idx], kv_cache.streaming_value_states_list[layer_idx]
+    attn_output = torch.empty_like(query_states)
+    new_len = str_len
+    for b in range(bsz):
+        new_len = be.decode_layer(query_states[b, 0], key_states[b, 0], value_states[b, 0], attn_output[b, 0], nf,
+                                  pk[b], pv[b], cur, sk[b], sv[b], str_len, kv_cache.sink_size,
+                                  kv_cache.recent_size, pos0, rope_scale, rope_theta, head_dim ** -0.5)
+    kv_cache.kv_seq_len_list[layer_idx] = cur + 1
+    kv_cache.streaming_kv_seq_len_list[layer_idx] = new_len
+    return attn_output
 
 
 # =============================================================================

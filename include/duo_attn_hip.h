@@ -24,6 +24,7 @@
  *   duo_attn_prefill_bf16     flash_attn_func at llama.py:366-372 (first chunk,
  *                             all heads causal) and llama.py:392-421 (later
  *                             chunks, one call per head class)
+ *   duo_decode_layer_bf16     llama.py:332-425 for q_len == 1 (whole decode step of a layer)
  *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
@@ -134,6 +135,46 @@ int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
                          const duo_head_class *full, const duo_head_class *stream_cls,
                          float scale, int32_t head_dim, void *workspace,
                          int64_t workspace_bytes, void *stream);
+
+/* ---- one decode step of one layer of the static dual-cache path, fused ------
+ * Everything reference llama.py:332-425 does for q_len == 1 after a prefill
+ * (RoPE in place, put_full_kv, the two flash_attn_func calls, the torch.cat and
+ * compress_and_replace_streaming_kv) in THREE launches:
+ *   1. RoPE of the new token's q/k heads + append of the retrieval K,V rows to
+ *      the full pool at row `full_len`;
+ *   2. the split-KV scan of both head classes (as duo_attn_decode_bf16);
+ *   3. merge of the partials + the streaming pool's sink+recent update.
+ * kv heads [0, n_full) are retrieval heads, the rest streaming heads; q heads
+ * follow in the same order (n_q_heads / n_kv_heads per kv head).
+ * *new_stream_len receives the streaming pool length after the step.          */
+typedef struct duo_decode_layer_args {
+    void *q;                 /* [n_q_heads, 128], rotated in place                */
+    int64_t q_head_stride;
+    int32_t n_q_heads;
+    int32_t n_kv_heads;
+    void *k;                 /* [n_kv_heads, 128] new key rows, rotated in place  */
+    const void *v;           /* [n_kv_heads, 128] new value rows                  */
+    int64_t kv_head_stride;
+    void *out;               /* [n_q_heads, 128]                                  */
+    int64_t out_head_stride;
+    int32_t n_full;
+    int32_t head_dim;
+    void *full_k, *full_v;   /* full pool, row 0 / head 0                         */
+    int64_t full_token_stride, full_head_stride;
+    int32_t full_len;        /* rows cached before this token                     */
+    int32_t full_capacity;   /* rows allocated                                    */
+    void *str_k, *str_v;     /* streaming pool                                    */
+    int64_t str_token_stride, str_head_stride;
+    int32_t str_len;
+    int32_t sink, recent;
+    int32_t _pad;
+    int64_t pos;             /* position id of the new token                      */
+    float rope_scale, rope_theta;
+    float scale;             /* softmax scale                                     */
+    float _pad2;
+} duo_decode_layer_args;
+int duo_decode_layer_bf16(const duo_decode_layer_args *args, int32_t *new_stream_len,
+                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
  * q/out: [S, n_q_heads, 128] with the given token/head strides.               */

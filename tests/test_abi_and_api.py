@@ -117,3 +117,30 @@ def test_parse_args_keeps_reference_flags():
                     "--prefilling_chunk_size", "32000", "--device", "0", "--seed", "42"])
     assert a.sparsity == 0.5 and a.prefilling_chunk_size == 32000 and a.device == "cuda:0"
     assert a.sink_size == 64 and a.recent_size == 256
+
+
+def test_decode_layer_struct_layout():
+    """ctypes mirror of duo_decode_layer_args == the C struct (offsets checked against gcc's layout of
+    include/duo_attn_hip.h)."""
+    import subprocess
+    import tempfile
+
+    from duo_attn import _hip
+
+    src = r'''
+#include "%s"
+#include <stdio.h>
+#include <stddef.h>
+int main() {
+  printf("%%zu %%zu %%zu %%zu %%zu %%zu\n", sizeof(duo_decode_layer_args), offsetof(duo_decode_layer_args, k),
+         offsetof(duo_decode_layer_args, full_k), offsetof(duo_decode_layer_args, str_len),
+         offsetof(duo_decode_layer_args, pos), offsetof(duo_decode_layer_args, scale));
+  return 0;
+}''' % HEADER
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        subprocess.run(["gcc", c, "-o", os.path.join(d, "t")], check=True)
+        got = [int(x) for x in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
+    A = _hip.DecodeLayerArgs
+    assert got == [ctypes.sizeof(A), A.k.offset, A.full_k.offset, A.str_len.offset, A.pos.offset, A.scale.offset]

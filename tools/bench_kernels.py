@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the two attention kernels alone (for A/B work and PMC passes).
+
+    python tools/bench_kernels.py prefill --nf 4 --past 65536 --chunk 16384 --reps 5
+    python tools/bench_kernels.py decode  --ctx 131072 --reps 20        # all 32 layers of the bench pattern
+Prints one JSON line per case: avg ms, algorithmic TFLOP/s or GB/s.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "duo-attention_amd"))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+HQ, HKV, D, W = 32, 8, 128, 384
+
+
+def pools(n_heads, rows, dev, g):
+    k = torch.randn(n_heads, rows, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).permute(1, 0, 2)
+    v = torch.randn(n_heads, rows, D, generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16).permute(1, 0, 2)
+    return k, v
+
+
+def time_it(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(x.elapsed_time(y) for x, y in evs)
+    return sum(ts) / len(ts), ts[0], ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["prefill", "decode"])
+    ap.add_argument("--nf", type=int, default=4)
+    ap.add_argument("--past", type=int, default=65536)
+    ap.add_argument("--chunk", type=int, default=16384)
+    ap.add_argument("--ctx", type=int, default=131072)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--flags", type=int, default=0)
+    a = ap.parse_args()
+    from duo_attn import _hip
+    from duo_attn.backend import get_backend
+
+    be = get_backend()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0)
+    G = HQ // HKV
+    scale = D ** -0.5
+    if a.what == "prefill":
+        nf, ns, S, past = a.nf, HKV - a.nf, a.chunk, a.past
+        q = torch.randn(S, HQ, D, generator=g, device=dev).to(torch.bfloat16)
+        kn, vn = pools(HKV, S, dev, g)
+        out = torch.empty_like(q)
+        fk, fv = pools(max(nf, 1), past + S, dev, g)
+        sk, sv = pools(max(ns, 1), W, dev, g)
+        full = (nf, 0, (fk[:past, :nf], fv[:past, :nf]), (fk[past:past + S, :nf], fv[past:past + S, :nf])) if nf else None
+        stream = (ns, nf * G, (sk[:, :ns], sv[:, :ns]), (kn[:, nf:], vn[:, nf:])) if ns else None
+        _hip.set_debug_flags(a.flags)
+        avg, mn, med = time_it(lambda: be.attention(q, out, G, full, stream, scale), a.reps)
+        tri = S * (S + 1) / 2
+        flops = 4 * D * G * (nf * (S * past + tri) + ns * (S * min(past, W) + tri))
+        print(json.dumps({"case": f"prefill nf={nf} past={past} S={S}", "avg_ms": avg, "min_ms": mn,
+                          "tflops_avg": flops / avg / 1e9, "tflops_best": flops / mn / 1e9}))
+    else:
+        import bench
+
+        counts = bench.LLAMA3_8B_FULL_KV_HEADS
+        N = a.ctx
+        q = torch.randn(1, HQ, D, generator=g, device=dev).to(torch.bfloat16)
+        kn, vn = pools(HKV, 1, dev, g)
+        out = torch.empty_like(q)
+        layers = []
+        for nf in counts:
+            ns = HKV - nf
+            fk, fv = pools(max(nf, 1), N + 1, dev, g)
+            sk, sv = pools(max(ns, 1), W, dev, g)
+            full = (nf, 0, (fk[:N, :nf], fv[:N, :nf]), (fk[N:N + 1, :nf], fv[N:N + 1, :nf])) if nf else None
+            stream = (ns, nf * G, (sk[:, :ns], sv[:, :ns]), (kn[:, nf:], vn[:, nf:])) if ns else None
+            layers.append((full, stream))
+        _hip.set_debug_flags(a.flags | 2)
+
+        def step():
+            for full, stream in layers:
+                be.attention(q, out, G, full, stream, scale)
+
+        avg, mn, med = time_it(step, a.reps)
+        nbytes = sum(bench.decode_bytes(counts, N))
+        print(json.dumps({"case": f"decode split kernel x32 layers ctx={N}", "avg_ms": avg, "min_ms": mn,
+                          "GBps_avg": nbytes / avg / 1e6, "GBps_best": nbytes / mn / 1e6,
+                          "frac_of_8TBps": nbytes / avg / 1e6 / 8000}))
+        _hip.set_debug_flags(0)
+
+
+if __name__ == "__main__":
+    main()
