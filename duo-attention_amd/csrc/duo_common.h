@@ -64,6 +64,27 @@ struct DuoClassDev {
     DuoSegDev b;
 };
 
+// Field-wise select between two class descriptors living in the kernarg segment.  Indexing a by-value
+// kernel argument with a runtime index (P.cls[ci]) makes hipcc copy the struct to scratch and reload
+// it with VMEM instructions inside the hot loop; scalar selects keep everything in SGPRs.
+__device__ __forceinline__ DuoSegDev duo_select(const DuoSegDev &a, const DuoSegDev &b, bool pick_b) {
+    DuoSegDev r;
+    r.k = pick_b ? b.k : a.k;
+    r.v = pick_b ? b.v : a.v;
+    r.token_stride = pick_b ? b.token_stride : a.token_stride;
+    r.head_stride = pick_b ? b.head_stride : a.head_stride;
+    r.len = pick_b ? b.len : a.len;
+    return r;
+}
+__device__ __forceinline__ DuoClassDev duo_select(const DuoClassDev &a, const DuoClassDev &b, bool pick_b) {
+    DuoClassDev r;
+    r.n_kv_heads = pick_b ? b.n_kv_heads : a.n_kv_heads;
+    r.q_head_offset = pick_b ? b.q_head_offset : a.q_head_offset;
+    r.a = duo_select(a.a, b.a, pick_b);
+    r.b = duo_select(a.b, b.b, pick_b);
+    return r;
+}
+
 static inline DuoSegDev duo_seg_dev(const duo_kv_seg &s) {
     DuoSegDev d;
     d.k = (const bf16_t *)s.k;

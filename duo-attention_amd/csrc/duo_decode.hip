@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     int b = blockIdx.x;
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
-    const DuoClassDev &C = P.cls[ci];
-    const int splits = P.splits[ci];
+    const DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    const int splits = ci ? P.splits[1] : P.splits[0];
     const int kvh = b / splits;
     const int split = b - kvh * splits;
     const int qh0 = C.q_head_offset + kvh * P.group + blockIdx.y * GT;

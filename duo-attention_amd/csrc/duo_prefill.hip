@@ -16,27 +16,33 @@
 //   * O^T[d][q] = V^T . P^T: the softmax scale factors stay lane-local too and
 //     P^T feeds the MFMA B operand straight from the score registers (the key
 //     order inside a 16-key step is permuted identically on the V^T side);
+//   * deferred rescale: the running max only moves (and O is only rescaled)
+//     when some row's max grew by more than 2^8;
 //   * K tile [64][128] in LDS, 16-B chunks XOR-swizzled by (row & 15) ->
 //     conflict-free ds_read_b128 for the A operand;
 //   * V tile in LDS as [key/4][dim/16][4][16] blocks read with
 //     ds_read_b64_tr_b16 (hardware transpose) -> V^T A operand with no shuffles;
-//   * K/V tiles double-buffered in LDS, the next tile's global loads are issued
-//     before the MFMA work on the current one and written to LDS after it
-//     (register staging; one barrier per tile);
+//   * K/V tiles arrive by LDS-DMA (global_load_lds_dwordx4, swizzle / block
+//     layout applied on the per-lane source address) into a THREE-deep LDS ring:
+//     tile t+2 is requested while tile t is consumed, and the only wait is a
+//     counted s_waitcnt vmcnt(4) (= "tile t+1 has landed") in front of ONE raw
+//     s_barrier per tile — the loads stay in flight across the barrier;
 //   * causal tiles beyond a wave's last row are skipped per wave; blocks are
 //     ordered heaviest-first, and the q heads that share a kv head are mapped to
 //     the same XCD (block id % 8) so K/V tiles are shared through one L2.
+#include <type_traits>
 #include "duo_common.h"
 
 namespace {
 
 constexpr int QBLK = 256;   // query rows per workgroup
 constexpr int KVBLK = 64;   // keys per tile
-constexpr int NWAVE = 8;
 constexpr int K_TILE_BYTES = KVBLK * DUO_HEAD_DIM * 2;  // 16 KiB
 constexpr int V_TILE_BYTES = K_TILE_BYTES;
 constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;               // 64 KiB
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;          // 96 KiB
+// each wave issues 4 global_load_lds per tile (2 K pieces + 2 V pieces): the vmcnt(4) below
 constexpr float kDeferLog2 = 8.0f;   // deferred-rescale threshold in the exp2 domain
 
 struct PrefillParams {
@@ -53,15 +59,19 @@ struct PrefillParams {
     uint32_t flags;
 };
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     f32x2 v = {lo, hi};
     hw_bf16x2 r = __builtin_convertvector(v, hw_bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
     return *reinterpret_cast<uint32_t *>(&r);
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }
 
 struct TileSrc {
@@ -90,70 +100,117 @@ __device__ __forceinline__ TileSrc tile_src(const DuoClassDev &C, int kvh, int t
     return s;
 }
 
-// 512 threads fetch one 64x128 K tile and one V tile: 2 x 16 B of each per thread.
-// K: thread -> (row = idx/16, 16-B chunk = idx%16): 16 lanes read one 256-B row.
-// V: within each wave the lanes are permuted so that 8 consecutive lanes hold one 128-B LDS block
-//    ([4 keys][16 dims]) -> conflict-free ds_write_b128; a wave still reads 4 whole rows.
-__device__ __forceinline__ void v_stage_coord(int idx, int &row, int &ch) {
-    const int l = idx & 63;
-    row = ((idx >> 6) << 2) + ((l & 7) >> 1);     // 4 rows per wave-load
-    ch = ((l >> 3) << 1) + (l & 1);               // dim block (l>>3), half (l&1)
-}
-__device__ __forceinline__ void stage_load(const TileSrc &s, int tid, u32x4 (&kr)[2], u32x4 (&vr)[2]) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = tid + 512 * j;
-        const int row = idx >> 4;
-        const int ch = idx & 15;
-        const int r = s.row0 + min(row, s.cnt - 1);
-        kr[j] = *reinterpret_cast<const u32x4 *>(s.k + (int64_t)r * s.ts + ch * 8);
-        int vrow, vch;
-        v_stage_coord(idx, vrow, vch);
-        const int rv = s.row0 + min(vrow, s.cnt - 1);
-        vr[j] = *reinterpret_cast<const u32x4 *>(s.v + (int64_t)rv * s.ts + vch * 8);
-    }
-}
-
 __device__ __forceinline__ int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
-// V image: [key/4][dim/16][4 keys][16 dims] bf16, 128-B blocks
-__device__ __forceinline__ int v_lds_off(int row, int d) {
-    return (((row >> 2) * 8 + (d >> 4)) << 7) + ((row & 3) << 5) + ((d & 15) << 1);
+
+// LDS-DMA staging: HBM/L2 -> LDS without the VGPR round trip and without ds_write.  The LDS
+// destination of a wave-instruction is wave-uniform base + lane*16 (one contiguous KiB), so the K
+// swizzle and the V block layout are applied on the per-lane SOURCE address:
+//   K piece w = rows 4w..4w+3, LDS chunk p of row r holds source chunk p ^ (r & 15);
+//   V piece w = key quad w = 8 blocks [4 keys][16 dims]  (byte (key,d): ((key/4)*8 + d/16)*128
+//               + (key%4)*32 + (d%16)*2).
+// 512 threads: 16 pieces of K and 16 of V per tile, 2 of each per wave (DMA_PER_TILE = 4).
+//
+// Issued through inline asm: hipcc orders two LDS-DMA writes whose destinations it cannot tell apart
+// (runtime ring slot) with an s_waitcnt vmcnt(0) in front of the second one, and drains the DMA
+// before LDS reads it cannot disambiguate — either would collapse the ring to depth one.  asm VMEM
+// operations are invisible to its waitcnt pass (they can only make its own waits more conservative),
+// so the kernel counts them itself: DMA_PER_TILE per wave per tile, waited with s_waitcnt vmcnt(N).
+// M0 (the LDS destination base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const bf16_t *gsrc, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+// same, address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: the
+// per-tile address arithmetic is scalar, the lane offsets are loop invariants -> no VALU per tile
+__device__ __forceinline__ void glds16_s(const bf16_t *sbase_uniform, uint32_t voff_bytes, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_dst_uniform)
+        : "memory");
 }
 
-__device__ __forceinline__ void stage_write(char *stage, int tid, const u32x4 (&kr)[2], const u32x4 (&vr)[2]) {
+// per-lane source byte offsets of piece j=0 inside a tile of a segment with token stride ts
+struct DmaLane {
+    uint32_t kofs, vofs;
+};
+__device__ __forceinline__ DmaLane dma_lane(int tid, int64_t ts) {
+    const int lane = tid & 63;
+    const int w0 = tid >> 6;
+    const int krow = 4 * w0 + (lane >> 4);
+    const int kch = (lane & 15) ^ (krow & 15);
+    const int vrow = 4 * w0 + ((lane & 7) >> 1);
+    const int vch = ((lane >> 3) << 1) + (lane & 1);
+    DmaLane d;
+    d.kofs = (uint32_t)(krow * ts + kch * 8) * 2u;
+    d.vofs = (uint32_t)(vrow * ts + vch * 8) * 2u;
+    return d;
+}
+
+// general form (tail tiles: rows past the segment end are clamped to its last row)
+__device__ __forceinline__ void stage_dma_tail(const TileSrc &s, uint32_t stage_lds, int tid) {
+    const int lane = tid & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int idx = tid + 512 * j;
-        const int row = idx >> 4;
-        const int ch = idx & 15;
-        *reinterpret_cast<u32x4 *>(stage + k_lds_off(row, ch)) = kr[j];
-        int vrow, vch;
-        v_stage_coord(idx, vrow, vch);
-        *reinterpret_cast<u32x4 *>(stage + K_TILE_BYTES + v_lds_off(vrow, vch * 8)) = vr[j];
+        const int piece = w0 + 8 * j;                    // 0..15, wave-uniform
+        const int krow = 4 * piece + (lane >> 4);
+        const int kch = (lane & 15) ^ (krow & 15);
+        const int rk = s.row0 + min(krow, s.cnt - 1);
+        glds16(s.k + (int64_t)rk * s.ts + kch * 8, base + piece * 1024);
+        const int vrow = 4 * piece + ((lane & 7) >> 1);
+        const int vch = ((lane >> 3) << 1) + (lane & 1);
+        const int rv = s.row0 + min(vrow, s.cnt - 1);
+        glds16(s.v + (int64_t)rv * s.ts + vch * 8, base + K_TILE_BYTES + piece * 1024);
     }
 }
 
-template <bool USE_TR>
-__device__ __forceinline__ bf16x8 load_vt_frag(const char *vst, int kq, int blk16, int lane15) {
-    // keys 4*kq..4*kq+3 and 4*(kq+2)..4*(kq+2)+3 of dim column (blk16*16 + lane15)
-    const int b0 = ((kq * 8 + blk16) << 7);
-    const int b1 = (((kq + 2) * 8 + blk16) << 7);
-    bf16x8 r;
-    if constexpr (USE_TR) {
-        // each lane of a 16-lane group points at its 8-byte piece of the
-        // row-major 4x16 block; the hardware hands lane i column i
-        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vst + b0 + lane15 * 8));
-        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(vst + b1 + lane15 * 8));
-        r[0] = x[0]; r[1] = x[1]; r[2] = x[2]; r[3] = x[3];
-        r[4] = y[0]; r[5] = y[1]; r[6] = y[2]; r[7] = y[3];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            r[j] = *reinterpret_cast<const short *>(vst + b0 + j * 32 + lane15 * 2);
-            r[4 + j] = *reinterpret_cast<const short *>(vst + b1 + j * 32 + lane15 * 2);
-        }
-    }
-    return r;
+// full 64-row tile: scalar tile base + loop-invariant lane offsets
+__device__ __forceinline__ void stage_dma_full(const TileSrc &s, const DmaLane &L, uint32_t stage_lds, int tid) {
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds) + w0 * 1024;
+    const bf16_t *kb = s.k + (int64_t)s.row0 * s.ts;     // wave-uniform
+    const bf16_t *vb = s.v + (int64_t)s.row0 * s.ts;
+    const int64_t half = 32 * s.ts;                      // piece j=1 starts 32 rows further
+    glds16_s(kb, L.kofs, base);
+    glds16_s(vb, L.vofs, base + K_TILE_BYTES);
+    glds16_s(kb + half, L.kofs, base + 8 * 1024);
+    glds16_s(vb + half, L.vofs, base + K_TILE_BYTES + 8 * 1024);
+}
+
+// ds_read_b64_tr_b16 through inline asm: hipcc treats the builtin form as possibly aliasing the
+// LDS-DMA in flight and drains it (s_waitcnt vmcnt(0)) before the first read of every tile, which
+// would undo the counted-vmcnt pipeline.  asm loads are invisible to the waitcnt pass, so their
+// completion is waited for by hand (lgkmcnt) before the MFMAs that consume them.
+#define DUO_TR_READ(dst, addr, off) \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+// the 8 transpose reads (4 output dim blocks x 2 key quads) of PV k-step `step` (= 2*bb + s)
+#define DUO_TR_STEP(buf, vaddr, ibase, step)                                          \
+    do {                                                                              \
+        _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                         \
+            DUO_TR_READ(buf[2 * db_], vaddr, (ibase) + (step) * 4096 + db_ * 256);    \
+            DUO_TR_READ(buf[2 * db_ + 1], vaddr, (ibase) + (step) * 4096 + db_ * 256 + 2048); \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ bf16x8 join_frag(const u32x2 &a, const u32x2 &b) {
+    u32x4 w = {a.x, a.y, b.x, b.y};
+    return *reinterpret_cast<bf16x8 *>(&w);
 }
 
 template <bool USE_TR>
@@ -170,7 +227,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     int b = blockIdx.x;
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
-    const DuoClassDev &C = P.cls[ci];
+    const DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
     const int nq_c = C.n_kv_heads * P.group;
     const int tile = P.n_qtiles - 1 - b / nq_c;   // heaviest (latest) tiles first
     const int p = b % nq_c;
@@ -207,22 +264,52 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     float lsum = 0.f;
     const float c = P.scale_log2e;
 
-    u32x4 kr[2], vr[2];
-    {
-        const TileSrc s0 = tile_src(C, kvh, 0, nA, S);
-        stage_load(s0, tid, kr, vr);
-        stage_write(smem, tid, kr, vr);
+    // ---- loop invariants: LDS read offsets and DMA lane offsets -----------------
+    const uint32_t smem_lds = lds_addr(smem);
+    uint32_t koff[8];    // K fragment of k-step kk, key block 0 (block 1: +8192), ring slot 0
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) koff[kk] = smem_lds + k_lds_off(l31, 2 * kk + hi);
+    // V^T fragment base: key quad hi, dim block (l31>>4), this lane's 8-byte piece of the 4x16 block
+    const uint32_t vaddr = smem_lds + K_TILE_BYTES + hi * 1024 + (l31 >> 4) * 128 + lane15 * 8;
+    const DmaLane dmaA = dma_lane(tid, C.a.token_stride);
+    const DmaLane dmaB = dma_lane(tid, C.b.token_stride);
+
+    auto issue_dma = [&](int t, int slot_) {
+        const TileSrc ts_ = tile_src(C, kvh, t, nA, S);
+        const uint32_t dst = smem_lds + slot_ * STAGE_BYTES;
+        if (ts_.cnt == KVBLK) stage_dma_full(ts_, t < nA ? dmaA : dmaB, dst, tid);
+        else stage_dma_tail(ts_, dst, tid);
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight, wait for tile 0 only ---------------
+    // (the Q loads above are older in the VMEM queue, so either wait also covers them)
+    issue_dma(0, 0);
+    if (nT > 1) {
+        issue_dma(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // Touch the Q fragments here so that hipcc waits for their loads NOW.  Otherwise it places the
+    // s_waitcnt vmcnt ladder at their first use inside the loop, where it re-executes every
+    // iteration and drains the (asm-issued, to it invisible) LDS-DMA each time.
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) asm volatile("" ::"v"(qfrag[kk]));
+    __builtin_amdgcn_sched_barrier(0);
 
-    for (int t = 0; t < nT; ++t) {
-        char *stage = smem + (t & 1) * STAGE_BYTES;
-        const bool has_next = t + 1 < nT;
-        if (has_next) {
-            const TileSrc sn = tile_src(C, kvh, t + 1, nA, S);
-            stage_load(sn, tid, kr, vr);
-        }
-
+    // One tile.  SLOT (= t % 3) is a compile-time constant so that every LDS address of the body is
+    // a loop-invariant VGPR plus an immediate: the tile loop is unrolled by the ring depth.
+    auto tile_body = [&](auto slot_c, int t) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        constexpr int SOFF = SLOT * STAGE_BYTES;
+        const bool more2 = t + 2 < nT;
+#ifndef DUO_ABLATE_STAGE
+        // ring slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, which every wave left through
+        // that iteration's barrier
+        if (more2) issue_dma(t + 2, (SLOT + 2) % NSTAGE);
+#endif
         const bool inB = t >= nA;
         const int key0 = inB ? (t - nA) * KVBLK : t * KVBLK;   // first key of the tile in its segment
         const int cnt = inB ? min(KVBLK, S - key0) : min(KVBLK, lenA - key0);
@@ -232,16 +319,16 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
         if (!skip) {
             // ---- S^T = K . Q^T  (two 32-key blocks) ---------------------------
             f32x16 sc[2];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_s_setprio(1);
+            // kk outer, key block inner: consecutive MFMAs alternate between the two accumulators
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb) {
+            for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sc[bb][r] = 0.f;
-                const int row = bb * 32 + l31;
-#pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(stage + k_lds_off(row, 2 * kk + hi));
-                    sc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[kk], sc[bb], 0, 0, 0);
+                for (int bb = 0; bb < 2; ++bb) {
+                    typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+                    const bf16x8 kf = *(lds_frag_t *)(uintptr_t)(koff[kk] + SOFF + bb * 8192);
+                    sc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[kk], kk == 0 ? zero16 : sc[bb], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -282,14 +369,18 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             }
             const float mc = mrow * c;
             float psum = 0.f;
-            bf16x8 pf[2][2];
+            bf16x8 pf[4];   // P^T B operands of the four PV k-steps (step = 2*bb + s)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
                 float pv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#ifdef DUO_ABLATE_SOFTMAX
+                    pv[r] = sc[bb][r] - mc;
+#else
                     pv[r] = fast_exp2(fmaf(sc[bb][r], c, -mc));
                     psum += pv[r];
+#endif
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -298,31 +389,109 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     w.y = cvt_pk_bf16(pv[8 * s + 2], pv[8 * s + 3]);
                     w.z = cvt_pk_bf16(pv[8 * s + 4], pv[8 * s + 5]);
                     w.w = cvt_pk_bf16(pv[8 * s + 6], pv[8 * s + 7]);
-                    pf[bb][s] = *reinterpret_cast<bf16x8 *>(&w);
+                    pf[2 * bb + s] = *reinterpret_cast<bf16x8 *>(&w);
                 }
             }
             lsum += psum;
 
             // ---- O^T += V^T . P^T ----------------------------------------------
-            const char *vst = stage + K_TILE_BYTES;
-            __builtin_amdgcn_s_setprio(1);
+            // k-step `step` covers keys 32*bb + 16*s + {4hi..4hi+3, 8+4hi..8+4hi+3}: key quads
+            // kq = 4*step + hi and kq + 2; quad kq / dim block blk16 sits at byte (kq*8 + blk16)*128.
+            if constexpr (USE_TR) {
+#ifndef DUO_PV_BUILTIN
+                // hand-pipelined: the 8 transpose reads of k-step n+1 are issued before the 4 MFMAs of
+                // k-step n, completion counted with lgkmcnt (asm loads are invisible to hipcc's waitcnt
+                // pass, rule 18: sched_barrier after each wait).
+                // the ds_read offset field is 16 bits: slot 2 needs its base folded into the address
+                const uint32_t va_ = SOFF >= 32768 ? vaddr + SOFF : vaddr;
+                constexpr int VO = SOFF >= 32768 ? 0 : SOFF;
+                u32x2 va[8], vb[8];
+                __builtin_amdgcn_sched_barrier(0);
+                DUO_TR_STEP(va, va_, VO, 0);
+                DUO_TR_STEP(vb, va_, VO, 1);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const int blk16 = 2 * db + (l31 >> 4);
+                for (int db = 0; db < 4; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(va[2 * db], va[2 * db + 1]), pf[0], o[db], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                DUO_TR_STEP(va, va_, VO, 2);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
+                for (int db = 0; db < 4; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(vb[2 * db], vb[2 * db + 1]), pf[1], o[db], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                DUO_TR_STEP(vb, va_, VO, 3);
+                asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int kq = 8 * bb + 4 * s + hi;
-                        const bf16x8 vf = load_vt_frag<USE_TR>(vst, kq, blk16, lane15);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[bb][s], o[db], 0, 0, 0);
+                for (int db = 0; db < 4; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(va[2 * db], va[2 * db + 1]), pf[2], o[db], 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int db = 0; db < 4; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(vb[2 * db], vb[2 * db + 1]), pf[3], o[db], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+#else
+                // alternative (-DDUO_PV_BUILTIN): builtin transpose reads scheduled by hipcc — measured
+                // 1.5 % slower than the hand-pipelined asm reads above (same run, nf=4 past=64K).
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int step = 0; step < 4; ++step)
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        const uint32_t a0 = vaddr + SOFF + step * 4096 + db * 256;
+                        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)a0);
+                        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(a0 + 2048));
+                        bf16x8 vf;
+                        vf[0] = x[0]; vf[1] = x[1]; vf[2] = x[2]; vf[3] = x[3];
+                        vf[4] = y[0]; vf[5] = y[1]; vf[6] = y[2]; vf[7] = y[3];
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[step], o[db], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+#endif
+            } else {
+                // debugging aid (duo_set_debug_flags bit 0): scalar LDS gathers instead of the transpose read
+                const char *vst = smem + SOFF + K_TILE_BYTES;
+#pragma unroll
+                for (int step = 0; step < 4; ++step)
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) {
+                        const int blk16 = 2 * db + (l31 >> 4);
+                        const int b0 = (((4 * step + hi) * 8 + blk16) << 7);
+                        bf16x8 vf;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            vf[j] = *reinterpret_cast<const short *>(vst + b0 + j * 32 + lane15 * 2);
+                            vf[4 + j] = *reinterpret_cast<const short *>(vst + b0 + 2048 + j * 32 + lane15 * 2);
+                        }
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[step], o[db], 0, 0, 0);
                     }
             }
-            __builtin_amdgcn_s_setprio(0);
         }
 
-        if (has_next) stage_write(smem + ((t + 1) & 1) * STAGE_BYTES, tid, kr, vr);
-        __syncthreads();
+        // ---- tile t+1 must have landed (tile t+2 may stay in flight), then ONE barrier:
+        //      it publishes tile t+1 and retires every read of ring slot t%3
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef DUO_ABLATE_STAGE
+        if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef DUO_ABLATE_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    for (int t = 0; t < nT; t += NSTAGE) {
+        tile_body(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nT) tile_body(std::integral_constant<int, 1>{}, t + 1);
+        if (t + 2 < nT) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
 
     // ---- epilogue: O^T / l -> out[q][qh][d] -----------------------------------
