@@ -30,195 +30,16 @@
 //   * causal tiles beyond a wave's last row are skipped per wave; blocks are
 //     ordered heaviest-first, and the q heads that share a kv head are mapped to
 //     the same XCD (block id % 8) so K/V tiles are shared through one L2.
-#include <type_traits>
-#include "duo_common.h"
+#include "duo_prefill_common.h"
 
 namespace {
-
-constexpr int QBLK = 256;   // query rows per workgroup
-constexpr int KVBLK = 64;   // keys per tile
-constexpr int K_TILE_BYTES = KVBLK * DUO_HEAD_DIM * 2;  // 16 KiB
-constexpr int V_TILE_BYTES = K_TILE_BYTES;
-constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
-constexpr int NSTAGE = 3;
-constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;          // 96 KiB
-// each wave issues 4 global_load_lds per tile (2 K pieces + 2 V pieces): the vmcnt(4) below
-constexpr float kDeferLog2 = 8.0f;   // deferred-rescale threshold in the exp2 domain
-
-struct PrefillParams {
-    const bf16_t *q;
-    int64_t q_ts, q_hs;
-    bf16_t *out;
-    int64_t o_ts, o_hs;
-    int32_t S;
-    int32_t group;
-    int32_t n_qtiles;
-    int32_t nblk_full;     // cls[0] q heads * n_qtiles
-    DuoClassDev cls[2];
-    float scale_log2e;
-    uint32_t flags;
-};
-
-typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    f32x2 v = {lo, hi};
-    hw_bf16x2 r = __builtin_convertvector(v, hw_bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
-    return *reinterpret_cast<uint32_t *>(&r);
-}
-
-__device__ __forceinline__ uint32_t lds_addr(const void *p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
-}
-
-struct TileSrc {
-    const bf16_t *k;
-    const bf16_t *v;
-    int64_t ts;
-    int32_t row0;
-    int32_t cnt;   // valid rows in the tile (1..64)
-};
-
-__device__ __forceinline__ TileSrc tile_src(const DuoClassDev &C, int kvh, int t, int nA, int S) {
-    TileSrc s;
-    if (t < nA) {
-        s.k = C.a.k + (int64_t)kvh * C.a.head_stride;
-        s.v = C.a.v + (int64_t)kvh * C.a.head_stride;
-        s.ts = C.a.token_stride;
-        s.row0 = t * KVBLK;
-        s.cnt = min(KVBLK, C.a.len - s.row0);
-    } else {
-        s.k = C.b.k + (int64_t)kvh * C.b.head_stride;
-        s.v = C.b.v + (int64_t)kvh * C.b.head_stride;
-        s.ts = C.b.token_stride;
-        s.row0 = (t - nA) * KVBLK;
-        s.cnt = min(KVBLK, S - s.row0);
-    }
-    return s;
-}
-
-__device__ __forceinline__ int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
-
-// LDS-DMA staging: HBM/L2 -> LDS without the VGPR round trip and without ds_write.  The LDS
-// destination of a wave-instruction is wave-uniform base + lane*16 (one contiguous KiB), so the K
-// swizzle and the V block layout are applied on the per-lane SOURCE address:
-//   K piece w = rows 4w..4w+3, LDS chunk p of row r holds source chunk p ^ (r & 15);
-//   V piece w = key quad w = 8 blocks [4 keys][16 dims]  (byte (key,d): ((key/4)*8 + d/16)*128
-//               + (key%4)*32 + (d%16)*2).
-// 512 threads: 16 pieces of K and 16 of V per tile, 2 of each per wave (DMA_PER_TILE = 4).
-//
-// Issued through inline asm: hipcc orders two LDS-DMA writes whose destinations it cannot tell apart
-// (runtime ring slot) with an s_waitcnt vmcnt(0) in front of the second one, and drains the DMA
-// before LDS reads it cannot disambiguate — either would collapse the ring to depth one.  asm VMEM
-// operations are invisible to its waitcnt pass (they can only make its own waits more conservative),
-// so the kernel counts them itself: DMA_PER_TILE per wave per tile, waited with s_waitcnt vmcnt(N).
-// M0 (the LDS destination base) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16(const bf16_t *gsrc, uint32_t lds_dst_uniform) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst_uniform)
-        : "memory");
-}
-// same, address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: the
-// per-tile address arithmetic is scalar, the lane offsets are loop invariants -> no VALU per tile
-__device__ __forceinline__ void glds16_s(const bf16_t *sbase_uniform, uint32_t voff_bytes, uint32_t lds_dst_uniform) {
-    uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_dst_uniform)
-        : "memory");
-}
-
-// per-lane source byte offsets of piece j=0 inside a tile of a segment with token stride ts
-struct DmaLane {
-    uint32_t kofs, vofs;
-};
-__device__ __forceinline__ DmaLane dma_lane(int tid, int64_t ts) {
-    const int lane = tid & 63;
-    const int w0 = tid >> 6;
-    const int krow = 4 * w0 + (lane >> 4);
-    const int kch = (lane & 15) ^ (krow & 15);
-    const int vrow = 4 * w0 + ((lane & 7) >> 1);
-    const int vch = ((lane >> 3) << 1) + (lane & 1);
-    DmaLane d;
-    d.kofs = (uint32_t)(krow * ts + kch * 8) * 2u;
-    d.vofs = (uint32_t)(vrow * ts + vch * 8) * 2u;
-    return d;
-}
-
-// general form (tail tiles: rows past the segment end are clamped to its last row)
-__device__ __forceinline__ void stage_dma_tail(const TileSrc &s, uint32_t stage_lds, int tid) {
-    const int lane = tid & 63;
-    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int piece = w0 + 8 * j;                    // 0..15, wave-uniform
-        const int krow = 4 * piece + (lane >> 4);
-        const int kch = (lane & 15) ^ (krow & 15);
-        const int rk = s.row0 + min(krow, s.cnt - 1);
-        glds16(s.k + (int64_t)rk * s.ts + kch * 8, base + piece * 1024);
-        const int vrow = 4 * piece + ((lane & 7) >> 1);
-        const int vch = ((lane >> 3) << 1) + (lane & 1);
-        const int rv = s.row0 + min(vrow, s.cnt - 1);
-        glds16(s.v + (int64_t)rv * s.ts + vch * 8, base + K_TILE_BYTES + piece * 1024);
-    }
-}
-
-// full 64-row tile: scalar tile base + loop-invariant lane offsets
-__device__ __forceinline__ void stage_dma_full(const TileSrc &s, const DmaLane &L, uint32_t stage_lds, int tid) {
-    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds) + w0 * 1024;
-    const bf16_t *kb = s.k + (int64_t)s.row0 * s.ts;     // wave-uniform
-    const bf16_t *vb = s.v + (int64_t)s.row0 * s.ts;
-    const int64_t half = 32 * s.ts;                      // piece j=1 starts 32 rows further
-    glds16_s(kb, L.kofs, base);
-    glds16_s(vb, L.vofs, base + K_TILE_BYTES);
-    glds16_s(kb + half, L.kofs, base + 8 * 1024);
-    glds16_s(vb + half, L.vofs, base + K_TILE_BYTES + 8 * 1024);
-}
-
-// ds_read_b64_tr_b16 through inline asm: hipcc treats the builtin form as possibly aliasing the
-// LDS-DMA in flight and drains it (s_waitcnt vmcnt(0)) before the first read of every tile, which
-// would undo the counted-vmcnt pipeline.  asm loads are invisible to the waitcnt pass, so their
-// completion is waited for by hand (lgkmcnt) before the MFMAs that consume them.
-#define DUO_TR_READ(dst, addr, off) \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-
-// the 8 transpose reads (4 output dim blocks x 2 key quads) of PV k-step `step` (= 2*bb + s)
-#define DUO_TR_STEP(buf, vaddr, ibase, step)                                          \
-    do {                                                                              \
-        _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                         \
-            DUO_TR_READ(buf[2 * db_], vaddr, (ibase) + (step) * 4096 + db_ * 256);    \
-            DUO_TR_READ(buf[2 * db_ + 1], vaddr, (ibase) + (step) * 4096 + db_ * 256 + 2048); \
-        }                                                                             \
-    } while (0)
-
-__device__ __forceinline__ bf16x8 join_frag(const u32x2 &a, const u32x2 &b) {
-    u32x4 w = {a.x, a.y, b.x, b.y};
-    return *reinterpret_cast<bf16x8 *>(&w);
-}
 
 template <bool USE_TR>
 __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
     const int l31 = lane & 31;
     const int hi = lane >> 5;
     const int lane15 = lane & 15;
@@ -277,8 +98,8 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     auto issue_dma = [&](int t, int slot_) {
         const TileSrc ts_ = tile_src(C, kvh, t, nA, S);
         const uint32_t dst = smem_lds + slot_ * STAGE_BYTES;
-        if (ts_.cnt == KVBLK) stage_dma_full(ts_, t < nA ? dmaA : dmaB, dst, tid);
-        else stage_dma_tail(ts_, dst, tid);
+        if (ts_.cnt == KVBLK) stage_dma_full<8>(ts_, t < nA ? dmaA : dmaB, dst, tid);
+        else stage_dma_tail<8>(ts_, dst, tid);
     };
 
     // ---- prologue: tiles 0 and 1 in flight, wait for tile 0 only ---------------
@@ -514,6 +335,8 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 
 }  // namespace
 
+#include "duo_prefill_w64.h"
+
 static uint32_t g_debug_flags = 0;
 extern "C" void duo_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
 extern "C" uint32_t duo_get_debug_flags(void) { return g_debug_flags; }
@@ -558,17 +381,24 @@ extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int6
     P.nblk_full = P.cls[0].n_kv_heads * group * P.n_qtiles;
 
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e;
-    if (g_debug_flags & 1u) {
-        e = hipFuncSetAttribute((const void *)duo_prefill_kernel<false>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    const bool tr = !(g_debug_flags & 1u);
+    const bool w64 = (g_debug_flags & 16u) != 0;   // debug bit 4: the 4-wave x 64-row kernel
+    // (hipFuncSetAttribute is cheap but not free: once per kernel instantiation)
+    static bool attr_done[4] = {false, false, false, false};
+    const void *fn = w64 ? (tr ? (const void *)duo_prefill_w64_kernel<true> : (const void *)duo_prefill_w64_kernel<false>)
+                         : (tr ? (const void *)duo_prefill_kernel<true> : (const void *)duo_prefill_kernel<false>);
+    const int fi = (w64 ? 2 : 0) + (tr ? 1 : 0);
+    if (!attr_done[fi]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(duo_prefill_kernel<false>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
+        attr_done[fi] = true;
+    }
+    if (w64) {
+        if (tr) hipLaunchKernelGGL(duo_prefill_w64_kernel<true>, dim3(nblk), dim3(256), LDS_BYTES, st, P);
+        else hipLaunchKernelGGL(duo_prefill_w64_kernel<false>, dim3(nblk), dim3(256), LDS_BYTES, st, P);
     } else {
-        e = hipFuncSetAttribute((const void *)duo_prefill_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(duo_prefill_kernel<true>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
+        if (tr) hipLaunchKernelGGL(duo_prefill_kernel<true>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
+        else hipLaunchKernelGGL(duo_prefill_kernel<false>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
     }
     DUO_HIP_CHECK_LAUNCH();
     return 0;

@@ -1,0 +1,192 @@
+// Shared pieces of the two prefill kernels (8 waves x 32 rows, 4 waves x 64 rows): tile geometry,
+// parameter block, LDS layouts, LDS-DMA staging helpers.  Internal linkage, included by the .hip files.
+#pragma once
+#include <type_traits>
+#include "duo_common.h"
+
+namespace {
+
+constexpr int QBLK = 256;   // query rows per workgroup
+constexpr int KVBLK = 64;   // keys per tile
+constexpr int K_TILE_BYTES = KVBLK * DUO_HEAD_DIM * 2;  // 16 KiB
+constexpr int V_TILE_BYTES = K_TILE_BYTES;
+constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;
+constexpr int NSTAGE = 3;
+constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;          // 96 KiB
+// each wave issues 4 global_load_lds per tile (2 K pieces + 2 V pieces): the vmcnt(4) below
+constexpr float kDeferLog2 = 8.0f;   // deferred-rescale threshold in the exp2 domain
+
+struct PrefillParams {
+    const bf16_t *q;
+    int64_t q_ts, q_hs;
+    bf16_t *out;
+    int64_t o_ts, o_hs;
+    int32_t S;
+    int32_t group;
+    int32_t n_qtiles;
+    int32_t nblk_full;     // cls[0] q heads * n_qtiles
+    DuoClassDev cls[2];
+    float scale_log2e;
+    uint32_t flags;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    hw_bf16x2 r = __builtin_convertvector(v, hw_bf16x2);  // v_cvt_pk_bf16_f32 (RNE)
+    return *reinterpret_cast<uint32_t *>(&r);
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+struct TileSrc {
+    const bf16_t *k;
+    const bf16_t *v;
+    int64_t ts;
+    int32_t row0;
+    int32_t cnt;   // valid rows in the tile (1..64)
+};
+
+__device__ __forceinline__ TileSrc tile_src(const DuoClassDev &C, int kvh, int t, int nA, int S) {
+    TileSrc s;
+    if (t < nA) {
+        s.k = C.a.k + (int64_t)kvh * C.a.head_stride;
+        s.v = C.a.v + (int64_t)kvh * C.a.head_stride;
+        s.ts = C.a.token_stride;
+        s.row0 = t * KVBLK;
+        s.cnt = min(KVBLK, C.a.len - s.row0);
+    } else {
+        s.k = C.b.k + (int64_t)kvh * C.b.head_stride;
+        s.v = C.b.v + (int64_t)kvh * C.b.head_stride;
+        s.ts = C.b.token_stride;
+        s.row0 = (t - nA) * KVBLK;
+        s.cnt = min(KVBLK, S - s.row0);
+    }
+    return s;
+}
+
+__device__ __forceinline__ int k_lds_off(int row, int ch) { return row * 256 + ((ch ^ (row & 15)) << 4); }
+
+// LDS-DMA staging: HBM/L2 -> LDS without the VGPR round trip and without ds_write.  The LDS
+// destination of a wave-instruction is wave-uniform base + lane*16 (one contiguous KiB), so the K
+// swizzle and the V block layout are applied on the per-lane SOURCE address:
+//   K piece w = rows 4w..4w+3, LDS chunk p of row r holds source chunk p ^ (r & 15);
+//   V piece w = key quad w = 8 blocks [4 keys][16 dims]  (byte (key,d): ((key/4)*8 + d/16)*128
+//               + (key%4)*32 + (d%16)*2).
+// 512 threads: 16 pieces of K and 16 of V per tile, 2 of each per wave (DMA_PER_TILE = 4).
+//
+// Issued through inline asm: hipcc orders two LDS-DMA writes whose destinations it cannot tell apart
+// (runtime ring slot) with an s_waitcnt vmcnt(0) in front of the second one, and drains the DMA
+// before LDS reads it cannot disambiguate — either would collapse the ring to depth one.  asm VMEM
+// operations are invisible to its waitcnt pass (they can only make its own waits more conservative),
+// so the kernel counts them itself: DMA_PER_TILE per wave per tile, waited with s_waitcnt vmcnt(N).
+// M0 (the LDS destination base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const bf16_t *gsrc, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst_uniform)
+        : "memory");
+}
+// same, address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: the
+// per-tile address arithmetic is scalar, the lane offsets are loop invariants -> no VALU per tile
+__device__ __forceinline__ void glds16_s(const bf16_t *sbase_uniform, uint32_t voff_bytes, uint32_t lds_dst_uniform) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff_bytes), "s"(sbase_uniform), "s"(lds_dst_uniform)
+        : "memory");
+}
+
+// per-lane source byte offsets of piece j=0 inside a tile of a segment with token stride ts
+struct DmaLane {
+    uint32_t kofs, vofs;
+};
+__device__ __forceinline__ DmaLane dma_lane(int tid, int64_t ts) {
+    const int lane = tid & 63;
+    const int w0 = tid >> 6;
+    const int krow = 4 * w0 + (lane >> 4);
+    const int kch = (lane & 15) ^ (krow & 15);
+    const int vrow = 4 * w0 + ((lane & 7) >> 1);
+    const int vch = ((lane >> 3) << 1) + (lane & 1);
+    DmaLane d;
+    d.kofs = (uint32_t)(krow * ts + kch * 8) * 2u;
+    d.vofs = (uint32_t)(vrow * ts + vch * 8) * 2u;
+    return d;
+}
+
+// general form (tail tiles: rows past the segment end are clamped to its last row).
+// NW = waves per workgroup: wave w stages pieces w, w+NW, ... of the 16 K and 16 V pieces.
+template <int NW>
+__device__ __forceinline__ void stage_dma_tail(const TileSrc &s, uint32_t stage_lds, int tid) {
+    const int lane = tid & 63;
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds);
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+        const int piece = w0 + NW * j;                   // 0..15, wave-uniform
+        const int krow = 4 * piece + (lane >> 4);
+        const int kch = (lane & 15) ^ (krow & 15);
+        const int rk = s.row0 + min(krow, s.cnt - 1);
+        glds16(s.k + (int64_t)rk * s.ts + kch * 8, base + piece * 1024);
+        const int vrow = 4 * piece + ((lane & 7) >> 1);
+        const int vch = ((lane >> 3) << 1) + (lane & 1);
+        const int rv = s.row0 + min(vrow, s.cnt - 1);
+        glds16(s.v + (int64_t)rv * s.ts + vch * 8, base + K_TILE_BYTES + piece * 1024);
+    }
+}
+
+// full 64-row tile: scalar tile base + loop-invariant lane offsets (4*NW rows between a wave's pieces;
+// (krow + 4*NW*j) & 15 == krow & 15 for NW in {4, 8}, so the swizzled lane offset is the same)
+template <int NW>
+__device__ __forceinline__ void stage_dma_full(const TileSrc &s, const DmaLane &L, uint32_t stage_lds, int tid) {
+    const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t base = __builtin_amdgcn_readfirstlane(stage_lds) + w0 * 1024;
+    const bf16_t *kb = s.k + (int64_t)s.row0 * s.ts;     // wave-uniform
+    const bf16_t *vb = s.v + (int64_t)s.row0 * s.ts;
+    const int64_t step = 4 * NW * s.ts;                  // rows between consecutive pieces of a wave
+#pragma unroll
+    for (int j = 0; j < 16 / NW; ++j) {
+        glds16_s(kb + j * step, L.kofs, base + j * NW * 1024);
+        glds16_s(vb + j * step, L.vofs, base + K_TILE_BYTES + j * NW * 1024);
+    }
+}
+
+// ds_read_b64_tr_b16 through inline asm: hipcc treats the builtin form as possibly aliasing the
+// LDS-DMA in flight and drains it (s_waitcnt vmcnt(0)) before the first read of every tile, which
+// would undo the counted-vmcnt pipeline.  asm loads are invisible to the waitcnt pass, so their
+// completion is waited for by hand (lgkmcnt) before the MFMAs that consume them.
+#define DUO_TR_READ(dst, addr, off) \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+// the 8 transpose reads (4 output dim blocks x 2 key quads) of PV k-step `step` (= 2*bb + s)
+#define DUO_TR_STEP(buf, vaddr, ibase, step)                                          \
+    do {                                                                              \
+        _Pragma("unroll") for (int db_ = 0; db_ < 4; ++db_) {                         \
+            DUO_TR_READ(buf[2 * db_], vaddr, (ibase) + (step) * 4096 + db_ * 256);    \
+            DUO_TR_READ(buf[2 * db_ + 1], vaddr, (ibase) + (step) * 4096 + db_ * 256 + 2048); \
+        }                                                                             \
+    } while (0)
+
+__device__ __forceinline__ bf16x8 join_frag(const u32x2 &a, const u32x2 &b) {
+    u32x4 w = {a.x, a.y, b.x, b.y};
+    return *reinterpret_cast<bf16x8 *>(&w);
+}
+
+}  // namespace
