@@ -335,8 +335,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 
 }  // namespace
 
-#include "duo_prefill_w64.h"
-
 static uint32_t g_debug_flags = 0;
 extern "C" void duo_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
 extern "C" uint32_t duo_get_debug_flags(void) { return g_debug_flags; }
@@ -382,24 +380,16 @@ extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int6
 
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
-    const bool w64 = (g_debug_flags & 16u) != 0;   // debug bit 4: the 4-wave x 64-row kernel
     // (hipFuncSetAttribute is cheap but not free: once per kernel instantiation)
-    static bool attr_done[4] = {false, false, false, false};
-    const void *fn = w64 ? (tr ? (const void *)duo_prefill_w64_kernel<true> : (const void *)duo_prefill_w64_kernel<false>)
-                         : (tr ? (const void *)duo_prefill_kernel<true> : (const void *)duo_prefill_kernel<false>);
-    const int fi = (w64 ? 2 : 0) + (tr ? 1 : 0);
-    if (!attr_done[fi]) {
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[tr]) {
+        const void *fn = tr ? (const void *)duo_prefill_kernel<true> : (const void *)duo_prefill_kernel<false>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done[fi] = true;
+        attr_done[tr] = true;
     }
-    if (w64) {
-        if (tr) hipLaunchKernelGGL(duo_prefill_w64_kernel<true>, dim3(nblk), dim3(256), LDS_BYTES, st, P);
-        else hipLaunchKernelGGL(duo_prefill_w64_kernel<false>, dim3(nblk), dim3(256), LDS_BYTES, st, P);
-    } else {
-        if (tr) hipLaunchKernelGGL(duo_prefill_kernel<true>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
-        else hipLaunchKernelGGL(duo_prefill_kernel<false>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
-    }
+    if (tr) hipLaunchKernelGGL(duo_prefill_kernel<true>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
+    else hipLaunchKernelGGL(duo_prefill_kernel<false>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
 }
