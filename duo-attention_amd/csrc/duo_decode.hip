@@ -292,7 +292,10 @@ struct MergeParams {
     int32_t qh_begin[2], qh_end[2], splits[2];
 };
 
-// one workgroup (256 threads) per q head: 8 split lanes x 32 dim quads
+// One workgroup (256 threads) per q head: 8 split lanes x 32 dim quads.  Two passes so that the
+// accumulation has no serial max/rescale chain and its loads can all be in flight:
+//   1. M = max over the splits' m (every thread scans a strided share of the <= 1024 floats);
+//   2. each split lane sums w_s * acc_s and w_s * l_s with w_s = exp2(m_s - M), 4 splits per step.
 __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
     int qh = blk;
     int splits;
@@ -311,35 +314,53 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
     const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
     const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + dq * 4;
 
-    float M = kNegSentinel, Lsum = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int s = sl; s < splits; s += 8) {
-        const float ms = ml[s * 2], ls = ml[s * 2 + 1];
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM);
-        const float mn = fmaxf(M, ms);
-        const float s_old = fast_exp2(M - mn), s_new = fast_exp2(ms - mn);
-        Lsum = Lsum * s_old + ls * s_new;
-        o = o * s_old + a * s_new;
-        M = mn;
-    }
-    __shared__ float sm[8][32];
+    __shared__ float red[4];
     __shared__ float slm[8][32];
     __shared__ f32x4 so[8][32];
-    sm[sl][dq] = M;
+
+    float M = kNegSentinel;
+    for (int s = threadIdx.x; s < splits; s += 256) M = fmaxf(M, ml[s * 2]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+
+    float Lsum = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+    for (; s + 24 < splits; s += 32) {       // 4 splits (stride 8) per step
+        float w[4], l[4];
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int su = s + 8 * u;
+            w[u] = ml[su * 2];
+            l[u] = ml[su * 2 + 1];
+            a[u] = *reinterpret_cast<const f32x4 *>(ac + (int64_t)su * DUO_HEAD_DIM);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wu = fast_exp2(w[u] - M);
+            Lsum = fmaf(l[u], wu, Lsum);
+            o = o + a[u] * wu;
+        }
+    }
+    for (; s < splits; s += 8) {
+        const float wu = fast_exp2(ml[s * 2] - M);
+        Lsum = fmaf(ml[s * 2 + 1], wu, Lsum);
+        o = o + *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM) * wu;
+    }
     slm[sl][dq] = Lsum;
     so[sl][dq] = o;
     __syncthreads();
     if (sl == 0) {
-        float MM = sm[0][dq];
-#pragma unroll
-        for (int i = 1; i < 8; ++i) MM = fmaxf(MM, sm[i][dq]);
         float LL = 0.f;
         f32x4 oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float sc = fast_exp2(sm[i][dq] - MM);
-            LL = fmaf(slm[i][dq], sc, LL);
-            oo = oo + so[i][dq] * sc;
+            LL += slm[i][dq];
+            oo = oo + so[i][dq];
         }
         const float inv = 1.f / LL;
         u32x2 w;
