@@ -48,6 +48,16 @@ class HeadClass(Structure):
     ]
 
 
+class Int4Pool(Structure):
+    """``duo_int4_pool``"""
+
+    _fields_ = [
+        ("k_q", c_void_p), ("v_q", c_void_p), ("k_sz", c_void_p), ("v_sz", c_void_p),
+        ("token_stride_rows", c_int64), ("head_stride_rows", c_int64),
+        ("len", c_int32), ("n_kv_heads", c_int32), ("q_head_offset", c_int32), ("_pad", c_int32),
+    ]
+
+
 class DecodeLayerArgs(Structure):
     """``duo_decode_layer_args``"""
 
@@ -100,6 +110,24 @@ _SIGNATURES = {
          POINTER(HeadClass), c_float, c_int32, c_void_p],
     ),
     "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "duo_int4_quantize": (
+        ctypes.c_int,
+        [c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+         c_int32, c_void_p],
+    ),
+    "duo_int4_dequantize_f16": (
+        ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "duo_int4_stream_compress": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
+         POINTER(c_int32), c_void_p],
+    ),
+    "duo_attn_decode_int4_f16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_void_p, c_int64, c_int32, POINTER(Int4Pool), POINTER(Int4Pool), c_float, c_int32,
+         c_void_p, c_int64, c_void_p],
+    ),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -339,6 +367,92 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
         "duo_rmsnorm_bf16",
     )
     return y.view(x.shape)
+
+
+# ----------------------------------------------------------------------------- INT4 KV pools
+def _require_gpu(t: torch.Tensor, name: str, dtype):
+    if not t.is_cuda:
+        raise DuoHipError(f"{name} is on {t.device}; the INT4 KV path only runs on an MI355X — no CPU fallback.")
+    if t.dtype != dtype:
+        raise DuoHipError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _pool_row_strides(q_pool: torch.Tensor):
+    """q_pool: [T, h, 64] uint8 view (row = 64 contiguous bytes) -> (token, head) strides in rows."""
+    assert q_pool.dim() == 3 and q_pool.shape[2] == 64 and q_pool.stride(2) == 1
+    assert q_pool.stride(0) % 64 == 0 and q_pool.stride(1) % 64 == 0
+    return q_pool.stride(0) // 64, q_pool.stride(1) // 64
+
+
+def int4_quantize(src: torch.Tensor, q_pool: torch.Tensor, sz_pool: torch.Tensor, dst_row0: int):
+    """src [S, h, 128] fp16/bf16 view -> rows dst_row0.. of q_pool [T, h, 64] u8 / sz_pool [T, h, 2] f16."""
+    lib = load_library()
+    if src.shape[0] == 0 or src.shape[1] == 0:
+        return
+    if src.dtype not in (torch.float16, torch.bfloat16):
+        raise DuoHipError(f"int4_quantize: fp16 or bf16 input, got {src.dtype}")
+    _require_gpu(src, "src", src.dtype)
+    _require_gpu(q_pool, "q_pool", torch.uint8)
+    _require_gpu(sz_pool, "sz_pool", torch.float16)
+    ts, hs = _pool_row_strides(q_pool)
+    assert sz_pool.stride(0) == 2 * ts and sz_pool.stride(1) == 2 * hs and sz_pool.stride(2) == 1
+    assert src.stride(2) == 1 and dst_row0 + src.shape[0] <= q_pool.shape[0]
+    _check(lib.duo_int4_quantize(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), src.stride(1),
+                                 q_pool.data_ptr(), sz_pool.data_ptr(), ts, hs, src.shape[1], src.shape[0],
+                                 int(dst_row0), src.shape[2], _stream_ptr()), "duo_int4_quantize")
+
+
+def int4_dequantize(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, out: torch.Tensor) -> torch.Tensor:
+    """rows [0, n_tokens) of the pool -> out[: n_tokens*h*128] viewed [n_tokens, h, 128] fp16."""
+    lib = load_library()
+    h = q_pool.shape[1]
+    res = out[: n_tokens * h * HEAD_DIM].view(n_tokens, h, HEAD_DIM)
+    if n_tokens == 0 or h == 0:
+        return res
+    _require_gpu(q_pool, "q_pool", torch.uint8)
+    _require_gpu(out, "out", torch.float16)
+    ts, hs = _pool_row_strides(q_pool)
+    _check(lib.duo_int4_dequantize_f16(q_pool.data_ptr(), sz_pool.data_ptr(), ts, hs, res.data_ptr(), h,
+                                       int(n_tokens), HEAD_DIM, _stream_ptr()), "duo_int4_dequantize_f16")
+    return res
+
+
+def int4_stream_compress(kq, ksz, vq, vsz, length: int, sink: int, recent: int) -> int:
+    lib = load_library()
+    new_len = c_int32(0)
+    h = kq.shape[1]
+    ts, hs = _pool_row_strides(kq) if h else (0, 0)
+    _check(lib.duo_int4_stream_compress(kq.data_ptr() if h else None, ksz.data_ptr() if h else None,
+                                        vq.data_ptr() if h else None, vsz.data_ptr() if h else None, ts, hs, h,
+                                        int(length), int(sink), int(recent), byref(new_len), _stream_ptr()),
+           "duo_int4_stream_compress")
+    return int(new_len.value)
+
+
+def make_int4_pool(kq, ksz, vq, vsz, length: int, q_head_offset: int) -> Optional[Int4Pool]:
+    """kq/vq [T, h, 64] u8, ksz/vsz [T, h, 2] f16 views of one head class."""
+    if kq is None or kq.shape[1] == 0 or length <= 0:
+        return None
+    p = Int4Pool()
+    p.k_q, p.v_q, p.k_sz, p.v_sz = kq.data_ptr(), vq.data_ptr(), ksz.data_ptr(), vsz.data_ptr()
+    p.token_stride_rows, p.head_stride_rows = _pool_row_strides(kq)
+    assert _pool_row_strides(vq) == (p.token_stride_rows, p.head_stride_rows)
+    p.len, p.n_kv_heads, p.q_head_offset = int(length), kq.shape[1], int(q_head_offset)
+    return p
+
+
+def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[Int4Pool],
+                     stream: Optional[Int4Pool], scale: float):
+    """q, out [Hq, 128] fp16: decode attention over the packed pools, dequantisation in registers."""
+    lib = load_library()
+    _require_gpu(q, "q", torch.float16)
+    _require_gpu(out, "out", torch.float16)
+    assert q.dim() == 2 and q.stride(1) == 1 and out.shape == q.shape
+    ws = decode_workspace(q.device, q.shape[0])
+    _check(lib.duo_attn_decode_int4_f16(q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), int(group),
+                                        byref(full) if full is not None else None,
+                                        byref(stream) if stream is not None else None, float(scale), q.shape[1],
+                                        ws.data_ptr(), ws.numel() * 4, _stream_ptr()), "duo_attn_decode_int4_f16")
 
 
 def set_debug_flags(flags: int):

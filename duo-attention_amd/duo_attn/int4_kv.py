@@ -1,0 +1,184 @@
+"""INT4 KV pools for the static dual cache (reference ``demo/int4_kv.py``, BASELINE config 5).
+
+``DuoAttentionStaticINT4KVCache`` keeps the reference's constructor, counters and methods
+(:115-492): ``put`` quantises the new K/V rows and appends them to the retrieval and streaming
+pools, ``get`` dequantises whole pools into fp16 scratch (kept because callers of the reference use
+it — the decode path below does not), ``compress`` keeps sink + recent rows of the streaming pool.
+Differences that do not change the interface: pools are head-major in HBM (one contiguous stream per
+kv head) behind token-major views; the fp16 (scale, zero) pair of a row is stored adjacently; rows are
+quantised straight into the pool (no staging buffers); and ``decode_attention`` runs the attention of a
+single-token step directly on the packed pools (``duo_attn_decode_int4_f16``), which is what turns the
+reference's per-step "dequantise 100 % of the cache, write it, read it back" into one read of 136 B per
+row.  fp16, like the reference's QServe model (``demo/w8a8kv4_llama.py``).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+
+GROUP_SIZE = 128
+
+
+class QuantizedCache:
+    """reference int4_kv.py:4-43 — same attribute names; ``scale`` / ``zero_point`` are views of one
+    interleaved (scale, zero) tensor."""
+
+    def __init__(self, batch_size, max_size, num_kv_heads, head_dim, device, group_size):
+        assert group_size == head_dim == GROUP_SIZE, "one quantisation group per row (reference :140)"
+        self.batch_size, self.max_size = batch_size, max_size
+        self.num_kv_heads, self.head_dim, self.device, self.group_size = num_kv_heads, head_dim, device, group_size
+        self.num_groups = 1
+        q = torch.zeros(batch_size, num_kv_heads, max_size, head_dim // 2, device=device, dtype=torch.uint8)
+        sz = torch.zeros(batch_size, num_kv_heads, max_size, 2, device=device, dtype=torch.float16)
+        self.quantized_data = q.permute(0, 2, 1, 3)      # logical [B, T, h, 64]
+        self.scale_zero = sz.permute(0, 2, 1, 3)         # logical [B, T, h, 2]
+        self.scale = self.scale_zero[..., 0:1]
+        self.zero_point = self.scale_zero[..., 1:2]
+
+
+class DuoAttentionStaticINT4KVCache:
+    def __init__(self, model, full_attention_heads, batch_size, max_size, sink_size, recent_size,
+                 prefilling_chunk_size):
+        self.batch_size, self.max_size = batch_size, max_size
+        self.sink_size, self.recent_size = sink_size, recent_size
+        self.prefilling_chunk_size = prefilling_chunk_size
+        self.device = next(model.parameters()).device
+        self.dtype = next(model.parameters()).dtype
+        cfg = model.config
+        self.num_layers = cfg.num_hidden_layers
+        self.num_heads = cfg.num_attention_heads
+        self.num_kv_heads = cfg.num_key_value_heads
+        self.num_kv_groups = self.num_heads // self.num_kv_heads
+        self.head_dim = cfg.hidden_size // self.num_heads
+        self.group_size = GROUP_SIZE
+        self.num_full_kv_head_list, self.num_streaming_kv_head_list = [], []
+        self.streaming_key_caches, self.streaming_value_caches = [], []
+        self.full_key_caches, self.full_value_caches = [], []
+        max_nf = max_ns = 0
+        cap_s = sink_size + recent_size + prefilling_chunk_size
+        for heads in full_attention_heads:
+            nf = int((torch.as_tensor(heads) > 0.5).sum().item())
+            ns = self.num_kv_heads - nf
+            max_nf, max_ns = max(max_nf, nf), max(max_ns, ns)
+            self.num_full_kv_head_list.append(nf)
+            self.num_streaming_kv_head_list.append(ns)
+            mk = lambda rows, h: QuantizedCache(batch_size, rows, h, self.head_dim, self.device, GROUP_SIZE)
+            self.streaming_key_caches.append(mk(cap_s, ns))
+            self.streaming_value_caches.append(mk(cap_s, ns))
+            self.full_key_caches.append(mk(max_size, nf))
+            self.full_value_caches.append(mk(max_size, nf))
+        self.kv_seq_len_list = [0] * self.num_layers
+        self.streaming_kv_seq_len_list = [0] * self.num_layers
+        # fp16 scratch of get() — allocated lazily: the fused decode path never needs it
+        self._scratch = {}
+        self._max_nf, self._max_ns, self._cap_s = max_nf, max_ns, cap_s
+
+    @property
+    def streaming_kv_seq_len(self):
+        return self.streaming_kv_seq_len_list[-1]
+
+    @property
+    def kv_seq_len(self):
+        return self.kv_seq_len_list[-1]
+
+    def _buf(self, name, numel):
+        b = self._scratch.get(name)
+        if b is None or b.numel() < numel:
+            b = torch.empty(numel, device=self.device, dtype=torch.float16)
+            self._scratch[name] = b
+        return b
+
+    # ---------------------------------------------------------------- put (reference :261-371)
+    def put(self, layer_idx, key_states, value_states, dequantize=True):
+        nf = self.num_full_kv_head_list[layer_idx]
+        incoming = key_states.shape[1]
+        cur, cur_s = self.kv_seq_len_list[layer_idx], self.streaming_kv_seq_len_list[layer_idx]
+        if incoming + cur > self.max_size:
+            raise ValueError(
+                f"Trying to put {incoming} KVs into a cache with max size {self.max_size}, current size: {cur}."
+            )
+        # (a layer without streaming heads never compresses: its counter just grows, reference :444)
+        if self.num_streaming_kv_head_list[layer_idx] > 0 and incoming + cur_s > self._cap_s:
+            raise ValueError(
+                f"Trying to put {incoming} KVs into a streaming cache of {self._cap_s} rows, current size: {cur_s}."
+            )
+        for b in range(key_states.shape[0]):
+            for src, fc, sc in ((key_states, self.full_key_caches, self.streaming_key_caches),
+                                (value_states, self.full_value_caches, self.streaming_value_caches)):
+                _hip.int4_quantize(src[b, :, :nf], fc[layer_idx].quantized_data[b], fc[layer_idx].scale_zero[b], cur)
+                _hip.int4_quantize(src[b, :, nf:], sc[layer_idx].quantized_data[b], sc[layer_idx].scale_zero[b], cur_s)
+        self.kv_seq_len_list[layer_idx] += incoming
+        self.streaming_kv_seq_len_list[layer_idx] += incoming
+        return self.get(layer_idx) if dequantize else None
+
+    # ---------------------------------------------------------------- get (reference :373-436)
+    def get(self, layer_idx):
+        n, m = self.kv_seq_len_list[layer_idx], self.streaming_kv_seq_len_list[layer_idx]
+        nf, ns = self.num_full_kv_head_list[layer_idx], self.num_streaming_kv_head_list[layer_idx]
+        B = self.batch_size
+        empty = torch.empty(0, device=self.device, dtype=torch.float16)
+
+        def deq(cache, rows, heads, name):
+            if heads == 0:
+                return empty
+            out = self._buf(name, B * rows * heads * self.head_dim)
+            per = rows * heads * self.head_dim
+            for b in range(B):
+                _hip.int4_dequantize(cache.quantized_data[b], cache.scale_zero[b], rows, out[b * per:(b + 1) * per])
+            return out[: B * per].view(B, rows, heads, self.head_dim)
+
+        return (deq(self.full_key_caches[layer_idx], n, nf, "fk"), deq(self.full_value_caches[layer_idx], n, nf, "fv"),
+                deq(self.streaming_key_caches[layer_idx], m, ns, "sk"), deq(self.streaming_value_caches[layer_idx], m, ns, "sv"))
+
+    # ---------------------------------------------------------------- compress (reference :438-492)
+    def compress(self, layer_idx):
+        m = self.streaming_kv_seq_len_list[layer_idx]
+        if m <= self.recent_size + self.sink_size:
+            return
+        kc, vc = self.streaming_key_caches[layer_idx], self.streaming_value_caches[layer_idx]
+        if self.num_streaming_kv_head_list[layer_idx] > 0:
+            for b in range(self.batch_size):
+                _hip.int4_stream_compress(kc.quantized_data[b], kc.scale_zero[b], vc.quantized_data[b],
+                                          vc.scale_zero[b], m, self.sink_size, self.recent_size)
+            # (the reference only moves the counter when the layer has streaming heads, :444-492)
+            self.streaming_kv_seq_len_list[layer_idx] = self.recent_size + self.sink_size
+
+    def clear(self):
+        for i in range(self.num_layers):
+            self.kv_seq_len_list[i] = 0
+            self.streaming_kv_seq_len_list[i] = 0
+
+    def evict_last(self, num_tokens):
+        for i in range(self.num_layers):
+            self.kv_seq_len_list[i] = max(0, self.kv_seq_len_list[i] - num_tokens)
+            self.streaming_kv_seq_len_list[i] = max(0, self.streaming_kv_seq_len_list[i] - num_tokens)
+
+    @property
+    def memory_usage(self):
+        total = 0
+        for caches in (self.full_key_caches, self.full_value_caches, self.streaming_key_caches,
+                       self.streaming_value_caches):
+            for c in caches:
+                total += c.quantized_data.numel() + 2 * c.scale_zero.numel()
+        return total
+
+    # ---------------------------------------------------------------- fused decode attention
+    def decode_attention(self, layer_idx, query_states, scale=None):
+        """query_states [B, 1, Hq, 128] fp16 (after RoPE, after put()): attention of the decode branch
+        of reference demo/w8a8kv4_llama.py:240-274 over the dequantised pools, computed on the packed
+        pools.  Returns [B, 1, Hq, 128] fp16."""
+        nf, ns = self.num_full_kv_head_list[layer_idx], self.num_streaming_kv_head_list[layer_idx]
+        n, m = self.kv_seq_len_list[layer_idx], self.streaming_kv_seq_len_list[layer_idx]
+        G = self.num_kv_groups
+        out = torch.empty_like(query_states)
+        scale = self.head_dim ** -0.5 if scale is None else scale
+        fk, fv = self.full_key_caches[layer_idx], self.full_value_caches[layer_idx]
+        sk, sv = self.streaming_key_caches[layer_idx], self.streaming_value_caches[layer_idx]
+        for b in range(query_states.shape[0]):
+            full = _hip.make_int4_pool(fk.quantized_data[b], fk.scale_zero[b], fv.quantized_data[b],
+                                       fv.scale_zero[b], n, 0) if nf else None
+            stream = _hip.make_int4_pool(sk.quantized_data[b], sk.scale_zero[b], sv.quantized_data[b],
+                                         sv.scale_zero[b], m, nf * G) if ns else None
+            _hip.attn_decode_int4(query_states[b, 0], out[b, 0], G, full, stream, scale)
+        return out

@@ -26,6 +26,8 @@
  *                             chunks, one call per head class)
  *   duo_decode_layer_bf16     llama.py:332-425 for q_len == 1 (whole decode step of a layer)
  *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
+ *   duo_int4_quantize / duo_int4_dequantize_f16 / duo_int4_stream_compress /
+ *   duo_attn_decode_int4_f16  demo/quantize_int4.cu:9-178, demo/int4_kv.py:261-492
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -184,6 +186,52 @@ int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride,
                           int32_t n_tokens, int32_t group,
                           const duo_head_class *full, const duo_head_class *stream_cls,
                           float scale, int32_t head_dim, void *stream);
+
+/* ---- INT4 KV pools (BASELINE config 5): the reference's only native code,
+ * demo/quantize_int4.cu, and the attention over its pools ---------------------
+ * Row = one (token, kv head): 128 values -> 64 packed bytes (even element in the
+ * HIGH nibble) + fp16 scale + fp16 zero (group_size = head_dim = 128, demo/int4_kv.py:140).
+ * scale = (max-min)/15 + 1e-8 (fp32), zero = min, q = clamp(roundf((x-zero)/scale),0,15)
+ * (quantize_int4.cu:104-143); dequantised value = hadd(hmul(half(q), scale), zero) in fp16
+ * (:27-40).  Pools: packed bytes at q + row*64, (scale, zero) fp16 pair at sz + row*2 with
+ * row = t*token_stride_rows + h*head_stride_rows.                                        */
+typedef struct duo_int4_pool {
+    const void *k_q, *v_q;        /* packed nibbles                                        */
+    const void *k_sz, *v_sz;      /* fp16 (scale, zero) pairs                              */
+    int64_t token_stride_rows;
+    int64_t head_stride_rows;
+    int32_t len;                  /* rows per head to attend to                            */
+    int32_t n_kv_heads;           /* 0 => class absent                                     */
+    int32_t q_head_offset;
+    int32_t _pad;
+} duo_int4_pool;
+
+/* quantise n_tokens rows of n_heads heads of src ([T, h, 128] fp16 or bf16, element strides)
+ * straight into the pool at row dst_row0 (replaces quantize_int4.cu:73-178 + the copy_ chains of
+ * demo/int4_kv.py:296-365)                                                                 */
+int duo_int4_quantize(const void *src, int32_t src_is_bf16, int64_t src_token_stride,
+                      int64_t src_head_stride, void *q_pool, void *sz_pool,
+                      int64_t pool_token_stride_rows, int64_t pool_head_stride_rows,
+                      int32_t n_heads, int32_t n_tokens, int32_t dst_row0, int32_t head_dim,
+                      void *stream);
+/* pool rows [0, n_tokens) x n_heads -> out [n_tokens, n_heads, 128] fp16 contiguous
+ * (quantize_int4.cu:9-71; kept for DuoAttentionStaticINT4KVCache.get())                    */
+int duo_int4_dequantize_f16(const void *q_pool, const void *sz_pool, int64_t pool_token_stride_rows,
+                            int64_t pool_head_stride_rows, void *out, int32_t n_heads,
+                            int32_t n_tokens, int32_t head_dim, void *stream);
+/* streaming pool: keep the first `sink` and the last `recent` of `len` rows, in place
+ * (DuoAttentionStaticINT4KVCache.compress, demo/int4_kv.py:438-492)                        */
+int duo_int4_stream_compress(void *k_q, void *k_sz, void *v_q, void *v_sz,
+                             int64_t pool_token_stride_rows, int64_t pool_head_stride_rows,
+                             int32_t n_heads, int32_t len, int32_t sink, int32_t recent,
+                             int32_t *new_len, void *stream);
+/* decode attention (one fp16 query token) straight over the packed pools: dequantisation in
+ * registers instead of the reference's dequantise-everything-to-scratch + flash_attn_func
+ * (demo/int4_kv.py:373-436, demo/w8a8kv4_llama.py:240-274).  q/out [n_q_heads, 128] fp16.  */
+int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
+                             int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
+                             float scale, int32_t head_dim, void *workspace, int64_t workspace_bytes,
+                             void *stream);
 
 /* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
 int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,

@@ -1,0 +1,218 @@
+"""INT4 KV pools: oracle self-checks on CPU; on the GPU the HIP kernels are bit-exact against the
+oracle (quantise / dequantise / compaction) and the fused decode attention matches attention over the
+oracle's dequantised pools."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ShapeModel, heads_from_counts
+from oracle.int4_oracle import dequantize_int4_ref, quantize_int4_ref, roundf_ref
+
+DEV = "cuda:0"
+
+
+# ----------------------------------------------------------------------------- CPU: the oracle itself
+def test_roundf_is_half_away_from_zero():
+    x = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 0.49999997, 14.5, 15.4999], dtype=np.float32)
+    assert roundf_ref(x).tolist() == [1.0, 2.0, 3.0, -1.0, -2.0, 0.0, 15.0, 15.0]
+
+
+def test_oracle_layout_and_error_bound():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((7, 3, 128)).astype(np.float16)
+    p, s, z = quantize_int4_ref(x)
+    assert p.shape == (7, 3, 64) and p.dtype == np.uint8 and s.dtype == np.float16
+    # zero point = row min, codes span 0..15, even element in the high nibble
+    assert np.array_equal(z, x.min(-1))
+    i = x[0, 0].astype(np.float32).argmax()
+    code = (p[0, 0, i // 2] >> 4) if i % 2 == 0 else (p[0, 0, i // 2] & 15)
+    assert code == 15
+    d = dequantize_int4_ref(p, s, z).astype(np.float32)
+    step = (x.astype(np.float32).max(-1) - x.astype(np.float32).min(-1)) / 15
+    assert (np.abs(d - x.astype(np.float32)) <= step[..., None] * 0.5 + 4e-3).all()
+    # constant row: scale = 1e-8 -> fp16 0, every code 0, dequantises to the constant
+    c = np.full((1, 1, 128), 1.5, dtype=np.float16)
+    p, s, z = quantize_int4_ref(c)
+    assert (p == 0).all() and s[0, 0] == 0 and (dequantize_int4_ref(p, s, z) == 1.5).all()
+
+
+# ----------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+def _pools(T, h, head_major=True):
+    if head_major:
+        q = torch.zeros(h, T, 64, dtype=torch.uint8, device=DEV).permute(1, 0, 2)
+        sz = torch.zeros(h, T, 2, dtype=torch.float16, device=DEV).permute(1, 0, 2)
+    else:
+        q = torch.zeros(T, h, 64, dtype=torch.uint8, device=DEV)
+        sz = torch.zeros(T, h, 2, dtype=torch.float16, device=DEV)
+    return q, sz
+
+
+@gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("head_major", [True, False])
+@pytest.mark.parametrize("S,h,row0", [(1, 1, 0), (37, 3, 5), (300, 8, 17)])
+def test_quantize_bit_exact(dtype, head_major, S, h, row0):
+    from duo_attn import _hip
+
+    g = torch.Generator().manual_seed(S)
+    x = (torch.randn(S, h + 2, 128, generator=g) * 2).to(dtype)
+    x[0, 1] = 0.75                                   # constant row
+    if S > 3:
+        x[3, 1, :64] = 10.0                          # two-level row: every code is 0 or 15
+        x[3, 1, 64:] = -3.0
+    q, sz = _pools(row0 + S + 2, h, head_major)
+    _hip.int4_quantize(x.to(DEV)[:, 1:1 + h], q, sz, row0)
+    xf = x[:, 1:1 + h].float().numpy()
+    p, s, z = quantize_int4_ref(xf)
+    assert np.array_equal(q.cpu().numpy()[row0:row0 + S], p)
+    assert np.array_equal(sz.cpu()[row0:row0 + S, :, 0].numpy(), s)
+    assert np.array_equal(sz.cpu()[row0:row0 + S, :, 1].numpy(), z)
+    assert (q.cpu().numpy()[:row0] == 0).all() and (q.cpu().numpy()[row0 + S:] == 0).all()
+
+
+@gpu
+@pytest.mark.parametrize("T,h", [(1, 1), (50, 3), (1000, 4)])
+def test_dequantize_bit_exact(T, h):
+    from duo_attn import _hip
+
+    rng = np.random.default_rng(T)
+    p = rng.integers(0, 256, (T, h, 64), dtype=np.uint8)
+    s = (rng.random((T, h)) * 0.5).astype(np.float16)
+    z = rng.standard_normal((T, h)).astype(np.float16)
+    q, sz = _pools(T, h)
+    q.copy_(torch.from_numpy(p))
+    sz[..., 0].copy_(torch.from_numpy(s))
+    sz[..., 1].copy_(torch.from_numpy(z))
+    out = torch.empty(T * h * 128, dtype=torch.float16, device=DEV)
+    got = _hip.int4_dequantize(q, sz, T, out).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), dequantize_int4_ref(p, s, z).view(np.uint16))
+
+
+@gpu
+@pytest.mark.parametrize("sink,recent,length", [(128, 256, 385), (128, 256, 384 + 4096), (4, 8, 13), (4, 8, 12), (16, 64, 100)])
+def test_stream_compress_exact(sink, recent, length):
+    from duo_attn import _hip
+
+    rng = np.random.default_rng(length)
+    h = 3
+    cap = max(length, sink + recent)
+    q, sz = _pools(cap, h)
+    vq, vsz = _pools(cap, h)
+    for t in (q, vq):
+        t.copy_(torch.from_numpy(rng.integers(0, 256, (cap, h, 64), dtype=np.uint8)))
+    for t in (sz, vsz):
+        t.copy_(torch.from_numpy(rng.standard_normal((cap, h, 2)).astype(np.float16)))
+    before = [t.cpu().clone() for t in (q, sz, vq, vsz)]
+    n = _hip.int4_stream_compress(q, sz, vq, vsz, length, sink, recent)
+    W = sink + recent
+    assert n == min(length, W)
+    for t, b in zip((q, sz, vq, vsz), before):
+        exp = b.clone()
+        if length > W:
+            exp[sink:W] = b[length - recent:length]
+        assert torch.equal(t.cpu()[:n], exp[:n])
+
+
+def _ref_attention(q, kd, vd, group):
+    """q [Hq,128] fp32; kd/vd [T,h,128] fp32 (dequantised) -> [Hq,128] fp32, exact softmax."""
+    Hq = q.shape[0]
+    out = torch.empty(Hq, 128)
+    for hq in range(Hq):
+        k, v = kd[:, hq // group], vd[:, hq // group]
+        s = (k @ q[hq]) / (128 ** 0.5)
+        out[hq] = torch.softmax(s, 0) @ v
+    return out
+
+
+@gpu
+@pytest.mark.parametrize("group,nf,ns,n_full,n_stream", [(4, 1, 1, 1, 1), (4, 2, 6, 300, 385), (4, 8, 0, 5000, 0),
+                                                          (4, 0, 8, 0, 384), (1, 4, 4, 777, 100), (2, 3, 1, 40000, 50)])
+def test_fused_int4_decode(group, nf, ns, n_full, n_stream):
+    from duo_attn import _hip
+
+    g = torch.Generator().manual_seed(n_full + n_stream)
+    Hq = (nf + ns) * group
+    q = torch.randn(Hq, 128, generator=g).to(torch.float16)
+    ref = torch.empty(Hq, 128)
+    pools = []
+    for n_h, T, off in ((nf, n_full, 0), (ns, n_stream, nf * group)):
+        if n_h == 0:
+            pools.append(None)
+            continue
+        k = torch.randn(T, n_h, 128, generator=g).to(torch.float16)
+        v = torch.randn(T, n_h, 128, generator=g).to(torch.float16)
+        kq, ksz = _pools(T + 3, n_h)
+        vq, vsz = _pools(T + 3, n_h)
+        _hip.int4_quantize(k.to(DEV), kq, ksz, 0)
+        _hip.int4_quantize(v.to(DEV), vq, vsz, 0)
+        pools.append(_hip.make_int4_pool(kq, ksz, vq, vsz, T, off))
+        kd = torch.from_numpy(dequantize_int4_ref(*quantize_int4_ref(k.float().numpy())).astype(np.float32))
+        vd = torch.from_numpy(dequantize_int4_ref(*quantize_int4_ref(v.float().numpy())).astype(np.float32))
+        ref[off:off + n_h * group] = _ref_attention(q.float()[off:off + n_h * group], kd, vd, group)
+        pools[-1]._keep = (kq, ksz, vq, vsz)
+    out = torch.full((Hq, 128), float("nan"), dtype=torch.float16, device=DEV)
+    _hip.attn_decode_int4(q.to(DEV), out, group, pools[0], pools[1], 128 ** -0.5)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    err = (o - ref).abs()
+    tol = 1e-3 * ref.abs() + 2.0 ** -10 * ref.abs() + 1e-3 * ref.pow(2).mean().sqrt()   # fp16 output ulp
+    assert (err <= tol).all(), f"max err {err.max():.3e}"
+
+
+@gpu
+def test_int4_cache_put_compress_decode_flow():
+    """DuoAttentionStaticINT4KVCache: chunked put + compress, then decode steps — against the reference's
+    control flow restated with the oracle (demo/int4_kv.py:261-492, demo/w8a8kv4_llama.py:219-278)."""
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+
+    counts, Hq, Hkv, sink, recent, chunk = [1, 3, 0, 4], 16, 4, 16, 48, 200
+    L = len(counts)
+    model = ShapeModel(L, Hq, Hkv, 128, device=DEV, dtype=torch.float16)
+    cache = DuoAttentionStaticINT4KVCache(model, heads_from_counts(counts, Hkv), 1, 700, sink, recent, chunk)
+    g = torch.Generator().manual_seed(7)
+    W = sink + recent
+    ref_full = [[np.zeros((0, nf, 128), np.float16)] * 2 for nf in counts]
+    ref_str = [[np.zeros((0, Hkv - nf, 128), np.float16)] * 2 for nf in counts]
+
+    def dq(x):
+        return dequantize_int4_ref(*quantize_int4_ref(x.astype(np.float32)))
+
+    for S in (200, 150, 1, 1, 1):
+        for l, nf in enumerate(counts):
+            k = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16)
+            v = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16)
+            q = torch.randn(1, S, Hq, 128, generator=g).to(torch.float16)
+            fk, fv, sk, sv = cache.put(l, k.to(DEV), v.to(DEV))
+            kn, vn = k[0].numpy(), v[0].numpy()
+            ref_full[l] = [np.concatenate([ref_full[l][0], dq(kn[:, :nf])]), np.concatenate([ref_full[l][1], dq(vn[:, :nf])])]
+            ref_str[l] = [np.concatenate([ref_str[l][0], dq(kn[:, nf:])]), np.concatenate([ref_str[l][1], dq(vn[:, nf:])])]
+            if nf:
+                assert np.array_equal(fk.cpu().numpy()[0].view(np.uint16), ref_full[l][0].view(np.uint16))
+                assert np.array_equal(fv.cpu().numpy()[0].view(np.uint16), ref_full[l][1].view(np.uint16))
+            if Hkv - nf:
+                assert np.array_equal(sk.cpu().numpy()[0].view(np.uint16), ref_str[l][0].view(np.uint16))
+            if S == 1:
+                out = cache.decode_attention(l, q.to(DEV)).float().cpu()[0, 0]
+                G = Hq // Hkv
+                ref = torch.empty(Hq, 128)
+                if nf:
+                    ref[:nf * G] = _ref_attention(q[0, 0, :nf * G].float(), torch.from_numpy(ref_full[l][0].astype(np.float32)),
+                                                  torch.from_numpy(ref_full[l][1].astype(np.float32)), G)
+                if Hkv - nf:
+                    ref[nf * G:] = _ref_attention(q[0, 0, nf * G:].float(), torch.from_numpy(ref_str[l][0].astype(np.float32)),
+                                                  torch.from_numpy(ref_str[l][1].astype(np.float32)), G)
+                err = (out - ref).abs()
+                tol = 1e-3 * ref.abs() + 2.0 ** -10 * ref.abs() + 1e-3 * ref.pow(2).mean().sqrt()
+                assert (err <= tol).all(), (S, l, float(err.max()))
+            cache.compress(l)
+            if Hkv - nf and ref_str[l][0].shape[0] > W:
+                ref_str[l] = [np.concatenate([a[:sink], a[-recent:]]) for a in ref_str[l]]
+            assert cache.kv_seq_len_list[l] == ref_full[l][0].shape[0]
+            if Hkv - nf:
+                assert cache.streaming_kv_seq_len_list[l] == ref_str[l][0].shape[0]
+            else:
+                ref_str[l] = [a[:0] for a in ref_str[l]]
+    assert cache.memory_usage == sum(2 * 68 * (nf * 700 + (Hkv - nf) * (W + chunk)) for nf in counts)
