@@ -309,15 +309,25 @@ def main():
     hp = HotPath(counts, lr, args.ctx, args.chunk, device)
     t_job, t_pre, t_dec = timed(hp, args.steps, args.warmup)
 
+    # HBM-side traffic per launch is a PMC measurement (rocprofv3 --pmc FETCH_SIZE, its own pass, x2 gfx950
+    # correction): not obtainable live here, so the committed figures of the same build/workload are
+    # attached when the workload matches (profiles/r1_pmc_traffic.json, provenance in profiles/r1_c_final.md)
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(tpath) and world == 1 and (args.ctx, args.chunk, L) == (131072, 16384, 32):
+        with open(tpath) as f:
+            traffic = json.load(f)
     roof = roof_dec = None
     if not args.no_kernel_roofline:
         pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
         roof = {"kernel": "duo_prefill_kernel", "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
-                "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK, "traffic": None,
+                "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK,
+                "traffic": traffic.get("duo_prefill_kernel", {}).get("traffic_bytes_per_launch"),
                 "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"]}
         roof_dec = {"kernel": "duo_decode_split_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
-                    "unit": "GB/s", "frac": td / HBM_PEAK, "traffic": None,
+                    "unit": "GB/s", "frac": td / HBM_PEAK,
+                    "traffic": traffic.get("duo_decode_split_kernel", {}).get("traffic_bytes_per_launch"),
                     "avg_launch_ms": dec["seconds"] / dec["launches"] * 1e3, "launches": dec["launches"],
                     "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"]}
     kv_bytes = hp.cache.memory_usage

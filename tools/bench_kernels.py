@@ -42,7 +42,7 @@ def time_it(fn, reps, warm=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["prefill", "decode"])
+    ap.add_argument("what", choices=["prefill", "decode", "decode_int4"])
     ap.add_argument("--nf", type=int, default=4)
     ap.add_argument("--past", type=int, default=65536)
     ap.add_argument("--chunk", type=int, default=16384)
@@ -73,6 +73,36 @@ def main():
         flops = 4 * D * G * (nf * (S * past + tri) + ns * (S * min(past, W) + tri))
         print(json.dumps({"case": f"prefill nf={nf} past={past} S={S}", "avg_ms": avg, "min_ms": mn,
                           "tflops_avg": flops / avg / 1e9, "tflops_best": flops / mn / 1e9}))
+    elif a.what == "decode_int4":
+        import bench
+
+        counts = bench.LLAMA3_8B_FULL_KV_HEADS
+        N = a.ctx
+        q = torch.randn(HQ, D, generator=g, device=dev).to(torch.float16)
+        out = torch.empty_like(q)
+        layers = []
+        for nf in counts:
+            ns = HKV - nf
+            mk = lambda h, T: (torch.randint(0, 256, (h, T, 64), generator=g, device=dev, dtype=torch.uint8).permute(1, 0, 2),
+                               (torch.rand(h, T, 2, generator=g, device=dev) * 0.3).to(torch.float16).permute(1, 0, 2))
+            fkq, fksz = mk(max(nf, 1), N + 1)
+            fvq, fvsz = mk(max(nf, 1), N + 1)
+            skq, sksz = mk(max(ns, 1), W + 1)
+            svq, svsz = mk(max(ns, 1), W + 1)
+            full = _hip.make_int4_pool(fkq[:, :nf], fksz[:, :nf], fvq[:, :nf], fvsz[:, :nf], N + 1, 0) if nf else None
+            stream = _hip.make_int4_pool(skq[:, :ns], sksz[:, :ns], svq[:, :ns], svsz[:, :ns], W + 1, nf * G) if ns else None
+            layers.append((full, stream, (fkq, fksz, fvq, fvsz, skq, sksz, svq, svsz)))
+
+        def step():
+            for full, stream, _ in layers:
+                _hip.attn_decode_int4(q, out, G, full, stream, scale)
+
+        avg, mn, med = time_it(step, a.reps)
+        rows = sum(nf * (N + 1) + (HKV - nf) * (W + 1) for nf in counts)
+        nbytes = rows * 2 * 68
+        print(json.dumps({"case": f"int4 decode (split+merge) x32 layers ctx={N}", "avg_ms": avg, "min_ms": mn,
+                          "GBps_avg": nbytes / avg / 1e6, "rows_per_us": rows / avg / 1e3,
+                          "bf16_equivalent_GBps": rows * 512 / avg / 1e6}))
     else:
         import bench
 
