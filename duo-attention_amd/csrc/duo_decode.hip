@@ -20,6 +20,7 @@
 //     class needs a single split).
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "duo_kv_ops.h"
 
 namespace {
@@ -41,6 +42,17 @@ struct DecodeParams {
     float *ws_ml;            // [n_q_heads][max_splits][2]
     float *ws_acc;           // [n_q_heads][max_splits][128]
     int32_t max_splits;
+    // ---- fused decode step (duo_decode_layer_bf16): q and the new k row arrive UN-rotated, the new
+    //      token is not in the pools yet.  cls[c].a = pool rows cached before this token; cls[c].b =
+    //      the new row (len 1, token stride 0).  The workgroup of a kv head's LAST split rotates the
+    //      new k row, scores it and — for retrieval heads — appends k,v to the pool at row app_row.
+    //      q and k are never written (the epilogue's pool update rotates the streaming rows itself).
+    int32_t fused;
+    int32_t app_row;
+    bf16_t *app_k, *app_v;   // full pool bases (head 0, row 0)
+    int64_t app_ts, app_hs;
+    float pos;
+    float inv_freq[64];
 };
 
 __device__ __forceinline__ void unpack8(const u32x4 &w, float (&f)[8]) {
@@ -139,7 +151,7 @@ __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4
 
 // grid.x = (kv head, split) pairs of the full class then of the streaming class
 // grid.y = group / GT
-template <int GT, bool NT, bool PREFETCH>
+template <int GT, bool NT, bool PREFETCH, bool FUSED>
 __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -157,7 +169,8 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
 
     // balanced static partition: the head's ceil(L/64) 64-token units are dealt to the splits as
     // evenly as possible, so every workgroup of the (single-round) grid streams the same bytes
-    const int L = C.a.len + C.b.len;
+    // FUSED: the scan covers the cached rows only; the new token is handled after the loop
+    const int L = FUSED ? C.a.len : C.a.len + C.b.len;
     const int units = (L + 63) >> 6;
     const int uq = units / splits, ur = units - uq * splits;
     const int u0 = split * uq + min(split, ur);
@@ -177,11 +190,37 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     src.tsb = C.b.token_stride;
     src.lenA = C.a.len;
 
+    // RoPE factors of this lane's 8 dims (FUSED): dims 8*sub+e pair with dims (8*sub+e) ^ 64, i.e.
+    // with the slice of lane sub ^ 8; both slices of a pair use frequency index (8*sub+e) & 63
+    float cs[8], sn[8];
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sincos_rev(P.pos * P.inv_freq[((sub & 7) << 3) + e], sn[e], cs[e]);
+    }
+    // x: own slice, y: partner slice -> rotated own slice (first half: x*c - y*s, second half: x*c + y*s)
+    auto rope8 = [&](const u32x4 &own, const u32x4 &partner, float (&o)[8]) {
+        float x[8], y[8];
+        unpack8(own, x);
+        unpack8(partner, y);
+        const float sgn = sub < 8 ? -1.f : 1.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // round to bf16 exactly like the standalone RoPE kernel does before the attention reads it
+            o[e] = __uint_as_float(f32_to_bf16_bits(x[e] * cs[e] + sgn * y[e] * sn[e]) << 16);
+        }
+    };
+
     float qf[GT][8];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-        const u32x4 w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)(qh0 + g) * P.q_head_stride + sub * 8);
-        unpack8(w, qf[g]);
+        const bf16_t *qrow = P.q + (int64_t)(qh0 + g) * P.q_head_stride;
+        const u32x4 w = *reinterpret_cast<const u32x4 *>(qrow + sub * 8);
+        if constexpr (FUSED) {
+            const u32x4 wp = *reinterpret_cast<const u32x4 *>(qrow + (sub ^ 8) * 8);
+            rope8(w, wp, qf[g]);
+        } else {
+            unpack8(w, qf[g]);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[g][e] *= P.scale_log2e;
     }
@@ -213,6 +252,46 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
             for (int t = w0; t < w1; t += kTokPerIter) {
                 load_rows<NT>(src, t, tg, w1, k0, v0);
                 consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
+            }
+        }
+    }
+
+    if constexpr (FUSED) {
+        // ---- the new token: last split of the kv head, wave 0, token group 0 (one 16-lane DPP row) ----
+        if (split == splits - 1 && wave == 0 && tg == 0) {
+            const bf16_t *krow = C.b.k + (int64_t)kvh * C.b.head_stride;
+            const bf16_t *vrow = C.b.v + (int64_t)kvh * C.b.head_stride;
+            const u32x4 kw = *reinterpret_cast<const u32x4 *>(krow + sub * 8);
+            const u32x4 kp = *reinterpret_cast<const u32x4 *>(krow + (sub ^ 8) * 8);
+            const u32x4 vw = *reinterpret_cast<const u32x4 *>(vrow + sub * 8);
+            float kf[8], vf[8];
+            rope8(kw, kp, kf);
+            unpack8(vw, vf);
+            u32x4 kr;   // rotated slice, bf16
+            kr.x = (__float_as_uint(kf[0]) >> 16) | (__float_as_uint(kf[1]) & 0xffff0000u);
+            kr.y = (__float_as_uint(kf[2]) >> 16) | (__float_as_uint(kf[3]) & 0xffff0000u);
+            kr.z = (__float_as_uint(kf[4]) >> 16) | (__float_as_uint(kf[5]) & 0xffff0000u);
+            kr.w = (__float_as_uint(kf[6]) >> 16) | (__float_as_uint(kf[7]) & 0xffff0000u);
+#pragma unroll
+            for (int g = 0; g < GT; ++g) {
+                float d = qf[g][0] * kf[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e) d = fmaf(qf[g][e], kf[e], d);
+                const float sc_ = row16_allreduce_sum(d);
+                const float mn = fmaxf(m[g], sc_);
+                const float alpha = fast_exp2(m[g] - mn);
+                const float p_ = fast_exp2(sc_ - mn);
+                l[g] = fmaf(l[g], alpha, p_);
+                m[g] = mn;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p_, vf[e], acc[g][e] * alpha);
+            }
+            // retrieval heads: the rotated key and the value join the pool (row app_row is outside
+            // every scan range of this launch)
+            if (ci == 0 && blockIdx.y == 0) {
+                const int64_t po = (int64_t)P.app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
+                *reinterpret_cast<u32x4 *>(P.app_k + po) = kr;
+                *reinterpret_cast<u32x4 *>(P.app_v + po) = vw;
             }
         }
     }
@@ -379,10 +458,6 @@ __global__ __launch_bounds__(256) void duo_decode_post_kernel(const MergeParams 
     else duo_stream_compress_block(C, blockIdx.x - n_merge);
 }
 
-__global__ __launch_bounds__(64) void duo_decode_pre_kernel(const DecodePreParams P) {
-    duo_decode_pre_block(P, blockIdx.x, threadIdx.x);
-}
-
 }  // namespace
 
 extern "C" int64_t duo_attn_decode_workspace_bytes(int32_t n_q_heads, int32_t max_splits) {
@@ -488,6 +563,7 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     return 0;
 }
 
+template <bool FUSED>
 static int decode_launch_split(const DecodePlan &D, hipStream_t st) {
     if (D.nblk <= 0) return 0;
     const DecodeParams &P = D.P;
@@ -495,12 +571,12 @@ static int decode_launch_split(const DecodePlan &D, hipStream_t st) {
     const uint32_t fl = duo_get_debug_flags();
     const bool nt = !(fl & 4u);        // debug bit 2: plain (temporal) K/V loads
     const bool pf = !(fl & 8u);        // debug bit 3: no register prefetch of the next 16 tokens
-#define DUO_LAUNCH_DECODE(GT_)                                                                               \
-    do {                                                                                                     \
-        if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true>), grid, block, 0, st, P);   \
-        else if (nt) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, false>), grid, block, 0, st, P);   \
-        else if (pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, true>), grid, block, 0, st, P);   \
-        else hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, false>), grid, block, 0, st, P);          \
+#define DUO_LAUNCH_DECODE(GT_)                                                                                      \
+    do {                                                                                                            \
+        if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true, FUSED>), grid, block, 0, st, P);   \
+        else if (nt) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, false, FUSED>), grid, block, 0, st, P);   \
+        else if (pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, true, FUSED>), grid, block, 0, st, P);   \
+        else hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, false, FUSED>), grid, block, 0, st, P);          \
     } while (0)
     if (D.gt == 4) DUO_LAUNCH_DECODE(4);
     else if (D.gt == 2) DUO_LAUNCH_DECODE(2);
@@ -522,7 +598,7 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
                          workspace_bytes, D);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    rc = decode_launch_split(D, st);
+    rc = decode_launch_split<false>(D, st);
     if (rc) return rc;
     // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
     if (D.n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
@@ -533,9 +609,9 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     return 0;
 }
 
-// One decode step of one layer of the static dual-cache path in three launches
-// (prologue: RoPE + full-pool append; split-KV scan of both head classes; epilogue: merge +
-// streaming-pool update).  See include/duo_attn_hip.h.
+// One decode step of one layer of the static dual-cache path in two launches: the split-KV scan of
+// both head classes with RoPE of q / the new key row and the retrieval-pool append folded in, then
+// merge + streaming-pool update.  See include/duo_attn_hip.h.
 extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
     if (!a) return DUO_EINVAL;
@@ -554,39 +630,37 @@ extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *ne
     const int group = a->n_q_heads / nkv;
     hipStream_t st = (hipStream_t)stream;
 
-    // ---- launch 1: RoPE(q, k) in place + append of the retrieval rows ---------------------------
-    DecodePreParams R;
-    R.q = (bf16_t *)a->q; R.q_hs = a->q_head_stride; R.n_q_heads = a->n_q_heads;
-    R.k = (bf16_t *)a->k; R.v = (const bf16_t *)a->v; R.kv_hs = a->kv_head_stride; R.n_kv_heads = nkv;
-    R.n_full = nf;
-    R.kp = (bf16_t *)a->full_k; R.vp = (bf16_t *)a->full_v;
-    R.p_ts = a->full_token_stride; R.p_hs = a->full_head_stride;
-    R.dst_row = a->full_len;
-    R.pos = (float)a->pos;
-    for (int i = 0; i < 64; ++i)
-        R.inv_freq[i] = (float)(pow((double)a->rope_theta, -2.0 * i / 128.0) / (double)a->rope_scale);
-    hipLaunchKernelGGL(duo_decode_pre_kernel, dim3(a->n_q_heads + nkv), dim3(64), 0, st, R);
-    DUO_HIP_CHECK_LAUNCH();
-
-    // ---- launch 2: split-KV scan ---------------------------------------------------------------
+    // ---- launch 1: split-KV scan (+ RoPE, + retrieval append) -----------------------------------
+    const bf16_t *kn = (const bf16_t *)a->k, *vn = (const bf16_t *)a->v;
     duo_head_class fc{}, sc{};
     fc.n_kv_heads = nf;
     fc.q_head_offset = 0;
-    fc.segA = duo_kv_seg{a->full_k, a->full_v, a->full_token_stride, a->full_head_stride, a->full_len + 1, 0};
-    fc.segB = duo_kv_seg{nullptr, nullptr, 0, 0, 0, 0};
+    fc.segA = duo_kv_seg{a->full_k, a->full_v, a->full_token_stride, a->full_head_stride, a->full_len, 0};
+    fc.segB = duo_kv_seg{kn, vn, 0, a->kv_head_stride, 1, 0};
     sc.n_kv_heads = ns;
     sc.q_head_offset = nf * group;
     sc.segA = duo_kv_seg{a->str_k, a->str_v, a->str_token_stride, a->str_head_stride, a->str_len, 0};
-    sc.segB = duo_kv_seg{(const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
-                         (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride, 1, 0};
+    sc.segB = duo_kv_seg{kn + (int64_t)nf * a->kv_head_stride, vn + (int64_t)nf * a->kv_head_stride, 0,
+                         a->kv_head_stride, 1, 0};
     DecodePlan D;
     int rc = decode_plan(a->q, a->q_head_stride, a->out, a->out_head_stride, group, nf ? &fc : nullptr,
                          ns ? &sc : nullptr, a->scale, workspace, workspace_bytes, D);
     if (rc) return rc;
-    rc = decode_launch_split(D, st);
+    float inv_freq[64];
+    for (int i = 0; i < 64; ++i)
+        inv_freq[i] = (float)(pow((double)a->rope_theta, -2.0 * i / 128.0) / (double)a->rope_scale);
+    D.P.fused = 1;
+    D.P.app_row = a->full_len;
+    D.P.app_k = (bf16_t *)a->full_k;
+    D.P.app_v = (bf16_t *)a->full_v;
+    D.P.app_ts = a->full_token_stride;
+    D.P.app_hs = a->full_head_stride;
+    D.P.pos = (float)a->pos;
+    memcpy(D.P.inv_freq, inv_freq, sizeof(inv_freq));
+    rc = decode_launch_split<true>(D, st);
     if (rc) return rc;
 
-    // ---- launch 3: merge + streaming-pool update -------------------------------------------------
+    // ---- launch 2: merge + streaming-pool update -------------------------------------------------
     CompressParams C{};
     int n_compress = 0;
     const int T = a->str_len + 1;
@@ -597,7 +671,8 @@ extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *ne
         C = CompressParams{(bf16_t *)a->str_k, (bf16_t *)a->str_v, a->str_token_stride, a->str_head_stride,
                            (const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
                            (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride,
-                           ns, a->str_len, 1, a->sink, a->recent};
+                           ns, a->str_len, 1, a->sink, a->recent, 1, (float)a->pos, {}};
+        memcpy(C.inv_freq, inv_freq, sizeof(inv_freq));
         n_compress = 2 * ns;
     }
     if (D.n_merge + n_compress > 0) {

@@ -33,54 +33,6 @@ __device__ __forceinline__ void sincos_rev(float angle, float &s, float &c) {
 }
 
 // ---------------------------------------------------------------------------
-// Decode-step prologue, one launch: RoPE of the single new token's q and k heads
-// in place, and the append of the retrieval heads' new K (rotated) and V rows to
-// the full pool at row `dst_row`.  One wave per head; lane i owns the rotation
-// pair (i, i+64).  Replaces duo_rope_kernel + duo_kv_append_kernel for S == 1.
-// ---------------------------------------------------------------------------
-struct DecodePreParams {
-    bf16_t *q;
-    int64_t q_hs;
-    int32_t n_q_heads;
-    bf16_t *k;
-    const bf16_t *v;
-    int64_t kv_hs;
-    int32_t n_kv_heads;
-    int32_t n_full;          // kv heads [0, n_full) are appended to the pool
-    bf16_t *kp, *vp;         // pool bases (row 0, head 0)
-    int64_t p_ts, p_hs;
-    int32_t dst_row;
-    float pos;
-    float inv_freq[64];
-};
-
-__device__ __forceinline__ void duo_decode_pre_block(const DecodePreParams &P, int h, int i) {
-    float sn, cs;
-    sincos_rev(P.pos * P.inv_freq[i], sn, cs);
-    if (h < P.n_q_heads) {
-        bf16_t *row = P.q + (int64_t)h * P.q_hs;
-        const float lo = __uint_as_float((uint32_t)row[i] << 16), hi = __uint_as_float((uint32_t)row[i + 64] << 16);
-        row[i] = (bf16_t)f32_to_bf16_bits(lo * cs - hi * sn);
-        row[i + 64] = (bf16_t)f32_to_bf16_bits(hi * cs + lo * sn);
-    } else {
-        const int kh = h - P.n_q_heads;
-        bf16_t *row = P.k + (int64_t)kh * P.kv_hs;
-        const float lo = __uint_as_float((uint32_t)row[i] << 16), hi = __uint_as_float((uint32_t)row[i + 64] << 16);
-        const bf16_t olo = (bf16_t)f32_to_bf16_bits(lo * cs - hi * sn);
-        const bf16_t ohi = (bf16_t)f32_to_bf16_bits(hi * cs + lo * sn);
-        row[i] = olo;
-        row[i + 64] = ohi;
-        if (kh < P.n_full) {
-            const int64_t po = (int64_t)P.dst_row * P.p_ts + (int64_t)kh * P.p_hs;
-            P.kp[po + i] = olo;
-            P.kp[po + i + 64] = ohi;
-            const uint32_t vv = reinterpret_cast<const uint32_t *>(P.v + (int64_t)kh * P.kv_hs)[i];
-            reinterpret_cast<uint32_t *>(P.vp + po)[i] = vv;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // Streaming pool update (compress_and_replace_streaming_kv,
 // static_kv_cache.py:127-167, input = torch.cat([pool[:cur], new]) of
 // llama.py:385-390).  X = pool[:cur] ++ new[:n_new], T = cur + n_new.
@@ -97,6 +49,11 @@ struct CompressParams {
     const bf16_t *kn, *vn;
     int64_t n_ts, n_hs;
     int32_t n_heads, cur, n_new, sink, recent;
+    // rope != 0 (fused decode step, n_new == 1): the new K row arrives un-rotated and is rotated
+    // at position `pos` on its way into the pool (V rows are copied as they are)
+    int32_t rope;
+    float pos;
+    float inv_freq[64];
 };
 
 constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
@@ -129,6 +86,20 @@ __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &
             if (act[j]) {
                 const bf16_t *src = x < P.cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - P.cur) * P.n_ts;
                 buf[j] = *reinterpret_cast<const u32x4 *>(src + ch * 8);
+                if (P.rope && !is_v && x >= P.cur) {
+                    // chunk ch holds dims 8ch..8ch+7; its rotation partner is chunk ch ^ 8
+                    float xs[8], ys[8];
+                    unpack8f(buf[j], xs);
+                    unpack8f(*reinterpret_cast<const u32x4 *>(src + (ch ^ 8) * 8), ys);
+                    const float sgn = ch < 8 ? -1.f : 1.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float sn, cs;
+                        sincos_rev(P.pos * P.inv_freq[((ch & 7) << 3) + e], sn, cs);
+                        xs[e] = xs[e] * cs + sgn * ys[e] * sn;
+                    }
+                    buf[j] = pack8f(xs);
+                }
             }
         }
         __syncthreads();   // all loads of this batch complete before any store of it

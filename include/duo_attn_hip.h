@@ -140,21 +140,25 @@ int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
 
 /* ---- one decode step of one layer of the static dual-cache path, fused ------
  * Everything reference llama.py:332-425 does for q_len == 1 after a prefill
- * (RoPE in place, put_full_kv, the two flash_attn_func calls, the torch.cat and
- * compress_and_replace_streaming_kv) in THREE launches:
- *   1. RoPE of the new token's q/k heads + append of the retrieval K,V rows to
- *      the full pool at row `full_len`;
- *   2. the split-KV scan of both head classes (as duo_attn_decode_bf16);
- *   3. merge of the partials + the streaming pool's sink+recent update.
+ * (RoPE, put_full_kv, the two flash_attn_func calls, the torch.cat and
+ * compress_and_replace_streaming_kv) in TWO launches:
+ *   1. the split-KV scan of both head classes (as duo_attn_decode_bf16) over the
+ *      rows cached so far; q is rotated as it is loaded, and the workgroup that
+ *      owns a kv head's last split rotates the new key row, scores it and, for a
+ *      retrieval head, appends the rotated K and the V row to the full pool at
+ *      row `full_len`;
+ *   2. merge of the partials + the streaming pool's sink+recent update (the new
+ *      streaming key row is rotated on its way into the pool).
+ * q, k, v are inputs only: un-rotated projections of the new token.
  * kv heads [0, n_full) are retrieval heads, the rest streaming heads; q heads
  * follow in the same order (n_q_heads / n_kv_heads per kv head).
  * *new_stream_len receives the streaming pool length after the step.          */
 typedef struct duo_decode_layer_args {
-    void *q;                 /* [n_q_heads, 128], rotated in place                */
+    void *q;                 /* [n_q_heads, 128] un-rotated; read only            */
     int64_t q_head_stride;
     int32_t n_q_heads;
     int32_t n_kv_heads;
-    void *k;                 /* [n_kv_heads, 128] new key rows, rotated in place  */
+    void *k;                 /* [n_kv_heads, 128] new key rows, un-rotated; read only */
     const void *v;           /* [n_kv_heads, 128] new value rows                  */
     int64_t kv_head_stride;
     void *out;               /* [n_q_heads, 128]                                  */

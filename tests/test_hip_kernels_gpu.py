@@ -201,6 +201,69 @@ def test_decode(case, head_major):
     attn_close(out, ref, f"decode {case} hm={head_major}", bud)
 
 
+FUSED_CASES = [
+    # group, nf, ns, full_len, str_len, sink, recent, pos
+    (4, 4, 4, 1000, 384, 128, 256, 1000), (4, 1, 7, 5000, 384, 128, 256, 131071), (4, 8, 0, 300, 12, 4, 8, 300),
+    (4, 0, 8, 0, 383, 128, 256, 77), (8, 1, 1, 2049, 11, 4, 8, 2049), (1, 3, 5, 64, 5, 4, 8, 1_000_000),
+    (2, 2, 2, 0, 0, 4, 8, 0), (4, 2, 6, 40000, 384, 128, 256, 40000), (3, 2, 1, 515, 12, 4, 8, 515),
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES)
+def test_decode_layer_fused(case):
+    """duo_decode_layer_bf16 (two launches: scan with RoPE + retrieval append folded in, then merge +
+    streaming update) against the oracle's step-by-step restatement of llama.py:332-425 for q_len == 1."""
+    from oracle.duo_oracle import OracleBackend
+
+    group, nf, ns, full_len, str_len, sink, recent, pos = case
+    h = _hip()
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    nkv, Hq, W = nf + ns, (nf + ns) * group, sink + recent
+    theta, rscale = 3580165449.0, 1.0
+    q, k, v = _rand((Hq, D), g), _rand((nkv, D), g), _rand((nkv, D), g)
+    cap = full_len + 3
+    fk, fv, fkd, fvd = _make_pool(cap, max(nf, 1), g, True)
+    sk, sv, skd, svd = _make_pool(W, max(ns, 1), g, True)
+    fk, fv, fkd, fvd = fk[:, :nf], fv[:, :nf], fkd[:, :nf], fvd[:, :nf]
+    sk, sv, skd, svd = sk[:, :ns], sv[:, :ns], skd[:, :ns], svd[:, :ns]
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    out = torch.full((Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    n = h.decode_layer(qd, kd, vd, out, nf, fkd, fvd, full_len, skd, svd, str_len, sink, recent, pos, rscale,
+                       theta, D ** -0.5)
+    # inputs are read-only
+    assert torch.equal(qd.cpu(), q) and torch.equal(kd.cpu(), k) and torch.equal(vd.cpu(), v)
+
+    qr = rope_ref(q[None], pos, rscale, theta)[0]
+    kr = rope_ref(k[None], pos, rscale, theta)[0]
+    kw = dict(round_p=False, out_dtype=torch.float32)
+    ref = torch.empty(Hq, D, dtype=torch.float32)
+    if nf:
+        kk = torch.cat([fk[:full_len], kr[None, :nf]], 0)
+        vv = torch.cat([fv[:full_len], v[None, :nf]], 0)
+        ref[:nf * group] = flash_attn_func_ref(qr[None, None, :nf * group], kk[None], vv[None], **kw)[0, 0]
+        # the pool gained the rotated key / the value at row full_len; everything else untouched
+        _ulp_close(fkd.cpu()[full_len], kr[:nf], "appended k")
+        assert torch.equal(fvd.cpu()[full_len], v[:nf])
+        assert torch.equal(fkd.cpu()[:full_len], fk[:full_len]) and torch.equal(fkd.cpu()[full_len + 1:], fk[full_len + 1:])
+        assert torch.equal(fvd.cpu()[:full_len], fv[:full_len]) and torch.equal(fvd.cpu()[full_len + 1:], fv[full_len + 1:])
+    T = str_len + 1
+    assert n == min(T, W)
+    if ns:
+        kk = torch.cat([sk[:str_len], kr[None, nf:]], 0)
+        vv = torch.cat([sv[:str_len], v[None, nf:]], 0)
+        ref[nf * group:] = flash_attn_func_ref(qr[None, None, nf * group:], kk[None], vv[None], **kw)[0, 0]
+        ek, ev = sk.clone(), sv.clone()
+        en = OracleBackend().stream_compress(ek, ev, kr[None, nf:], v[None, nf:], str_len, sink, recent)
+        assert en == n
+        # V rows and the old K rows move bit-exactly; the one new K row is rotated on the device
+        assert torch.equal(svd.cpu()[:n], ev[:n])
+        assert torch.equal(skd.cpu()[:n - 1], ek[:n - 1])
+        _ulp_close(skd.cpu()[n - 1], ek[n - 1], "new streaming k")
+    # the device rotates q/k with its own sincos: allow the 1-ulp bf16 input differences through the
+    # attention tolerance (rms floor)
+    attn_close(out, ref, f"fused decode {case}", None)
+
+
 PREFILL_CASES = [
     # S, group, nf, ns, lenA_full, lenA_stream
     (2, 4, 1, 1, 3, 2), (31, 4, 1, 1, 64, 100), (64, 4, 2, 2, 5, 384), (100, 4, 1, 3, 1000, 384),
