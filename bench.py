@@ -126,15 +126,21 @@ def sync_all(world):
     torch.cuda.synchronize()
 
 
-def run_job(hp: HotPath, pipe, n_decode, world, device):
+def run_job(hp: HotPath, pipe, n_decode, world, device, handoff=None):
     """One whole job; returns (t_total, t_prefill, t_decode) seconds (wall, max over ranks not yet taken)."""
+    handoff = handoff or device
+    pre = hp.prefill_stage if handoff == device else (lambda i, x: hp.prefill_stage(i, x).to(handoff))
+    dec = hp.decode_stage if handoff == device else (lambda i, x: hp.decode_stage(i, x).to(handoff))
     hp.cache.clear()
     sync_all(world)
     t0 = time.perf_counter()
-    pipe.run([(1, c, HIDDEN) for _, c in hp.chunks], hp.prefill_stage, device)
+    pipe.run([(1, c, HIDDEN) for _, c in hp.chunks], pre, handoff)
     sync_all(world)
     t1 = time.perf_counter()
-    pipe.run([(1, 1, HIDDEN)] * n_decode, hp.decode_stage, device)
+    # batch-1 decode is autoregressive: token i+1 enters stage 0 only after token i left the last stage
+    # (one [1, 1] int64 hop back per token), so the layer pipeline cannot overlap decode steps
+    tok = torch.zeros(1, 1, dtype=torch.int64, device=handoff)
+    pipe.run([(1, 1, HIDDEN)] * n_decode, dec, handoff, token_feedback=lambda i, t: tok)
     sync_all(world)
     t2 = time.perf_counter()
     return t2 - t0, t1 - t0, t2 - t1
@@ -279,29 +285,43 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # DUO_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a ONE-GPU box — every rank
+    # computes on cuda:0 and the hand-off goes through gloo/host memory.  Not a measurement mode.
+    shared = os.environ.get("DUO_BENCH_DEBUG_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    handoff = torch.device("cpu") if shared else device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from duo_attn.pipeline import LayerPipeline
 
     counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
     L = len(counts)
-    pipe = LayerPipeline(L, rank=rank, world_size=world)
+    # stage boundaries: contiguous layers, split so that the most expensive stage is as cheap as possible
+    # (per-layer cost = its algorithmic prefill FLOPs — the ragged retrieval-head counts make the
+    # reference's even split lopsided: 6 vs 21 retrieval heads in the first/last 4-layer block)
+    pf = prefill_flops(counts, args.ctx, args.chunk)
+    layer_cost = [sum(row[l] for row in pf) for l in range(L)]
+    pipe = LayerPipeline(L, rank=rank, world_size=world, layer_costs=layer_cost if world > 1 else None)
     lr = (pipe.first_layer, pipe.last_layer)
     n_tok = args.ctx + args.decode_tokens
 
     def timed(hp, steps, warmup):
         for _ in range(warmup):
-            run_job(hp, pipe, args.decode_tokens, world, device)
+            run_job(hp, pipe, args.decode_tokens, world, device, handoff)
         sync_all(world)
         t0 = time.perf_counter()
-        parts = [run_job(hp, pipe, args.decode_tokens, world, device) for _ in range(steps)]
+        parts = [run_job(hp, pipe, args.decode_tokens, world, device, handoff) for _ in range(steps)]
         sync_all(world)
         t = torch.tensor([time.perf_counter() - t0, sum(p[1] for p in parts), sum(p[2] for p in parts)],
-                         device=device, dtype=torch.float64)
+                         device=handoff, dtype=torch.float64)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return (t / steps).tolist()
@@ -330,7 +350,13 @@ def main():
                     "traffic": traffic.get("duo_decode_split_kernel", {}).get("traffic_bytes_per_launch"),
                     "avg_launch_ms": dec["seconds"] / dec["launches"] * 1e3, "launches": dec["launches"],
                     "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"]}
-    kv_bytes = hp.cache.memory_usage
+    def all_ranks_sum(x):
+        t = torch.tensor([float(x)], device=handoff, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    kv_bytes = all_ranks_sum(hp.cache.memory_usage)   # every rank owns the pools of its layers
     hp.free()
 
     full = None
@@ -338,7 +364,7 @@ def main():
         hpf = HotPath([HKV] * L, lr, args.ctx, args.chunk, device)
         f_job, f_pre, f_dec = timed(hpf, 1, 0)
         full = {"job_tok_s": n_tok / f_job, "prefill_tok_s": args.ctx / f_pre,
-                "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": hpf.cache.memory_usage}
+                "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": all_ranks_sum(hpf.cache.memory_usage)}
         hpf.free()
 
     cpu = None

@@ -109,6 +109,39 @@ def even_layer_split(num_layers: int, num_stages: int):
     return bounds
 
 
+def balanced_layer_split(costs, num_stages: int):
+    """Contiguous split of the layers that minimises the most expensive stage.
+
+    With DuoAttention the per-layer cost is ragged: a layer's attention work and KV bytes grow with
+    its number of retrieval heads, so the reference's even split (``even_layer_split``) leaves the
+    pipeline waiting on whichever stage drew the retrieval-heavy layers.  ``costs[l]`` is any positive
+    per-layer cost (e.g. ``base + n_full_kv_heads[l]``).  Exact DP over cut points; every stage gets
+    at least one layer.  Returns ``[(first, last_exclusive), ...]``."""
+    n = len(costs)
+    if not 1 <= num_stages <= n:
+        raise ValueError(f"{num_stages} stages for {n} layers")
+    pre = [0.0]
+    for c in costs:
+        pre.append(pre[-1] + float(c))
+    INF = float("inf")
+    # best[s][i]: minimal bottleneck splitting the first i layers into s stages
+    best = [[INF] * (n + 1) for _ in range(num_stages + 1)]
+    cut = [[0] * (n + 1) for _ in range(num_stages + 1)]
+    best[0][0] = 0.0
+    for s in range(1, num_stages + 1):
+        for i in range(s, n - (num_stages - s) + 1):
+            for j in range(s - 1, i):
+                b = max(best[s - 1][j], pre[i] - pre[j])
+                if b < best[s][i]:
+                    best[s][i], cut[s][i] = b, j
+    bounds, i = [], n
+    for s in range(num_stages, 0, -1):
+        j = cut[s][i]
+        bounds.append((j, i))
+        i = j
+    return bounds[::-1]
+
+
 def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_map=True, even_split_layers=True):
     """Single device: ``model.to(device)``.  ``enable_pp`` with a device list is the layer pipeline:
     on MI355X that is one process per GPU with RCCL point-to-point hand-off (``duo_attn.pipeline``),

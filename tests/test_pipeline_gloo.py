@@ -54,6 +54,11 @@ def _hot_path_stage_factory(counts, Hq, Hkv, sink, recent, max_size, layer_range
     return stage
 
 
+def _sample(y):
+    """stand-in for argmax over logits: an int64 [1, 1] token derived from the last stage's output"""
+    return y.float().abs().argmax().reshape(1, 1).to(torch.int64) % 97
+
+
 def _worker(rank, world, port, counts, chunks, q):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -66,16 +71,31 @@ def _worker(rank, world, port, counts, chunks, q):
 
         backend._set_backend_for_testing(OracleBackend())
         Hq, Hkv, D, sink, recent = 4, 2, 128, 2, 4
-        pipe = LayerPipeline(len(counts))
+        # ragged costs -> the bottleneck-minimising split (what bench.py uses for N > 1)
+        pipe = LayerPipeline(len(counts), layer_costs=[0.5 + c for c in counts])
+        assert pipe.bounds[0][0] == 0 and pipe.bounds[-1][1] == len(counts)
         stage = _hot_path_stage_factory(counts, Hq, Hkv, sink, recent, sum(chunks) + 2,
                                         (pipe.first_layer, pipe.last_layer))
         g = torch.Generator().manual_seed(0)
         inputs = [torch.randn(1, S, Hq * D, generator=g).to(torch.bfloat16) for S in chunks]
+        n_pre = sum(1 for S in chunks if S > 1)
 
-        def fn(i, x):
-            return stage(i, inputs[i] if x is None else x, chunks[i])
+        # prefill chunks: streamed (chunk c+1 enters stage 0 while chunk c is downstream)
+        outs = pipe.run([(1, S, Hq * D) for S in chunks[:n_pre]],
+                        lambda i, x: stage(i, inputs[i] if x is None else x, chunks[i]), device="cpu")
+        # decode tokens: autoregressive — the "sampled token" of item i shapes item i+1's input
+        tok = {"t": 0}
 
-        outs = pipe.run([(1, S, Hq * D) for S in chunks], fn, device="cpu")
+        def feedback(i, t):
+            if pipe.is_last:
+                return _sample(t)
+            tok["t"] = int(t.item())
+
+        def dec(i, x):
+            j = n_pre + i
+            return stage(j, torch.roll(inputs[j], tok["t"], dims=-1) if x is None else x, 1)
+
+        outs += pipe.run([(1, 1, Hq * D)] * (len(chunks) - n_pre), dec, device="cpu", token_feedback=feedback)
         if pipe.is_last:
             q.put([o.float().numpy() for o in outs])
         dist.barrier()
@@ -94,7 +114,13 @@ def _single_process(counts, chunks):
         stage = _hot_path_stage_factory(counts, Hq, Hkv, sink, recent, sum(chunks) + 2, (0, len(counts)))
         g = torch.Generator().manual_seed(0)
         inputs = [torch.randn(1, S, Hq * D, generator=g).to(torch.bfloat16) for S in chunks]
-        return [stage(i, inputs[i], S).float().numpy() for i, S in enumerate(chunks)]
+        outs, t = [], 0
+        for i, S in enumerate(chunks):
+            y = stage(i, torch.roll(inputs[i], t, dims=-1) if S == 1 else inputs[i], S)
+            if S == 1:
+                t = int(_sample(y).item())
+            outs.append(y.float().numpy())
+        return outs
     finally:
         backend._set_backend_for_testing(None)
 
@@ -116,6 +142,26 @@ def test_sharded_hot_path_equals_single_process(world, counts):
     assert len(got) == len(expected)
     for a, b in zip(got, expected):
         assert (a == b).all()
+
+
+def test_balanced_layer_split():
+    from duo_attn.utils import balanced_layer_split, even_layer_split
+
+    counts = [1, 1, 2, 2, 2, 4, 2, 4, 6, 4, 5, 3, 2, 6, 5, 5, 5, 6, 3, 5, 6, 3, 3, 6, 4, 5, 3, 4, 6, 5, 8, 2]
+    costs = [0.5 + c for c in counts]
+    for P in (1, 2, 4, 8, 32):
+        b = balanced_layer_split(costs, P)
+        assert len(b) == P and b[0][0] == 0 and b[-1][1] == 32
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:])) and all(e > s for s, e in b)
+        worst = max(sum(costs[s:e]) for s, e in b)
+        even = max(sum(costs[s:e]) for s, e in even_layer_split(32, P))
+        assert worst <= even
+        # exhaustive optimum for P = 2
+        if P == 2:
+            assert worst == min(max(sum(costs[:c]), sum(costs[c:])) for c in range(1, 32))
+    assert balanced_layer_split([1, 1, 1, 1], 2) == [(0, 2), (2, 4)]
+    with pytest.raises(ValueError):
+        balanced_layer_split([1, 1], 3)
 
 
 def test_even_layer_split():
