@@ -69,6 +69,21 @@ struct RowSrc {
     int32_t lenA;
 };
 
+// A wave-uniform global address pinned to an SGPR pair (readfirstlane), typed as a GLOBAL pointer: an
+// integer-to-pointer cast alone would make it generic and the loads flat_load (vmcnt AND lgkmcnt).
+typedef __attribute__((address_space(1))) const char gchar_t;
+typedef __attribute__((address_space(1))) const u32x4 gu32x4_t;
+__device__ __forceinline__ gchar_t *uniform_gptr(const char *p) {
+    const uint64_t a = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return (gchar_t *)(((uint64_t)hi << 32) | lo);
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16g(gchar_t *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(p));
+    else return *reinterpret_cast<gu32x4_t *>(p);
+}
+
 template <bool NT>
 __device__ __forceinline__ u32x4 ld16(const bf16_t *p) {
     // K/V rows are read exactly once per token: the non-temporal policy keeps them from
@@ -93,7 +108,8 @@ __device__ __forceinline__ void load_rows(const RowSrc &src, int tok0, int tg, i
     }
 }
 
-template <int GT>
+// FULL: all 16 tokens of the group are inside the range (no masks)
+template <int GT, bool FULL = false>
 __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4 (&vbuf)[4],
                                              int tok0, int tg, int tok_end,
                                              const float (&qf)[GT][8], float (&m)[GT],
@@ -118,7 +134,7 @@ __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4
 
     bool valid[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) valid[u] = (tok0 + 4 * u + tg) < tok_end;
+    for (int u = 0; u < 4; ++u) valid[u] = FULL || (tok0 + 4 * u + tg) < tok_end;
 
     float p[4][GT];
 #pragma unroll
@@ -154,7 +170,7 @@ __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4
 template <int GT, bool NT, bool PREFETCH, bool FUSED>
 __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar loop control
     const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
     const int tg = lane >> 4;    // which of the 4 rows a wave-load covers
 
@@ -178,8 +194,8 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     const int c0 = u0 << 6;
     const int c1 = min((u0 + un) << 6, L);
     const int per_wave = (((c1 - c0 + 3) >> 2) + 15) & ~15;  // quarter of the chunk, multiple of 16
-    const int w0 = c0 + wave * per_wave;
-    const int w1 = min(w0 + per_wave, c1);
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + wave * per_wave);
+    const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
 
     RowSrc src;
     src.ka = C.a.k + kvh * C.a.head_stride + sub * 8;
@@ -234,25 +250,63 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
         for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
     }
 
-    if (w0 < w1) {
-        if constexpr (PREFETCH) {
+    // Main loop: the 16-token groups that lie wholly in segment A and inside the wave's range.  Their
+    // addresses are a uniform base (SGPR pair, advanced per group) + four per-lane 32-bit byte offsets that
+    // never change: no per-load address arithmetic, and straight-line code with a FIXED number of loads
+    // in flight at every use — with a conditional prefetch hipcc has to wait with the smaller count, which
+    // on the common path means waiting for the loads it has just issued.  The prefetch of the group after
+    // the last one re-reads the last one (never consumed).  What is left — a partial group, segment B
+    // rows — goes through the general clamped loader, one group at a time.
+    const char *kA = reinterpret_cast<const char *>(C.a.k + kvh * C.a.head_stride);
+    const char *vA = reinterpret_cast<const char *>(C.a.v + kvh * C.a.head_stride);
+    uint32_t roff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) roff[u] = (uint32_t)(((4 * u + tg) * src.tsa + sub * 8) * 2);
+    auto load_fast = [&](int t, u32x4 (&kb)[4], u32x4 (&vb)[4]) __attribute__((always_inline)) {
+        // (readfirstlane: keeps the group base in SGPRs — loop strength reduction otherwise turns it into
+        // a per-lane 64-bit pointer whose registers then collide with loads still in flight)
+        gchar_t *kt = uniform_gptr(kA + (int64_t)t * src.tsa * 2), *vt = uniform_gptr(vA + (int64_t)t * src.tsa * 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // (empty asm: the 32-bit offset is re-materialised as such in THIS basic block, so instruction
+            // selection sees sgpr base + zext(vgpr32) and emits the saddr form; hoisted out of the loop the
+            // zero-extension becomes a 64-bit VGPR pair and every load pays a v_lshl_add_u64)
+            // (in place, no copy: a temporary would be a fresh register — possibly one a load still in
+            // flight is about to write, which costs a vmcnt(0))
+            asm volatile("" : "+v"(roff[u]));
+            kb[u] = ld16g<NT>(kt + roff[u]);
+            vb[u] = ld16g<NT>(vt + roff[u]);
+        }
+    };
+
+    int t_rest = w0;
+    if constexpr (PREFETCH) {
+        const int fast_end = min(w1, C.a.len);
+        const int nfast = fast_end > w0 ? (fast_end - w0) / kTokPerIter : 0;
+        if (nfast > 0) {
+            const int t_last = w0 + (nfast - 1) * kTokPerIter;
             u32x4 k0[4], v0[4], k1[4], v1[4];
-            load_rows<NT>(src, w0, tg, w1, k0, v0);
-            for (int t = w0; t < w1; t += 2 * kTokPerIter) {
-                const bool more1 = t + kTokPerIter < w1;
-                if (more1) load_rows<NT>(src, t + kTokPerIter, tg, w1, k1, v1);
-                consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
-                if (more1) {
-                    if (t + 2 * kTokPerIter < w1) load_rows<NT>(src, t + 2 * kTokPerIter, tg, w1, k0, v0);
-                    consume_rows<GT>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
-                }
+            load_fast(w0, k0, v0);
+            // (sched_barrier: the loads stay ahead of the arithmetic on the other buffer — the scheduler
+            // would otherwise sink them next to their first use, one iteration later.)
+            for (int t = w0;; t += 2 * kTokPerIter) {
+                load_fast(min(t + kTokPerIter, t_last), k1, v1);
+                __builtin_amdgcn_sched_barrier(0);
+                consume_rows<GT, true>(k0, v0, t, tg, w1, qf, m, l, acc);
+                if (t >= t_last) break;
+                load_fast(min(t + 2 * kTokPerIter, t_last), k0, v0);
+                __builtin_amdgcn_sched_barrier(0);
+                consume_rows<GT, true>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
+                if (t + kTokPerIter >= t_last) break;
             }
-        } else {
-            u32x4 k0[4], v0[4];
-            for (int t = w0; t < w1; t += kTokPerIter) {
-                load_rows<NT>(src, t, tg, w1, k0, v0);
-                consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
-            }
+            t_rest = w0 + nfast * kTokPerIter;
+        }
+    }
+    {
+        u32x4 k0[4], v0[4];
+        for (int t = t_rest; t < w1; t += kTokPerIter) {
+            load_rows<NT>(src, t, tg, w1, k0, v0);
+            consume_rows<GT>(k0, v0, t, tg, w1, qf, m, l, acc);
         }
     }
 

@@ -19,6 +19,7 @@
 #include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "duo_common.h"
 
 namespace {
@@ -227,6 +228,7 @@ struct Int4DecodeParams {
     float scale_log2e;
     float *ws_ml, *ws_acc;
     int32_t max_splits;
+    uint32_t flags;            // debug: bit 5 = loads only (memory-side ceiling of the access pattern)
 };
 
 __device__ __forceinline__ Int4SegDev i4_select(const Int4SegDev &a, const Int4SegDev &b, bool pb) {
@@ -421,6 +423,375 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
     }
 }
 
+// ----------------------------------------------------------------------------- fused decode, MFMA form
+// The scalar-FMA kernel above is VALU-bound: at 136 B per (token, kv head) the HBM roofline asks for
+// ~38 K rows/us, and 1024 fp32 FMAs per row (4 q heads x 128 dims x {QK, PV}) alone are the whole
+// chip's VALU rate at that pace.  Here the dot products go to the matrix cores and the VALU only
+// dequantises (packed fp16, bit-exact with the reference: 17 instructions per 8 values):
+//   S^T[16 keys x 16 q] = K^[16 keys x 32 dims] . Q^T        v_mfma_f32_16x16x32_f16, 4 k-steps, 2 key halves
+//   O[16 q x 16 dims]  += P[16 q x 32 keys] . V^[32 keys x 16 dims]   8 dim blocks
+// (q columns beyond the GQA group are zero padding; the MFMA is ~8x faster than needed even so.)
+// One wave owns a tile of 32 keys.  K^ fragments come straight from the packed words: lane (r, g) =
+// (key r of the half, 16-byte quarter g of the 64-byte row) holds dims 32g..32g+31, and the order of the
+// 8 values inside each packed dword is whatever the nibble extraction yields ([1,5,0,4,3,7,2,6]) — Q is
+// loaded in the same order, the dot product does not care.  V^ needs keys along the MFMA k axis, i.e. a
+// transpose: the dequantised tile goes through a wave-private 8 KiB LDS tile (XOR-swizzled 16-B chunks)
+// and comes back with ds_read_b64_tr_b16.  The S accumulator layout (lane = q column, 4 keys per
+// 16-lane group) is exactly the A-operand layout of P if k-slot (g, e) means key 4g+e (e<4) or
+// 16+4g+e-4: no cross-lane traffic for P.
+// Softmax keeps a per-q-head reference maximum that is only raised when some score exceeds it by 2^8
+// (wave vote), so the steady state has no cross-lane reduction and no accumulator rescale.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h2_t as_h2(uint32_t x) { return *reinterpret_cast<const h2_t *>(&x); }
+__device__ __forceinline__ uint32_t as_u32(h2_t x) { return *reinterpret_cast<const uint32_t *>(&x); }
+__device__ __forceinline__ h2_t h2_splat(float v) { return h2_t{(_Float16)v, (_Float16)v}; }
+
+// Per-row dequantisation constants, both fp16 lanes equal.  The reference value is
+//     hadd(hmul(half(n), s), z)                       (quantize_int4.cu:36-39, two roundings)
+// A nibble OR-ed into the mantissa of 1024.0 reads as 1024 + n (bits 0-3) or 1024 + 16 n (bits 4-7), and
+//     fma(1024 + n,    s,      -1024 s) = round(n s)         one rounding of the exact product: == hmul
+//     fma(1024 + 16 n, s / 16, -64 s)   = round(n s)
+// PROVIDED -1024 s and s / 16 are exact in fp16: 2^-10 <= s < 64 (or s == 0).  Rows outside that range
+// (wave vote per tile) take the three-instruction form subtract-multiply-add, which is always exact.
+struct RowConst {
+    h2_t s, z, c, s16, c16;
+};
+__device__ __forceinline__ RowConst row_const(uint32_t sz, bool fast) {
+#pragma clang fp contract(off)
+    RowConst R;
+    R.s = as_h2(__builtin_amdgcn_perm(sz, sz, 0x01000100u));
+    R.z = as_h2(__builtin_amdgcn_perm(sz, sz, 0x03020302u));
+    if (fast) {
+        R.c = R.s * h2_splat(-1024.f);
+        R.s16 = R.s * h2_splat(0.0625f);
+        R.c16 = R.s * h2_splat(-64.f);
+    }
+    return R;
+}
+__device__ __forceinline__ bool row_is_fast(uint32_t sz) {
+    const uint32_t sb = sz & 0xffffu;   // scale >= 0
+    return sb == 0u || (sb >= 0x1400u && sb < 0x5400u);   // 0, or [2^-10, 64)
+}
+
+// one packed dword (8 nibbles) -> 4 x half2 of reference-exact dequantised values, element order
+// [1,5 | 0,4 | 3,7 | 2,6] of the dword's 8 dims.  m0 / m4: nibble masks 0x000f000f / 0x00f000f0 (SGPRs),
+// magic: half2(1024, 1024) (VGPR) — see the note at their definition.
+// `fast` is wave-uniform (a vote over the tile): a scalar branch around ~13 or ~17 instructions.
+__device__ __forceinline__ u32x4 dq8(uint32_t w, const RowConst &R, uint32_t m0, uint32_t m4, uint32_t magic, bool fast) {
+#pragma clang fp contract(off)
+    u32x4 o;
+    if (fast) {
+        const uint32_t w8 = w >> 8;
+        const h2_t a0 = as_h2((w & m0) | magic), a1 = as_h2((w & m4) | magic);
+        const h2_t a2 = as_h2((w8 & m0) | magic), a3 = as_h2((w8 & m4) | magic);
+        o.x = as_u32(__builtin_elementwise_fma(a0, R.s, R.c) + R.z);
+        o.y = as_u32(__builtin_elementwise_fma(a1, R.s16, R.c16) + R.z);
+        o.z = as_u32(__builtin_elementwise_fma(a2, R.s, R.c) + R.z);
+        o.w = as_u32(__builtin_elementwise_fma(a3, R.s16, R.c16) + R.z);
+    } else {
+        const h2_t bias = h2_splat(1024.f);
+        const h2_t a0 = as_h2((w & m0) | magic), a1 = as_h2(((w >> 4) & m0) | magic);
+        const h2_t a2 = as_h2(((w >> 8) & m0) | magic), a3 = as_h2(((w >> 12) & m0) | magic);
+        o.x = as_u32((a0 - bias) * R.s + R.z);
+        o.y = as_u32((a1 - bias) * R.s + R.z);
+        o.z = as_u32((a2 - bias) * R.s + R.z);
+        o.w = as_u32((a3 - bias) * R.s + R.z);
+    }
+    return o;
+}
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f16x8_t as_f16x8(const u32x4 &w) { return *reinterpret_cast<const f16x8_t *>(&w); }
+
+#define DUO_I4_TR_READ(dst, addr, off) \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+struct I4Tile {
+    u32x4 kw[2], vw[2];
+    uint32_t ks[2], vs[2];
+};
+
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+
+// MINW: waves per SIMD the register budget is cut for; RING: 32-key tiles per wave held in registers
+// (one being processed, RING-1 in flight) — the bytes in flight per CU are what hides the HBM latency.
+template <int MINW, int RING, int MODE>
+__global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const Int4DecodeParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15;    // key row inside a 16-key half / q column / dim column
+    const int g = lane >> 4;    // 16-byte quarter of the packed row / k-slot group
+
+    int b = blockIdx.x;
+    const int ci = b < P.nblk_full ? 0 : 1;
+    if (ci) b -= P.nblk_full;
+    const Int4SegDev C = i4_select(P.cls[0], P.cls[1], ci != 0);
+    const int splits = ci ? P.splits[1] : P.splits[0];
+    const int kvh = b / splits;
+    const int split = b - kvh * splits;
+    const int qh0 = C.q_head_offset + kvh * P.group;
+
+    const int L = C.len;
+    const int units = (L + 63) >> 6;
+    const int uq = units / splits, ur = units - uq * splits;
+    const int u0 = split * uq + min(split, ur);
+    const int un = uq + (split < ur ? 1 : 0);
+    const int c0 = u0 << 6;
+    const int c1 = min((u0 + un) << 6, L);
+    const int per_wave = (((c1 - c0 + 3) >> 2) + 31) & ~31;   // quarter of the chunk, whole 32-key tiles
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + wave * per_wave);
+    const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
+
+    // uniform (SGPR) row bases of this kv head + per-lane 32-bit byte offsets inside a 32-key tile
+    const uint8_t *kq = C.kq + (int64_t)kvh * C.hs * 64;
+    const uint8_t *vq = C.vq + (int64_t)kvh * C.hs * 64;
+    const uint8_t *ksz = reinterpret_cast<const uint8_t *>(C.ksz) + (int64_t)kvh * C.hs * 4;
+    const uint8_t *vsz = reinterpret_cast<const uint8_t *>(C.vsz) + (int64_t)kvh * C.hs * 4;
+    const int64_t ts = C.ts;
+    const uint32_t row_b = (uint32_t)ts * 64u, sz_b = (uint32_t)ts * 4u;   // bytes per token step
+    const uint32_t qoff0 = (uint32_t)r * row_b + g * 16, qoff1 = qoff0 + 16u * row_b;
+    const uint32_t soff0 = (uint32_t)r * sz_b, soff1 = soff0 + 16u * sz_b;
+
+    // Q^T fragments: column r = q head qh0 + r (zero beyond the group), dims 32g + 8kb + [1,5,0,4,3,7,2,6]
+    f16x8_t qB[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (r < P.group)
+            w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)(qh0 + r) * P.q_head_stride + 32 * g + 8 * kb);
+        // w = (d0 d1)(d2 d3)(d4 d5)(d6 d7), low half first
+        u32x4 o;
+        o.x = (w.x >> 16) | (w.z & 0xffff0000u);          // d1, d5
+        o.y = (w.x & 0xffffu) | (w.z << 16);              // d0, d4
+        o.z = (w.y >> 16) | (w.w & 0xffff0000u);          // d3, d7
+        o.w = (w.y & 0xffffu) | (w.w << 16);              // d2, d6
+        qB[kb] = as_f16x8(o);
+    }
+    const u32x4 ones_w = {0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u};
+    const f16x8_t ones = as_f16x8(ones_w);
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 8192];
+    // V^ tile of this wave: [32 keys][16 chunks of 16 B], chunk c of key k stored at slot c ^ (k & 15)
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)lds + wave * 8192;
+    uint32_t wa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = lbase + r * 256 + (((4 * g + j) ^ r) << 4);
+    // transpose read: lane i of a 16-lane group supplies the 8-byte piece (row i>>2, cols 4(i&3)..+3) of a
+    // 4 x 16 block and receives column i;  rows 4g..4g+3 (and +16), dim block nb -> address ^ (nb << 5)
+    const int kr = 4 * g + (r >> 2);
+    const uint32_t ra = lbase + kr * 256 + ((((r >> 1) & 1) ^ (kr & 15)) << 4) + 8 * (r & 1);
+
+    // opaque to the optimiser (masks in SGPRs, the exponent word in a VGPR) so that (w & mask) | magic is
+    // ONE v_and_or_b32: as literals the pair needs two instructions (one literal per VOP3 on gfx9)
+    uint32_t m0, m4, magic;
+    asm volatile("s_mov_b32 %0, 0x000f000f" : "=s"(m0));
+    asm volatile("s_mov_b32 %0, 0x00f000f0" : "=s"(m4));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+
+    f32x4 O[8], Lacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) O[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_ref = kNegSentinelI4;   // per q column, log2 domain (scores x scale x log2 e)
+    const float c_ = P.scale_log2e;
+
+    auto load_tile = [&](int t, I4Tile &T) {
+        const uint8_t *kq_t = kq + (int64_t)t * ts * 64, *vq_t = vq + (int64_t)t * ts * 64;
+        const uint8_t *ks_t = ksz + (int64_t)t * ts * 4, *vs_t = vsz + (int64_t)t * ts * 4;
+        uint32_t q0 = qoff0, q1 = qoff1, s0 = soff0, s1 = soff1;
+        if (t + 32 > w1) {   // tail tile (wave-uniform): rows past the range re-read the last one
+            const int last = w1 - 1 - t;
+            const int r0 = min(r, last), r1 = min(16 + r, last);
+            q0 = (uint32_t)r0 * row_b + g * 16; q1 = (uint32_t)r1 * row_b + g * 16;
+            s0 = (uint32_t)r0 * sz_b; s1 = (uint32_t)r1 * sz_b;
+        }
+        T.kw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kq_t + q0));
+        T.kw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kq_t + q1));
+        T.vw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vq_t + q0));
+        T.vw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vq_t + q1));
+        // (scale, zero) words: both 16-key halves of a tile share one 128-byte line — plain loads, so the
+        // second half hits in cache instead of fetching the line again (a streaming hint would drop it)
+        T.ks[0] = *reinterpret_cast<const uint32_t *>(ks_t + s0);
+        T.ks[1] = *reinterpret_cast<const uint32_t *>(ks_t + s1);
+        T.vs[0] = *reinterpret_cast<const uint32_t *>(vs_t + s0);
+        T.vs[1] = *reinterpret_cast<const uint32_t *>(vs_t + s1);
+    };
+
+    auto process = [&](const I4Tile &T, int t) {
+        // exact-fma form of the dequantisation unless some row of the tile has an out-of-range scale
+        const bool FAST = MODE == 1 && __all(row_is_fast(T.ks[0]) && row_is_fast(T.ks[1]) && row_is_fast(T.vs[0]) && row_is_fast(T.vs[1]));
+        if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic
+            m_ref += __uint_as_float((T.kw[0].x ^ T.kw[1].y ^ T.vw[0].z ^ T.vw[1].w ^ T.ks[0] ^ T.ks[1] ^ T.vs[0] ^ T.vs[1]) & 1u);
+            return;
+        }
+        // ---- S^T = K^ . Q^T ------------------------------------------------------------------
+        f32x4 S[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const RowConst R = row_const(T.ks[h], FAST);
+            const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8(kw[kb], R, m0, m4, magic, FAST)), qB[kb],
+                                                              S[h], 0, 0, 0);
+        }
+        // ---- V^ -> LDS (issued early: the writes drain while the softmax runs) -----------------
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const RowConst R = row_const(T.vs[h], FAST);
+            const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8(vw[j], R, m0, m4, magic, FAST);
+        }
+
+        // ---- softmax against the reference maximum ---------------------------------------------
+        float sv[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sv[4 * h + e] = S[h][e];
+        if (t + 32 > w1) {   // tail tile (wave-uniform): keys past the range score -inf
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + 16 * h + 4 * g + e >= w1) sv[4 * h + e] = kNegSentinelI4;
+        }
+        const float mx = c_ * fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])),
+                                    fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        if (__any(mx > m_ref + 8.f)) {
+            // raise the reference: true running maximum of every q column, accumulators rescaled
+            float tm = fmaxf(mx, __shfl_xor(mx, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float m_new = fmaxf(m_ref, tm);
+            const float alpha = fast_exp2(m_ref - m_new);
+            m_ref = m_new;
+            // O rows are q heads 4g + e: fetch their factors from the lanes that own those columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __shfl(alpha, 4 * g + e);
+                Lacc[e] *= a;
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) O[nb][e] *= a;
+            }
+        }
+        u32x4 pw;
+        {
+            float p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = fast_exp2(fmaf(sv[i], c_, -m_ref));
+            pw.x = cvt_pk_f16(p[0], p[1]);
+            pw.y = cvt_pk_f16(p[2], p[3]);
+            pw.z = cvt_pk_f16(p[4], p[5]);
+            pw.w = cvt_pk_f16(p[6], p[7]);
+        }
+        const f16x8_t pA = as_f16x8(pw);
+        // row sums of the (fp16-rounded) probabilities: one more MFMA against a block of ones
+        Lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, ones, Lacc, 0, 0, 0);
+
+        // ---- O += P . V^ : transpose reads two dim blocks at a time, one batch ahead of the MFMAs ------
+        u32x2 va[4], vb[4];
+        __builtin_amdgcn_sched_barrier(0);
+#define DUO_I4_TR_BATCH(buf, nb0)                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
+        const uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                     \
+        DUO_I4_TR_READ(buf[2 * i_], a_, 0);                                         \
+        DUO_I4_TR_READ(buf[2 * i_ + 1], a_, 4096);                                  \
+    }
+#define DUO_I4_PV(buf, nb0)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        const u32x4 w_ = {buf[2 * i_].x, buf[2 * i_].y, buf[2 * i_ + 1].x, buf[2 * i_ + 1].y};           \
+        O[(nb0) + i_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, as_f16x8(w_), O[(nb0) + i_], 0, 0, 0); \
+    }
+#define DUO_I4_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        DUO_I4_TR_BATCH(va, 0);
+        DUO_I4_TR_BATCH(vb, 2);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(va, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DUO_I4_TR_BATCH(va, 4);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(vb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DUO_I4_TR_BATCH(vb, 6);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(va, 4);
+        DUO_I4_WAIT(0);
+        DUO_I4_PV(vb, 6);
+#undef DUO_I4_TR_BATCH
+#undef DUO_I4_PV
+#undef DUO_I4_WAIT
+    };
+    if (w0 < w1) {
+        I4Tile T[RING];
+#pragma unroll
+        for (int i = 0; i < RING - 1; ++i)
+            if (w0 + 32 * i < w1) load_tile(w0 + 32 * i, T[i]);
+        for (int t = w0; t < w1; t += 32 * RING) {
+#pragma unroll
+            for (int i = 0; i < RING; ++i) {
+                const int tt = t + 32 * i;
+                if (tt < w1) {   // wave-uniform
+                    if (tt + 32 * (RING - 1) < w1) load_tile(tt + 32 * (RING - 1), T[(i + RING - 1) % RING]);
+                    process(T[i], tt);
+                }
+            }
+        }
+    }
+
+    // ---- combine the 4 waves through LDS ------------------------------------------------------
+    __syncthreads();   // every wave is done with its V^ tile: the LDS is reused for the partials
+    float *s_acc = reinterpret_cast<float *>(lds);                 // [4 waves][16 q][128 dims]  = 32 KiB
+    __shared__ float s_ml[4][16][2];
+    if (g == 0) s_ml[wave][r][0] = m_ref;
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_ml[wave][4 * g + e][1] = Lacc[e];
+    }
+    // O[nb][e] = (q row 4g + e, LDS column 16 nb + r) ; LDS column c <-> dim 8 (c >> 3) + perm[c & 7]
+    {
+        const int permv = (0x62734051u >> (4 * (r & 7))) & 15;   // [1,5,0,4,3,7,2,6][r & 7]
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const int dim = 16 * nb + 8 * (r >> 3) + permv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_acc[(wave * 16 + 4 * g + e) * DUO_HEAD_DIM + dim] = O[nb][e];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < P.group * DUO_HEAD_DIM; idx += 256) {
+        const int q = idx >> 7;
+        const int d = idx & 127;
+        float M = s_ml[0][q][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][q][0]);
+        float Lsum = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = fast_exp2(s_ml[w][q][0] - M);
+            Lsum = fmaf(s_ml[w][q][1], sc, Lsum);
+            o = fmaf(s_acc[(w * 16 + q) * DUO_HEAD_DIM + d], sc, o);
+        }
+        const int qh = qh0 + q;
+        if (splits == 1) {
+            P.out[(int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
+        } else {
+            const int64_t slot = (int64_t)qh * P.max_splits + split;
+            P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
+            if (d == 0) {
+                P.ws_ml[slot * 2 + 0] = M;
+                P.ws_ml[slot * 2 + 1] = Lsum;
+            }
+        }
+    }
+}
+
 struct Int4MergeParams {
     const float *ws_ml, *ws_acc;
     __half *out;
@@ -552,13 +923,24 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     }
     if (n_q_heads <= 0) return 0;
     P.group = group;
+    P.flags = duo_get_debug_flags();
     P.scale_log2e = scale * 1.4426950408889634f;
     const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
     const int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
     const int ms = max_splits > 0 ? max_splits : 1;
-    i4_choose_splits(P.cls[1].n_kv_heads, P.cls[1].len, ms, P.cls[0].n_kv_heads > 0 ? P.cls[1].n_kv_heads : 512, P.splits[1]);
+    // matrix-core form for GQA groups up to 16 q heads per kv head; debug flag bit 4 (and wider groups)
+    // select the scalar-FMA kernel
+    const bool mfma = group <= 16 && !(duo_get_debug_flags() & 16u);
+    static const int occ = [] {
+        const char *e = getenv("DUO_INT4_DECODE_WAVES");   // tuning knob: waves per SIMD the kernel is built for
+        const int x = e ? atoi(e) : 0;
+        return (x >= 2 && x <= 4) ? x : 3;
+    }();
+    // one resident round: 256 CUs x (workgroups per CU = waves per SIMD of the kernel in use)
+    const int target = 256 * (mfma ? occ : 2);
+    i4_choose_splits(P.cls[1].n_kv_heads, P.cls[1].len, ms, P.cls[0].n_kv_heads > 0 ? P.cls[1].n_kv_heads : target, P.splits[1]);
     i4_choose_splits(P.cls[0].n_kv_heads, P.cls[0].len, ms,
-                     std::max(512 - P.cls[1].n_kv_heads * P.splits[1], P.cls[0].n_kv_heads), P.splits[0]);
+                     std::max(target - P.cls[1].n_kv_heads * P.splits[1], P.cls[0].n_kv_heads), P.splits[0]);
     const int need = std::max(P.splits[0], P.splits[1]);
     if (need > 1 && max_splits < need) return DUO_EWORKSPC;
     P.max_splits = need > 1 ? need : 1;
@@ -566,12 +948,41 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     P.ws_acc = P.ws_ml ? P.ws_ml + (int64_t)n_q_heads * P.max_splits * 2 : nullptr;
     P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
     const int nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
-    const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
-    dim3 grid(nblk, group / gt), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (gt == 4) hipLaunchKernelGGL(duo_int4_decode_split_kernel<4>, grid, block, 0, st, P);
-    else if (gt == 2) hipLaunchKernelGGL(duo_int4_decode_split_kernel<2>, grid, block, 0, st, P);
-    else hipLaunchKernelGGL(duo_int4_decode_split_kernel<1>, grid, block, 0, st, P);
+    if (mfma) {
+        static const int ring = [] {
+            const char *e = getenv("DUO_INT4_DECODE_RING");    // tuning knob: register tiles per wave
+            const int x = e ? atoi(e) : 0;
+            return (x >= 2 && x <= 4) ? x : 3;
+        }();
+        dim3 grid(nblk), block(256);
+        static const int mode = [] {
+            const char *e = getenv("DUO_INT4_DECODE_MODE");
+            return e ? atoi(e) : 1;
+        }();
+#define DUO_I4_LAUNCH(W_, R_)                                                                                   \
+    do {                                                                                                        \
+        if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, R_, 0>), grid, block, 0, st, P);     \
+        else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, R_, 1>), grid, block, 0, st, P);               \
+    } while (0)
+        if (occ == 2) {
+            if (ring == 2) DUO_I4_LAUNCH(2, 2);
+            else if (ring == 4) DUO_I4_LAUNCH(2, 4);
+            else DUO_I4_LAUNCH(2, 3);
+        } else if (occ == 4) {
+            DUO_I4_LAUNCH(4, 2);
+        } else {
+            if (ring == 2) DUO_I4_LAUNCH(3, 2);
+            else DUO_I4_LAUNCH(3, 3);
+        }
+#undef DUO_I4_LAUNCH
+    } else {
+        const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
+        dim3 grid(nblk, group / gt), block(256);
+        if (gt == 4) hipLaunchKernelGGL(duo_int4_decode_split_kernel<4>, grid, block, 0, st, P);
+        else if (gt == 2) hipLaunchKernelGGL(duo_int4_decode_split_kernel<2>, grid, block, 0, st, P);
+        else hipLaunchKernelGGL(duo_int4_decode_split_kernel<1>, grid, block, 0, st, P);
+    }
     DUO_HIP_CHECK_LAUNCH();
     Int4MergeParams M;
     M.ws_ml = P.ws_ml; M.ws_acc = P.ws_acc; M.out = P.out; M.out_head_stride = out_head_stride;

@@ -93,6 +93,8 @@ def main():
             stream = _hip.make_int4_pool(skq[:, :ns], sksz[:, :ns], svq[:, :ns], svsz[:, :ns], W + 1, nf * G) if ns else None
             layers.append((full, stream, (fkq, fksz, fvq, fvsz, skq, sksz, svq, svsz)))
 
+        _hip.set_debug_flags(a.flags)
+
         def step():
             for full, stream, _ in layers:
                 _hip.attn_decode_int4(q, out, G, full, stream, scale)
