@@ -470,19 +470,27 @@ __device__ __forceinline__ RowConst row_const(uint32_t sz, bool fast) {
     }
     return R;
 }
-__device__ __forceinline__ bool row_is_fast(uint32_t sz) {
-    const uint32_t sb = sz & 0xffffu;   // scale >= 0
-    return sb == 0u || (sb >= 0x1400u && sb < 0x5400u);   // 0, or [2^-10, 64)
+// all four (scale, zero) words of a lane carry a scale in [2^-10, 64): as fp16 bit patterns
+// 0x1400 <= s < 0x5400  <=>  ((s - 0x1400) & 0xC000) == 0, tested two scales at a time.  (A zero scale —
+// a constant row — would qualify too but is left to the general form: one test fewer.)
+__device__ __forceinline__ bool scales_in_fma_range(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t ab = __builtin_amdgcn_perm(b, a, 0x05040100u);   // (scale(a), scale(b))
+    const uint32_t cd = __builtin_amdgcn_perm(d, c, 0x05040100u);
+    const uint32_t k = 0x14001400u;
+    uint32_t x, y;
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(x) : "v"(ab), "v"(k));
+    asm("v_pk_sub_u16 %0, %1, %2" : "=v"(y) : "v"(cd), "v"(k));
+    return ((x | y) & 0xC000C000u) == 0u;
 }
 
 // one packed dword (8 nibbles) -> 4 x half2 of reference-exact dequantised values, element order
 // [1,5 | 0,4 | 3,7 | 2,6] of the dword's 8 dims.  m0 / m4: nibble masks 0x000f000f / 0x00f000f0 (SGPRs),
 // magic: half2(1024, 1024) (VGPR) — see the note at their definition.
-// `fast` is wave-uniform (a vote over the tile): a scalar branch around ~13 or ~17 instructions.
-__device__ __forceinline__ u32x4 dq8(uint32_t w, const RowConst &R, uint32_t m0, uint32_t m4, uint32_t magic, bool fast) {
+template <bool FAST>
+__device__ __forceinline__ u32x4 dq8(uint32_t w, const RowConst &R, uint32_t m0, uint32_t m4, uint32_t magic) {
 #pragma clang fp contract(off)
     u32x4 o;
-    if (fast) {
+    if constexpr (FAST) {
         const uint32_t w8 = w >> 8;
         const h2_t a0 = as_h2((w & m0) | magic), a1 = as_h2((w & m4) | magic);
         const h2_t a2 = as_h2((w8 & m0) | magic), a3 = as_h2((w8 & m4) | magic);
@@ -518,9 +526,8 @@ struct I4Tile {
 
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
-// MINW: waves per SIMD the register budget is cut for; RING: 32-key tiles per wave held in registers
-// (one being processed, RING-1 in flight) — the bytes in flight per CU are what hides the HBM latency.
-template <int MINW, int RING, int MODE>
+// MINW: waves per SIMD the register budget is cut for; MODE: dequantisation form (see process()).
+template <int MINW, int MODE>
 __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const Int4DecodeParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -599,31 +606,46 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
     float m_ref = kNegSentinelI4;   // per q column, log2 domain (scores x scale x log2 e)
     const float c_ = P.scale_log2e;
 
-    auto load_tile = [&](int t, I4Tile &T) {
-        const uint8_t *kq_t = kq + (int64_t)t * ts * 64, *vq_t = vq + (int64_t)t * ts * 64;
-        const uint8_t *ks_t = ksz + (int64_t)t * ts * 4, *vs_t = vsz + (int64_t)t * ts * 4;
-        uint32_t q0 = qoff0, q1 = qoff1, s0 = soff0, s1 = soff1;
-        if (t + 32 > w1) {   // tail tile (wave-uniform): rows past the range re-read the last one
-            const int last = w1 - 1 - t;
-            const int r0 = min(r, last), r1 = min(16 + r, last);
-            q0 = (uint32_t)r0 * row_b + g * 16; q1 = (uint32_t)r1 * row_b + g * 16;
-            s0 = (uint32_t)r0 * sz_b; s1 = (uint32_t)r1 * sz_b;
-        }
-        T.kw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kq_t + q0));
-        T.kw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kq_t + q1));
-        T.vw[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vq_t + q0));
-        T.vw[1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(vq_t + q1));
-        // (scale, zero) words: both 16-key halves of a tile share one 128-byte line — plain loads, so the
-        // second half hits in cache instead of fetching the line again (a streaming hint would drop it)
-        T.ks[0] = *reinterpret_cast<const uint32_t *>(ks_t + s0);
-        T.ks[1] = *reinterpret_cast<const uint32_t *>(ks_t + s1);
-        T.vs[0] = *reinterpret_cast<const uint32_t *>(vs_t + s0);
-        T.vs[1] = *reinterpret_cast<const uint32_t *>(vs_t + s1);
+    // A full tile: uniform row bases (SGPR pairs) + the four constant per-lane offsets.  (The empty asm
+    // re-materialises each 32-bit offset in the basic block of the loads so that they select the
+    // sgpr-base + vgpr32-offset addressing form; in place, so no temporary register is involved.)
+    uint32_t qo0 = qoff0, qo1 = qoff1, so0 = soff0, so1 = soff1;
+    typedef __attribute__((address_space(1))) const uint8_t gbyte_t;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4_t;
+    typedef __attribute__((address_space(1))) const uint32_t gu32_t;
+    auto ubase = [&](const uint8_t *p) __attribute__((always_inline)) {
+        const uint64_t a = (uint64_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return (gbyte_t *)(((uint64_t)hi << 32) | lo);
+    };
+    auto load_at = [&](int t, I4Tile &T, uint32_t &q0, uint32_t &q1, uint32_t &s0, uint32_t &s1) __attribute__((always_inline)) {
+        gbyte_t *kq_t = ubase(kq + (int64_t)t * ts * 64), *vq_t = ubase(vq + (int64_t)t * ts * 64);
+        gbyte_t *ks_t = ubase(ksz + (int64_t)t * ts * 4), *vs_t = ubase(vsz + (int64_t)t * ts * 4);
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(s0), "+v"(s1));
+        T.kw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + q0));
+        T.kw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + q1));
+        T.vw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + q0));
+        T.vw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + q1));
+        T.ks[0] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(ks_t + s0));
+        T.ks[1] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(ks_t + s1));
+        T.vs[0] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(vs_t + s0));
+        T.vs[1] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(vs_t + s1));
+    };
+    auto load_full = [&](int t, I4Tile &T) __attribute__((always_inline)) { load_at(t, T, qo0, qo1, so0, so1); };
+    // the partial last tile: rows past the range re-read the last one
+    auto load_tail = [&](int t, I4Tile &T) __attribute__((always_inline)) {
+        const int last = w1 - 1 - t;
+        const int r0 = min(r, last), r1 = min(16 + r, last);
+        uint32_t q0 = (uint32_t)r0 * row_b + g * 16, q1 = (uint32_t)r1 * row_b + g * 16;
+        uint32_t s0 = (uint32_t)r0 * sz_b, s1 = (uint32_t)r1 * sz_b;
+        load_at(t, T, q0, q1, s0, s1);
     };
 
-    auto process = [&](const I4Tile &T, int t) {
-        // exact-fma form of the dequantisation unless some row of the tile has an out-of-range scale
-        const bool FAST = MODE == 1 && __all(row_is_fast(T.ks[0]) && row_is_fast(T.ks[1]) && row_is_fast(T.vs[0]) && row_is_fast(T.vs[1]));
+    // Tile body.  FAST: the exact-fma dequantisation (all row scales of the tile in range — the caller has
+    // voted); otherwise subtract-multiply-add.  TAIL: partial tile, keys past the range masked.
+    auto process = [&](const I4Tile &T, int t, auto fast_tag, auto tail_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool TAIL = decltype(tail_tag)::value;
         if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic
             m_ref += __uint_as_float((T.kw[0].x ^ T.kw[1].y ^ T.vw[0].z ^ T.vw[1].w ^ T.ks[0] ^ T.ks[1] ^ T.vs[0] ^ T.vs[1]) & 1u);
             return;
@@ -637,7 +659,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8(kw[kb], R, m0, m4, magic, FAST)), qB[kb],
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST>(kw[kb], R, m0, m4, magic)), qB[kb],
                                                               S[h], 0, 0, 0);
         }
         // ---- V^ -> LDS (issued early: the writes drain while the softmax runs) -----------------
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8(vw[j], R, m0, m4, magic, FAST);
+                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8<FAST>(vw[j], R, m0, m4, magic);
         }
 
         // ---- softmax against the reference maximum ---------------------------------------------
@@ -656,7 +678,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sv[4 * h + e] = S[h][e];
-        if (t + 32 > w1) {   // tail tile (wave-uniform): keys past the range score -inf
+        if constexpr (TAIL) {   // keys past the range score -inf
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -728,20 +750,47 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
 #undef DUO_I4_PV
 #undef DUO_I4_WAIT
     };
+    // Main loop over the full tiles: straight-line code with a fixed number of loads in flight (the next
+    // tile's 8 loads are issued, unconditionally, before the current tile is touched; after the last full
+    // tile the prefetch re-reads it) so every wait is vmcnt(8), never vmcnt(0).  It runs the FAST body and
+    // is left at a tile whose rows fail the scale vote: that one tile (re-loaded) goes through the
+    // always-exact general form, then the fast loop resumes.  The partial last tile is general too.
     if (w0 < w1) {
-        I4Tile T[RING];
-#pragma unroll
-        for (int i = 0; i < RING - 1; ++i)
-            if (w0 + 32 * i < w1) load_tile(w0 + 32 * i, T[i]);
-        for (int t = w0; t < w1; t += 32 * RING) {
-#pragma unroll
-            for (int i = 0; i < RING; ++i) {
-                const int tt = t + 32 * i;
-                if (tt < w1) {   // wave-uniform
-                    if (tt + 32 * (RING - 1) < w1) load_tile(tt + 32 * (RING - 1), T[(i + RING - 1) % RING]);
-                    process(T[i], tt);
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        const int t_full_end = w0 + (((w1 - w0) >> 5) << 5);   // end of the full tiles
+        int t = w0;
+        while (t < w1) {
+            if (MODE != 0 && t < t_full_end) {
+                const int t_last = t_full_end - 32;
+                I4Tile A, B;
+                load_full(t, A);
+                for (;;) {
+                    load_full(min(t + 32, t_last), B);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MODE == 1 && !__all(scales_in_fma_range(A.ks[0], A.ks[1], A.vs[0], A.vs[1]))) break;
+                    process(A, t, T_{}, F_{});
+                    t += 32;
+                    if (t > t_last) break;
+                    load_full(min(t + 32, t_last), A);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MODE == 1 && !__all(scales_in_fma_range(B.ks[0], B.ks[1], B.vs[0], B.vs[1]))) break;
+                    process(B, t, T_{}, F_{});
+                    t += 32;
+                    if (t > t_last) break;
                 }
+                if (t >= w1) break;
             }
+            // one tile in the general form: the one that failed the vote, or the partial last one
+            I4Tile X;
+            if (t + 32 <= w1) {
+                load_full(t, X);
+                process(X, t, F_{}, F_{});
+            } else {
+                load_tail(t, X);
+                process(X, t, F_{}, T_{});
+            }
+            t += 32;
         }
     }
 
@@ -807,12 +856,15 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
         if (qh < n0) { qh += P.qh_begin[0]; splits = P.splits[0]; }
         else { qh = qh - n0 + P.qh_begin[1]; splits = P.splits[1]; }
     }
-    const int sl = threadIdx.x >> 5, dq = threadIdx.x & 31;
+    // grid.y = 4: each workgroup merges a 32-dim quarter of the head — 8 threads x 4 dims across, 32 split
+    // lanes deep, so even ~200 splits are 6 dependent steps instead of 24
+    const int sl = threadIdx.x >> 3, dq = threadIdx.x & 7;
+    const int d0 = blockIdx.y * 32 + dq * 4;
     const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
-    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + dq * 4;
+    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
     __shared__ float red[4];
-    __shared__ float slm[8][32];
-    __shared__ f32x4 so[8][32];
+    __shared__ float slm[32][8];
+    __shared__ f32x4 so[32][8];
     float M = kNegSentinelI4;
     for (int s = threadIdx.x; s < splits; s += 256) M = fmaxf(M, ml[s * 2]);
 #pragma unroll
@@ -822,7 +874,8 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
     M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float Lsum = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int s = sl; s < splits; s += 8) {
+#pragma unroll 2
+    for (int s = sl; s < splits; s += 32) {
         const float wu = fast_exp2(ml[s * 2] - M);
         Lsum = fmaf(ml[s * 2 + 1], wu, Lsum);
         o = o + *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM) * wu;
@@ -834,11 +887,11 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
         float LL = 0.f;
         f32x4 oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { LL += slm[i][dq]; oo = oo + so[i][dq]; }
+        for (int i = 0; i < 32; ++i) { LL += slm[i][dq]; oo = oo + so[i][dq]; }
         const float inv = 1.f / LL;
         __half h4[4] = {__float2half(oo.x * inv), __float2half(oo.y * inv), __float2half(oo.z * inv),
                         __float2half(oo.w * inv)};
-        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + dq * 4) = *reinterpret_cast<const u32x2 *>(h4);
+        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + d0) = *reinterpret_cast<const u32x2 *>(h4);
     }
 }
 
@@ -934,7 +987,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     static const int occ = [] {
         const char *e = getenv("DUO_INT4_DECODE_WAVES");   // tuning knob: waves per SIMD the kernel is built for
         const int x = e ? atoi(e) : 0;
-        return (x >= 2 && x <= 4) ? x : 3;
+        return (x >= 2 && x <= 4) ? x : 2;
     }();
     // one resident round: 256 CUs x (workgroups per CU = waves per SIMD of the kernel in use)
     const int target = 256 * (mfma ? occ : 2);
@@ -950,31 +1003,21 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     const int nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
     hipStream_t st = (hipStream_t)stream;
     if (mfma) {
-        static const int ring = [] {
-            const char *e = getenv("DUO_INT4_DECODE_RING");    // tuning knob: register tiles per wave
-            const int x = e ? atoi(e) : 0;
-            return (x >= 2 && x <= 4) ? x : 3;
+        static const int mode = [] {
+            const char *e = getenv("DUO_INT4_DECODE_MODE");    // 0 exact 3-op, 1 voted fma (default), 2 fma always (unsafe)
+            const int x = e ? atoi(e) : 1;
+            return (x >= 0 && x <= 2) ? x : 1;
         }();
         dim3 grid(nblk), block(256);
-        static const int mode = [] {
-            const char *e = getenv("DUO_INT4_DECODE_MODE");
-            return e ? atoi(e) : 1;
-        }();
-#define DUO_I4_LAUNCH(W_, R_)                                                                                   \
-    do {                                                                                                        \
-        if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, R_, 0>), grid, block, 0, st, P);     \
-        else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, R_, 1>), grid, block, 0, st, P);               \
+#define DUO_I4_LAUNCH(W_)                                                                                   \
+    do {                                                                                                    \
+        if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 0>), grid, block, 0, st, P);     \
+        else if (mode == 2) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 2>), grid, block, 0, st, P); \
+        else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 1>), grid, block, 0, st, P);               \
     } while (0)
-        if (occ == 2) {
-            if (ring == 2) DUO_I4_LAUNCH(2, 2);
-            else if (ring == 4) DUO_I4_LAUNCH(2, 4);
-            else DUO_I4_LAUNCH(2, 3);
-        } else if (occ == 4) {
-            DUO_I4_LAUNCH(4, 2);
-        } else {
-            if (ring == 2) DUO_I4_LAUNCH(3, 2);
-            else DUO_I4_LAUNCH(3, 3);
-        }
+        if (occ == 2) DUO_I4_LAUNCH(2);
+        else if (occ == 4) DUO_I4_LAUNCH(4);
+        else DUO_I4_LAUNCH(3);
 #undef DUO_I4_LAUNCH
     } else {
         const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
@@ -995,7 +1038,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
         if (P.splits[c] > 1) n_merge += P.cls[c].n_kv_heads * group;
     }
     if (n_merge > 0) {
-        hipLaunchKernelGGL(duo_int4_decode_merge_kernel, dim3(n_merge), dim3(256), 0, st, M);
+        hipLaunchKernelGGL(duo_int4_decode_merge_kernel, dim3(n_merge, 4), dim3(256), 0, st, M);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;

@@ -84,7 +84,7 @@ def main():
         for nf in counts:
             ns = HKV - nf
             mk = lambda h, T: (torch.randint(0, 256, (h, T, 64), generator=g, device=dev, dtype=torch.uint8).permute(1, 0, 2),
-                               (torch.rand(h, T, 2, generator=g, device=dev) * 0.3).to(torch.float16).permute(1, 0, 2))
+                               (torch.rand(h, T, 2, generator=g, device=dev) * 0.3 + 0.01).to(torch.float16).permute(1, 0, 2))
             fkq, fksz = mk(max(nf, 1), N + 1)
             fvq, fvsz = mk(max(nf, 1), N + 1)
             skq, sksz = mk(max(ns, 1), W + 1)
