@@ -48,6 +48,7 @@ struct DecodeParams {
     //      new k row, scores it and — for retrieval heads — appends k,v to the pool at row app_row.
     //      q and k are never written (the epilogue's pool update rotates the streaming rows itself).
     int32_t fused;
+    uint32_t dbg;            // debug flags copy (bit 6: loads only — the memory-side ceiling of the scan)
     int32_t app_row;
     bf16_t *app_k, *app_v;   // full pool bases (head 0, row 0)
     int64_t app_ts, app_hs;
@@ -292,11 +293,13 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
             for (int t = w0;; t += 2 * kTokPerIter) {
                 load_fast(min(t + kTokPerIter, t_last), k1, v1);
                 __builtin_amdgcn_sched_barrier(0);
-                consume_rows<GT, true>(k0, v0, t, tg, w1, qf, m, l, acc);
+                if (P.dbg & 64u) l[0] += __uint_as_float((k0[0].x ^ k0[1].y ^ k0[2].z ^ k0[3].w ^ v0[0].x ^ v0[1].y ^ v0[2].z ^ v0[3].w) & 1u);
+                else consume_rows<GT, true>(k0, v0, t, tg, w1, qf, m, l, acc);
                 if (t >= t_last) break;
                 load_fast(min(t + 2 * kTokPerIter, t_last), k0, v0);
                 __builtin_amdgcn_sched_barrier(0);
-                consume_rows<GT, true>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
+                if (P.dbg & 64u) l[0] += __uint_as_float((k1[0].x ^ k1[1].y ^ k1[2].z ^ k1[3].w ^ v1[0].x ^ v1[1].y ^ v1[2].z ^ v1[3].w) & 1u);
+                else consume_rows<GT, true>(k1, v1, t + kTokPerIter, tg, w1, qf, m, l, acc);
                 if (t + kTokPerIter >= t_last) break;
             }
             t_rest = w0 + nfast * kTokPerIter;
@@ -567,6 +570,8 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.cls[0] = duo_class_dev(full);
     P.cls[1] = duo_class_dev(stream_cls);
     P.group = group;
+    P.dbg = duo_get_debug_flags();
+    P.fused = 0;
     P.scale_log2e = scale * 1.4426950408889634f;
     const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
     D.nblk = 0;
