@@ -49,6 +49,10 @@ struct DecodeParams {
     //      q and k are never written (the epilogue's pool update rotates the streaming rows itself).
     int32_t fused;
     uint32_t dbg;            // debug flags copy (bit 6: loads only — the memory-side ceiling of the scan)
+    // device-side step state {full_len, str_len, pos, _} of this layer (duo_decode_layer_dev_bf16): when
+    // set, the lengths and the position are read from here instead of the launch parameters, so a
+    // captured launch stays valid while the cache grows
+    const int32_t *dev_state;
     int32_t app_row;
     bf16_t *app_k, *app_v;   // full pool bases (head 0, row 0)
     int64_t app_ts, app_hs;
@@ -178,7 +182,16 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     int b = blockIdx.x;
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
-    const DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    int app_row = P.app_row;
+    float pos = P.pos;
+    if constexpr (FUSED) {
+        if (P.dev_state) {   // uniform scalar loads
+            app_row = P.dev_state[0];
+            C.a.len = ci ? P.dev_state[1] : app_row;
+            pos = (float)P.dev_state[2];
+        }
+    }
     const int splits = ci ? P.splits[1] : P.splits[0];
     const int kvh = b / splits;
     const int split = b - kvh * splits;
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     float cs[8], sn[8];
     if constexpr (FUSED) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sincos_rev(P.pos * P.inv_freq[((sub & 7) << 3) + e], sn[e], cs[e]);
+        for (int e = 0; e < 8; ++e) sincos_rev(pos * P.inv_freq[((sub & 7) << 3) + e], sn[e], cs[e]);
     }
     // x: own slice, y: partner slice -> rotated own slice (first half: x*c - y*s, second half: x*c + y*s)
     auto rope8 = [&](const u32x4 &own, const u32x4 &partner, float (&o)[8]) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
             // retrieval heads: the rotated key and the value join the pool (row app_row is outside
             // every scan range of this launch)
             if (ci == 0 && blockIdx.y == 0) {
-                const int64_t po = (int64_t)P.app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
+                const int64_t po = (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
                 *reinterpret_cast<u32x4 *>(P.app_k + po) = kr;
                 *reinterpret_cast<u32x4 *>(P.app_v + po) = vw;
             }
@@ -572,6 +585,7 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.group = group;
     P.dbg = duo_get_debug_flags();
     P.fused = 0;
+    P.dev_state = nullptr;
     P.scale_log2e = scale * 1.4426950408889634f;
     const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
     D.nblk = 0;
@@ -671,8 +685,8 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
 // One decode step of one layer of the static dual-cache path in two launches: the split-KV scan of
 // both head classes with RoPE of q / the new key row and the retrieval-pool append folded in, then
 // merge + streaming-pool update.  See include/duo_attn_hip.h.
-extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
-                                     void *workspace, int64_t workspace_bytes, void *stream) {
+static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream_len, const int32_t *dev_state,
+                             void *workspace, int64_t workspace_bytes, void *stream) {
     if (!a) return DUO_EINVAL;
     if (a->head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     const int nf = a->n_full, nkv = a->n_kv_heads, ns = nkv - nf;
@@ -715,6 +729,7 @@ extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *ne
     D.P.app_ts = a->full_token_stride;
     D.P.app_hs = a->full_head_stride;
     D.P.pos = (float)a->pos;
+    D.P.dev_state = dev_state;
     memcpy(D.P.inv_freq, inv_freq, sizeof(inv_freq));
     rc = decode_launch_split<true>(D, st);
     if (rc) return rc;
@@ -730,7 +745,7 @@ extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *ne
         C = CompressParams{(bf16_t *)a->str_k, (bf16_t *)a->str_v, a->str_token_stride, a->str_head_stride,
                            (const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
                            (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride,
-                           ns, a->str_len, 1, a->sink, a->recent, 1, (float)a->pos, {}};
+                           ns, a->str_len, 1, a->sink, a->recent, 1, (float)a->pos, {}, dev_state};
         memcpy(C.inv_freq, inv_freq, sizeof(inv_freq));
         n_compress = 2 * ns;
     }
@@ -738,5 +753,46 @@ extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *ne
         hipLaunchKernelGGL(duo_decode_post_kernel, dim3(D.n_merge + n_compress), dim3(256), 0, st, D.M, D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
+                                     void *workspace, int64_t workspace_bytes, void *stream) {
+    return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, stream);
+}
+
+// Same step with the lengths and the position read on the device (see include/duo_attn_hip.h): the
+// values in `a` only size the grid, so the two launches can sit in a captured HIP graph and be replayed
+// while the cache grows.
+extern "C" int duo_decode_layer_dev_bf16(const duo_decode_layer_args *a, const duo_decode_state *dev_state,
+                                         void *workspace, int64_t workspace_bytes, void *stream) {
+    if (!a || !dev_state) return DUO_EINVAL;
+    duo_decode_layer_args plan = *a;
+    // planning lengths: at least one cached row per class keeps the segment descriptors on the pools
+    if (plan.full_len < 1) plan.full_len = 1;
+    if (plan.n_full > 0 && plan.full_len + 1 > plan.full_capacity) plan.full_len = plan.full_capacity - 1;
+    if (plan.str_len < 1) plan.str_len = 1;
+    return decode_layer_impl(&plan, nullptr, reinterpret_cast<const int32_t *>(dev_state), workspace, workspace_bytes,
+                             stream);
+}
+
+namespace {
+__global__ void duo_decode_state_add_kernel(duo_decode_state *st, int n, int d_full, int d_str, int d_pos, int str_cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    duo_decode_state s = st[i];
+    s.full_len = max(0, s.full_len + d_full);
+    s.str_len = min(str_cap, max(0, s.str_len + d_str));
+    s.pos = max(0, s.pos + d_pos);
+    st[i] = s;
+}
+}  // namespace
+
+extern "C" int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t d_full, int32_t d_str,
+                                    int32_t d_pos, int32_t str_cap, void *stream) {
+    if (!dev_states || n_layers <= 0 || str_cap < 0) return DUO_EINVAL;
+    hipLaunchKernelGGL(duo_decode_state_add_kernel, dim3((n_layers + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       dev_states, n_layers, d_full, d_str, d_pos, str_cap);
+    DUO_HIP_CHECK_LAUNCH();
     return 0;
 }

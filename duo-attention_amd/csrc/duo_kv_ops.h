@@ -54,22 +54,29 @@ struct CompressParams {
     int32_t rope;
     float pos;
     float inv_freq[64];
+    const int32_t *dev_state;   // {full_len, str_len, pos, _}: overrides cur / pos when set (captured decode step)
 };
 
 constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
 
 __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &P, int blk) {
+    int cur = P.cur;
+    float pos = P.pos;
+    if (P.dev_state) {
+        cur = P.dev_state[1];
+        pos = (float)P.dev_state[2];
+    }
     const int h = blk >> 1;
     const bool is_v = blk & 1;
     bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs;
     const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs;
-    const int T = P.cur + P.n_new;
+    const int T = cur + P.n_new;
     const int W = P.sink + P.recent;
     const int ch = threadIdx.x & 15;
     const int r_in = threadIdx.x >> 4;   // 0..15
 
     int d_begin, d_end;
-    if (T <= W) { d_begin = P.cur; d_end = T; }
+    if (T <= W) { d_begin = cur; d_end = T; }
     else { d_begin = 0; d_end = W; }
 
     for (int d0 = d_begin; d0 < d_end; d0 += CMP_ROWS) {
@@ -82,11 +89,11 @@ __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &
             int x = d;                                   // source index in X
             if (T > W && d >= P.sink) x = T - P.recent + (d - P.sink);
             // rows that stay where they are need no traffic
-            if (act[j] && x == d && x < P.cur) act[j] = false;
+            if (act[j] && x == d && x < cur) act[j] = false;
             if (act[j]) {
-                const bf16_t *src = x < P.cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - P.cur) * P.n_ts;
+                const bf16_t *src = x < cur ? pool + (int64_t)x * P.p_ts : nw + (int64_t)(x - cur) * P.n_ts;
                 buf[j] = *reinterpret_cast<const u32x4 *>(src + ch * 8);
-                if (P.rope && !is_v && x >= P.cur) {
+                if (P.rope && !is_v && x >= cur) {
                     // chunk ch holds dims 8ch..8ch+7; its rotation partner is chunk ch ^ 8
                     float xs[8], ys[8];
                     unpack8f(buf[j], xs);
@@ -95,7 +102,7 @@ __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         float sn, cs;
-                        sincos_rev(P.pos * P.inv_freq[((ch & 7) << 3) + e], sn, cs);
+                        sincos_rev(pos * P.inv_freq[((ch & 7) << 3) + e], sn, cs);
                         xs[e] = xs[e] * cs + sgn * ys[e] * sn;
                     }
                     buf[j] = pack8f(xs);

@@ -104,6 +104,10 @@ _SIGNATURES = {
     "duo_decode_layer_bf16": (
         ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(c_int32), c_void_p, c_int64, c_void_p],
     ),
+    "duo_decode_layer_dev_bf16": (
+        ctypes.c_int, [POINTER(DecodeLayerArgs), c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_decode_state_add": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "duo_attn_prefill_bf16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
@@ -302,11 +306,8 @@ def attn_decode(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[H
     )
 
 
-def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
-                 rope_scale, rope_theta, scale) -> int:
-    """Fused decode step of one layer (one batch row).  q/out [Hq, D]; k/v [Hkv, D] new rows;
-    full_k/full_v [T, nf, D] and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
-    lib = load_library()
+def _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
+                       rope_scale, rope_theta, scale) -> DecodeLayerArgs:
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
         _require_gpu_bf16(t, n)
     assert k.stride(0) == v.stride(0)
@@ -330,11 +331,42 @@ def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, s
         a.str_token_stride, a.str_head_stride = str_k.stride(0), str_k.stride(1)
     a.str_len, a.sink, a.recent = int(str_len), int(sink), int(recent)
     a.pos, a.rope_scale, a.rope_theta, a.scale = int(pos), float(rope_scale), float(rope_theta), float(scale)
+    return a
+
+
+def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
+                 rope_scale, rope_theta, scale) -> int:
+    """Fused decode step of one layer (one batch row).  q/out [Hq, D]; k/v [Hkv, D] new rows;
+    full_k/full_v [T, nf, D] and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
+    lib = load_library()
+    a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
+                           rope_scale, rope_theta, scale)
     ws = decode_workspace(q.device, q.shape[0])
     new_len = c_int32(0)
     _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
            "duo_decode_layer_bf16")
     return int(new_len.value)
+
+
+def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink, recent,
+                     plan_pos, rope_scale, rope_theta, scale, dev_state: torch.Tensor) -> None:
+    """The same step with lengths / position read from ``dev_state`` (int32 [4] on the GPU:
+    full_len, str_len, pos, pad) — graph-capturable; the ``plan_*`` values only size the grid."""
+    lib = load_library()
+    assert dev_state.is_cuda and dev_state.dtype == torch.int32 and dev_state.numel() >= 4 and dev_state.is_contiguous()
+    a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink,
+                           recent, plan_pos, rope_scale, rope_theta, scale)
+    ws = decode_workspace(q.device, q.shape[0])
+    _check(lib.duo_decode_layer_dev_bf16(byref(a), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+           "duo_decode_layer_dev_bf16")
+
+
+def decode_state_add(dev_states: torch.Tensor, d_full: int, d_str: int, d_pos: int, str_cap: int) -> None:
+    """dev_states: int32 [n_layers, 4] on the GPU; one launch advances / rewinds every layer's counters."""
+    lib = load_library()
+    assert dev_states.is_cuda and dev_states.dtype == torch.int32 and dev_states.is_contiguous() and dev_states.shape[-1] == 4
+    _check(lib.duo_decode_state_add(dev_states.data_ptr(), dev_states.numel() // 4, int(d_full), int(d_str), int(d_pos),
+                                    int(str_cap), _stream_ptr()), "duo_decode_state_add")
 
 
 def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],

@@ -66,6 +66,12 @@ class HipBackend:
         return self._hip.decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len,
                                       sink, recent, pos, rope_scale, rope_theta, scale)
 
+    def decode_layer_dev(self, *args, **kw) -> None:
+        return self._hip.decode_layer_dev(*args, **kw)
+
+    def decode_state_add(self, dev_states, d_full, d_str, d_pos, str_cap) -> None:
+        return self._hip.decode_state_add(dev_states, d_full, d_str, d_pos, str_cap)
+
     # -- flashinfer.norm.rmsnorm (reference flashinfer_utils.py:9-16)
     def rmsnorm(self, x, weight, eps: float):
         return self._hip.rmsnorm(x, weight, eps)

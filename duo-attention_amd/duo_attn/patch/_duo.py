@@ -102,7 +102,7 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
 def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, layer_idx, pos0, rope_scale,
                        rope_theta):
     """q_len == 1 after a prefill: the same steps as the general path below (RoPE, put_full_kv, the two
-    head-class attentions, the streaming update) issued as ONE backend call = three kernel launches,
+    head-class attentions, the streaming update) issued as ONE backend call = two kernel launches,
     with the cache counters updated exactly as put_full_kv / compress_and_replace_streaming_kv do."""
     bsz, _, num_heads, head_dim = query_states.shape
     nf = kv_cache.num_full_kv_head_list[layer_idx]
@@ -115,11 +115,21 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
     pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
     sk, sv = kv_cache.streaming_key_states_list[layer_idx], kv_cache.streaming_value_states_list[layer_idx]
     attn_output = torch.empty_like(query_states)
-    new_len = str_len
-    for b in range(bsz):
-        new_len = be.decode_layer(query_states[b, 0], key_states[b, 0], value_states[b, 0], attn_output[b, 0], nf,
-                                  pk[b], pv[b], cur, sk[b], sv[b], str_len, kv_cache.sink_size,
-                                  kv_cache.recent_size, pos0, rope_scale, rope_theta, head_dim ** -0.5)
+    W = kv_cache.sink_size + kv_cache.recent_size
+    new_len = min(str_len + 1, W)
+    if getattr(kv_cache, "use_device_state", False):
+        # graph-capturable form: the kernels read full_len / str_len / pos from the layer's device state;
+        # the host values passed here only size the split-KV grid
+        if bsz != 1:
+            raise ValueError("device-side decode state supports batch size 1")
+        be.decode_layer_dev(query_states[0, 0], key_states[0, 0], value_states[0, 0], attn_output[0, 0], nf,
+                            pk[0], pv[0], cur, sk[0], sv[0], str_len, kv_cache.sink_size, kv_cache.recent_size,
+                            pos0, rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
+    else:
+        for b in range(bsz):
+            new_len = be.decode_layer(query_states[b, 0], key_states[b, 0], value_states[b, 0], attn_output[b, 0], nf,
+                                      pk[b], pv[b], cur, sk[b], sv[b], str_len, kv_cache.sink_size,
+                                      kv_cache.recent_size, pos0, rope_scale, rope_theta, head_dim ** -0.5)
     kv_cache.kv_seq_len_list[layer_idx] = cur + 1
     kv_cache.streaming_kv_seq_len_list[layer_idx] = new_len
     return attn_output

@@ -170,6 +170,32 @@ class DuoAttentionStaticKVCache:
             self.kv_seq_len_list[i] = max(0, self.kv_seq_len_list[i] - num_tokens)
             self.streaming_kv_seq_len_list[i] = max(0, self.streaming_kv_seq_len_list[i] - num_tokens)
 
+    # ---- device-side counters (a decode step that can be captured in a HIP graph) --------
+    # The reference keeps the lengths as Python ints only (static_kv_cache.py:44-45), so every launch
+    # bakes them in.  With the device state enabled each layer also has {full_len, str_len, pos, pad}
+    # int32 in HBM; while ``use_device_state`` is set the fused decode step reads its lengths from there
+    # (duo_decode_layer_dev_bf16), and ``device_state_add`` advances / rewinds all layers in one launch.
+    # The Python ints stay the host's view (planning, capacity checks, every non-captured path).
+    device_state = None
+    use_device_state = False
+
+    def enable_device_state(self):
+        if self.device_state is None:
+            self.device_state = torch.zeros(self.num_layers, 4, dtype=torch.int32, device=self.device)
+        self.sync_device_state()
+        return self.device_state
+
+    def sync_device_state(self):
+        """host counters -> device (one small H2D copy; not capturable, call it outside a graph)"""
+        rows = [[self.kv_seq_len_list[i], self.streaming_kv_seq_len_list[i], self.kv_seq_len_list[i], 0]
+                for i in range(self.num_layers)]
+        self.device_state.copy_(torch.tensor(rows, dtype=torch.int32), non_blocking=False)
+
+    def device_state_add(self, d_full, d_str, d_pos):
+        from ..backend import get_backend
+
+        get_backend().decode_state_add(self.device_state, d_full, d_str, d_pos, self.sink_size + self.recent_size)
+
     @property
     def memory_usage(self):
         total = 0

@@ -182,6 +182,27 @@ typedef struct duo_decode_layer_args {
 int duo_decode_layer_bf16(const duo_decode_layer_args *args, int32_t *new_stream_len,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- the same step with device-side lengths (graph-captured decode) ----------------
+ * The reference keeps the cache lengths as Python ints (static_kv_cache.py:44-45), which bakes them
+ * into every launch and rules out capturing the decode step in a graph.  Here each layer has a
+ * duo_decode_state in DEVICE memory; duo_decode_layer_dev_bf16 issues the same two launches as
+ * duo_decode_layer_bf16 but the kernels read full_len / str_len / pos from *dev_state.  The
+ * full_len / str_len / pos fields of `args` are only planning hints (they size the split-KV grid; the
+ * balanced partition in the kernel adapts to the real length), so a captured launch stays valid as the
+ * cache grows.  The caller keeps full_len + 1 <= full_capacity.
+ * duo_decode_state_add advances (or rewinds: evict_last) the states of all layers in one launch:
+ *   full_len = max(0, full_len + d_full); str_len = clamp(str_len + d_str, 0, str_cap); pos += d_pos. */
+typedef struct duo_decode_state {
+    int32_t full_len;        /* rows in the retrieval pool (kv_seq_len_list[l])              */
+    int32_t str_len;         /* rows in the streaming pool (streaming_kv_seq_len_list[l])    */
+    int32_t pos;             /* position id of the next token                                */
+    int32_t _pad;
+} duo_decode_state;
+int duo_decode_layer_dev_bf16(const duo_decode_layer_args *args, const duo_decode_state *dev_state,
+                              void *workspace, int64_t workspace_bytes, void *stream);
+int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t d_full, int32_t d_str,
+                         int32_t d_pos, int32_t str_cap, void *stream);
+
 /* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
  * q/out: [S, n_q_heads, 128] with the given token/head strides.               */
 int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride,

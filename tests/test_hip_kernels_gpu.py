@@ -372,3 +372,73 @@ def test_cpu_tensor_is_refused():
     q = torch.zeros(4, 4, D, dtype=torch.bfloat16)
     with pytest.raises(h.DuoHipError, match="no CPU fallback"):
         h.rope_inplace(q, q, 0, 1.0, 1e4)
+
+
+# ----------------------------------------------------------------------------- device-side step state / graph
+def _decode_loop_setup(counts, Hq, Hkv, sink, recent, prefill, max_size, seed):
+    from duo_attn.patch._duo import duo_static_attention_core
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    g = torch.Generator().manual_seed(seed)
+    L = len(counts)
+    model = ShapeModel(L, Hq, Hkv, D, device=DEV)
+    cache = DuoAttentionStaticKVCache(model, heads_from_counts(counts, Hkv), 1, max_size, sink, recent)
+    mk = lambda S, h: _rand((1, S, h, D), g).to(DEV)
+    for li in range(L):
+        duo_static_attention_core(mk(prefill, Hq), mk(prefill, Hkv), mk(prefill, Hkv), cache, li, 0, 1.0, 1e4)
+    # static step inputs (a graph replays the same buffers): per layer q, k, v of the "next token"
+    qs, ks, vs = [mk(1, Hq) for _ in range(L)], [mk(1, Hkv) for _ in range(L)], [mk(1, Hkv) for _ in range(L)]
+    outs = [torch.zeros(1, 1, Hq, D, dtype=torch.bfloat16, device=DEV) for _ in range(L)]
+
+    def step():
+        pos = cache.kv_seq_len
+        for li in range(L):
+            outs[li].copy_(duo_static_attention_core(qs[li], ks[li], vs[li], cache, li, pos, 1.0, 1e4))
+        return outs
+
+    return cache, step, outs
+
+
+def _pool_snapshot(cache):
+    return [t.clone() for lst in (cache.full_key_states_list, cache.full_value_states_list,
+                                   cache.streaming_key_states_list, cache.streaming_value_states_list) for t in lst]
+
+
+@pytest.mark.parametrize("evict", [0, 1])
+def test_graph_replayed_decode_equals_eager(evict):
+    """DecodeStepGraph (device-side lengths, one captured step replayed) == the eager fused decode, bit
+    for bit: outputs of every layer at every step, pools and counters afterwards.  evict=1 is the
+    reference's benchmark protocol, evict=0 real generation (cache grows across replays, also through
+    the streaming pool's fill -> slide transition)."""
+    from duo_attn.graph import DecodeStepGraph
+
+    counts, Hq, Hkv, sink, recent, prefill, steps = [1, 3, 0, 4], 16, 4, 4, 12, 13, 9
+    eager_out = []
+    cache_e, step_e, outs_e = _decode_loop_setup(counts, Hq, Hkv, sink, recent, prefill, 64, seed=21)
+    for _ in range(steps):
+        step_e()
+        if evict:
+            cache_e.evict_last(evict)
+        eager_out.append([o.clone() for o in outs_e])
+    cache_g, step_g, outs_g = _decode_loop_setup(counts, Hq, Hkv, sink, recent, prefill, 64, seed=21)
+    graph = DecodeStepGraph(cache_g, step_g, evict_after=evict)
+    for s in range(steps):
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(outs_g, eager_out[s]):
+            assert torch.equal(a, b), f"step {s}"
+    assert cache_g.kv_seq_len_list == cache_e.kv_seq_len_list
+    assert cache_g.streaming_kv_seq_len_list == cache_e.streaming_kv_seq_len_list
+    dev = cache_g.device_state.cpu()
+    assert dev[:, 0].tolist() == cache_e.kv_seq_len_list and dev[:, 1].tolist() == cache_e.streaming_kv_seq_len_list
+    for a, b in zip(_pool_snapshot(cache_g), _pool_snapshot(cache_e)):
+        assert torch.equal(a, b)
+
+
+def test_device_state_add_clamps():
+    h = _hip()
+    st = torch.tensor([[5, 3, 5, 0], [0, 12, 7, 0], [100, 11, 100, 0]], dtype=torch.int32, device=DEV)
+    h.decode_state_add(st, 1, 1, 1, 12)
+    assert st.cpu().tolist() == [[6, 4, 6, 0], [1, 12, 8, 0], [101, 12, 101, 0]]
+    h.decode_state_add(st, -7, -7, -7, 12)
+    assert st.cpu().tolist() == [[0, 0, 0, 0], [0, 5, 1, 0], [94, 5, 94, 0]]
