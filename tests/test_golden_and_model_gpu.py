@@ -96,6 +96,60 @@ def test_static_path_on_gpu_matches_hf(family):
     assert cache.kv_seq_len == 700
 
 
+def test_graph_captured_generation_matches_eager():
+    """Whole patched HF model, greedy generation: DecodeStepGraph (one captured step, device-side cache
+    lengths, the sampled token fed back inside the graph) produces the same tokens and logits as the eager
+    loop, across the streaming window's fill -> slide transition."""
+    from duo_attn.graph import DecodeStepGraph
+
+    mod = __import__("duo_attn.patch.llama", fromlist=["x"])
+    heads = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    ids = torch.randint(0, 211, (1, 40), generator=torch.Generator().manual_seed(3)).to(DEV)
+    n_new = 12
+
+    def run(use_graph):
+        model = tiny("llama", seed=4)
+        mod.enable_llama_duo_attention_static_kv_cache_eval(model, heads.copy())
+        cache = mod.DuoAttentionStaticKVCache(model, heads, 1, 80, 8, 36)    # window 44: slides from step 5 on
+        toks, logits = [], []
+        with torch.no_grad():
+            out = model(input_ids=ids, past_key_values=cache, use_cache=True)
+            tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+            # one eager decode step first (loads every kernel / GEMM handle before any capture)
+            out = model(input_ids=tok, past_key_values=cache, use_cache=True)
+            toks.append(tok.clone()); logits.append(out.logits.clone())
+            tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+            if use_graph:
+                cur = tok.clone()
+                state = {}
+
+                def step():
+                    o = model(input_ids=cur, past_key_values=cache, use_cache=True)
+                    state["logits"] = o.logits
+                    state["next"] = o.logits[:, -1, :].argmax(-1, keepdim=True)
+                    return o.logits
+
+                graph = DecodeStepGraph(cache, step, evict_after=0)
+                for _ in range(n_new):
+                    toks.append(cur.clone())
+                    graph.replay()
+                    logits.append(state["logits"].clone())
+                    cur.copy_(state["next"])          # feed the sampled token back (static buffer)
+            else:
+                for _ in range(n_new):
+                    toks.append(tok.clone())
+                    out = model(input_ids=tok, past_key_values=cache, use_cache=True)
+                    logits.append(out.logits.clone())
+                    tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+        return torch.cat(toks, 1).cpu(), torch.cat(logits, 1).float().cpu(), cache.kv_seq_len
+
+    t_e, l_e, n_e = run(False)
+    t_g, l_g, n_g = run(True)
+    assert n_e == n_g == 40 + 1 + n_new
+    assert torch.equal(t_e, t_g)
+    assert torch.equal(l_e, l_g)
+
+
 def test_tuple_path_on_gpu_matches_hf_and_truncates():
     from duo_attn.patch import enable_duo_attention_eval
 

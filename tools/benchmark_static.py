@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--decode_steps", type=int, default=100)
     ap.add_argument("--decode_warmup", type=int, default=20)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--graph", action="store_true",
+                    help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
     args = ap.parse_args()
 
     from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
@@ -118,6 +120,18 @@ def main():
             model(input_ids=pred, past_key_values=kv_cache, use_cache=True)
         kv_cache.evict_last(1)
 
+    if args.graph:
+        from duo_attn.graph import DecodeStepGraph
+
+        for _ in range(3):      # eager steps first: every kernel and GEMM handle is loaded before the capture
+            func2()
+
+        def step():
+            with torch.no_grad():
+                return model(input_ids=pred, past_key_values=kv_cache, use_cache=True).logits
+
+        graph = DecodeStepGraph(kv_cache, step, evict_after=1)
+        func2 = graph.replay    # noqa: F811 — same protocol: one token, then evict_last(1), inside the graph
     gen_latency, gen_memory = bench_func(func2, args.decode_steps, args.decode_warmup)
     res = {
         "shape": args.shape, "context_length": args.max_length, "sparsity": float(sparsity),
@@ -125,6 +139,7 @@ def main():
         "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
         "peak_context_memory_MB": ctx_memory, "peak_generation_memory_MB": gen_memory,
         "kv_cache_memory_MB": kv_cache.memory_usage / 1024 / 1024,
+        "decode_mode": "hip graph replay" if args.graph else "eager",
     }
     # same fields as the reference's benchmark_result.txt (benchmark_static.py:108-119)
     print(f"Average generation time: {gen_latency:.4f} ms")
