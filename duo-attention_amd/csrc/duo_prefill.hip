@@ -34,7 +34,7 @@
 
 namespace {
 
-template <bool USE_TR>
+template <bool USE_TR, bool F16>
 __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 for (int bb = 0; bb < 2; ++bb) {
                     typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
                     const bf16x8 kf = *(lds_frag_t *)(uintptr_t)(koff[kk] + SOFF + bb * 8192);
-                    sc[bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfrag[kk], kk == 0 ? zero16 : sc[bb], 0, 0, 0);
+                    sc[bb] = mfma32x32x16<F16>(kf, qfrag[kk], kk == 0 ? zero16 : sc[bb]);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     u32x4 w;
-                    w.x = cvt_pk_bf16(pv[8 * s + 0], pv[8 * s + 1]);
-                    w.y = cvt_pk_bf16(pv[8 * s + 2], pv[8 * s + 3]);
-                    w.z = cvt_pk_bf16(pv[8 * s + 4], pv[8 * s + 5]);
-                    w.w = cvt_pk_bf16(pv[8 * s + 6], pv[8 * s + 7]);
+                    w.x = cvt_pk16<F16>(pv[8 * s + 0], pv[8 * s + 1]);
+                    w.y = cvt_pk16<F16>(pv[8 * s + 2], pv[8 * s + 3]);
+                    w.z = cvt_pk16<F16>(pv[8 * s + 4], pv[8 * s + 5]);
+                    w.w = cvt_pk16<F16>(pv[8 * s + 6], pv[8 * s + 7]);
                     pf[2 * bb + s] = *reinterpret_cast<bf16x8 *>(&w);
                 }
             }
@@ -235,26 +235,26 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(va[2 * db], va[2 * db + 1]), pf[0], o[db], 0, 0, 0);
+                    o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[0], o[db]);
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(va, va_, VO, 2);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(vb[2 * db], vb[2 * db + 1]), pf[1], o[db], 0, 0, 0);
+                    o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[1], o[db]);
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(vb, va_, VO, 3);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(va[2 * db], va[2 * db + 1]), pf[2], o[db], 0, 0, 0);
+                    o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[2], o[db]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_frag(vb[2 * db], vb[2 * db + 1]), pf[3], o[db], 0, 0, 0);
+                    o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[3], o[db]);
                 __builtin_amdgcn_s_setprio(0);
 #else
                 // alternative (-DDUO_PV_BUILTIN): builtin transpose reads scheduled by hipcc — measured
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                         bf16x8 vf;
                         vf[0] = x[0]; vf[1] = x[1]; vf[2] = x[2]; vf[3] = x[3];
                         vf[4] = y[0]; vf[5] = y[1]; vf[6] = y[2]; vf[7] = y[3];
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[step], o[db], 0, 0, 0);
+                        o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
                     }
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                             vf[j] = *reinterpret_cast<const short *>(vst + b0 + j * 32 + lane15 * 2);
                             vf[4 + j] = *reinterpret_cast<const short *>(vst + b0 + 2048 + j * 32 + lane15 * 2);
                         }
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[step], o[db], 0, 0, 0);
+                        o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
                     }
             }
         }
@@ -326,8 +326,8 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             for (int rq = 0; rq < 4; ++rq) {
                 const int d = 32 * db + 8 * rq + 4 * hi;   // rows (r&3)+8*(r>>2)+4*hi, r = 4rq..4rq+3
                 u32x2 w;
-                w.x = cvt_pk_bf16(o[db][4 * rq + 0] * inv, o[db][4 * rq + 1] * inv);
-                w.y = cvt_pk_bf16(o[db][4 * rq + 2] * inv, o[db][4 * rq + 3] * inv);
+                w.x = cvt_pk16<F16>(o[db][4 * rq + 0] * inv, o[db][4 * rq + 1] * inv);
+                w.y = cvt_pk16<F16>(o[db][4 * rq + 2] * inv, o[db][4 * rq + 3] * inv);
                 *reinterpret_cast<u32x2 *>(op + d) = w;
             }
     }
@@ -339,11 +339,12 @@ static uint32_t g_debug_flags = 0;
 extern "C" void duo_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
 extern "C" uint32_t duo_get_debug_flags(void) { return g_debug_flags; }
 
-extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
-                                     void *out, int64_t out_token_stride, int64_t out_head_stride,
-                                     int32_t n_tokens, int32_t group, const duo_head_class *full,
-                                     const duo_head_class *stream_cls, float scale, int32_t head_dim,
-                                     void *stream) {
+template <bool F16>
+static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                        void *out, int64_t out_token_stride, int64_t out_head_stride,
+                        int32_t n_tokens, int32_t group, const duo_head_class *full,
+                        const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                        void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (q == nullptr || out == nullptr || group <= 0 || n_tokens < 0) return DUO_EINVAL;
     if (n_tokens == 0) return 0;
@@ -381,15 +382,35 @@ extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int6
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
     // (hipFuncSetAttribute is cheap but not free: once per kernel instantiation)
-    static bool attr_done[2] = {false, false};
+    static bool attr_done[2] = {false, false};   // per instantiation of this template (per element type)
     if (!attr_done[tr]) {
-        const void *fn = tr ? (const void *)duo_prefill_kernel<true> : (const void *)duo_prefill_kernel<false>;
+        const void *fn = tr ? (const void *)duo_prefill_kernel<true, F16> : (const void *)duo_prefill_kernel<false, F16>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done[tr] = true;
     }
-    if (tr) hipLaunchKernelGGL(duo_prefill_kernel<true>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
-    else hipLaunchKernelGGL(duo_prefill_kernel<false>, dim3(nblk), dim3(512), LDS_BYTES, st, P);
+    if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
+    else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                     void *out, int64_t out_token_stride, int64_t out_head_stride,
+                                     int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                     const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                     void *stream) {
+    return prefill_impl<false>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                               group, full, stream_cls, scale, head_dim, stream);
+}
+
+// fp16 twin (q, K, V, out all fp16): the attention of the INT4 path's chunked prefill over dequantised pools
+// (demo/w8a8kv4_llama.py:226-274) and of fp16 models.
+extern "C" int duo_attn_prefill_f16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                    void *out, int64_t out_token_stride, int64_t out_head_stride,
+                                    int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                    const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                    void *stream) {
+    return prefill_impl<true>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                              group, full, stream_cls, scale, head_dim, stream);
 }

@@ -41,6 +41,29 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return *reinterpret_cast<uint32_t *>(&r);
 }
 
+// 16-bit element type of the kernel: bf16 (the static dual-cache path) or fp16 (dequantised INT4 pools,
+// fp16 models).  Same data movement and layouts; only the MFMA opcode and the float -> 16-bit pack differ.
+typedef _Float16 f16x8_mfma __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_cvt __attribute__((ext_vector_type(2)));
+template <bool F16>
+__device__ __forceinline__ uint32_t cvt_pk16(float lo, float hi) {
+    if constexpr (F16) {
+        f32x2 v = {lo, hi};
+        f16x2_cvt r = __builtin_convertvector(v, f16x2_cvt);   // v_cvt_pk_f16_f32 (RNE)
+        return *reinterpret_cast<uint32_t *>(&r);
+    } else {
+        return cvt_pk_bf16(lo, hi);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32x32x16(const bf16x8 &a, const bf16x8 &b, const f32x16 &c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8_mfma *>(&a),
+                                                      *reinterpret_cast<const f16x8_mfma *>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
 }

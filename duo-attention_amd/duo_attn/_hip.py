@@ -113,6 +113,11 @@ _SIGNATURES = {
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
          POINTER(HeadClass), c_float, c_int32, c_void_p],
     ),
+    "duo_attn_prefill_f16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
+         POINTER(HeadClass), c_float, c_int32, c_void_p],
+    ),
     "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "duo_int4_quantize": (
         ctypes.c_int,
@@ -169,14 +174,14 @@ def _check(code: int, what: str):
         raise DuoHipError(f"{what} failed: [{code}] {msg}")
 
 
-def _require_gpu_bf16(t: torch.Tensor, name: str):
+def _require_gpu_bf16(t: torch.Tensor, name: str, dtype=torch.bfloat16):
     if not t.is_cuda:
         raise DuoHipError(
             f"{name} is on {t.device}; the DuoAttention hot path only runs on an MI355X (HIP) device — "
             "there is no CPU fallback."
         )
-    if t.dtype != torch.bfloat16:
-        raise DuoHipError(f"{name} must be bfloat16, got {t.dtype}")
+    if t.dtype != dtype:
+        raise DuoHipError(f"{name} must be {dtype}, got {t.dtype}")
     if t.stride(-1) != 1:
         raise DuoHipError(f"{name}: last (head_dim) dimension must be contiguous")
 
@@ -185,7 +190,7 @@ def _stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def make_seg(k: Optional[torch.Tensor], v: Optional[torch.Tensor]) -> KVSeg:
+def make_seg(k: Optional[torch.Tensor], v: Optional[torch.Tensor], dtype=torch.bfloat16) -> KVSeg:
     """k, v: views [T, h, D] (any token/head stride, D contiguous) or None for an empty segment."""
     s = KVSeg()
     if k is None or k.shape[0] == 0 or k.shape[1] == 0:
@@ -195,8 +200,8 @@ def make_seg(k: Optional[torch.Tensor], v: Optional[torch.Tensor]) -> KVSeg:
         s.head_stride = 0
         s.len = 0
         return s
-    _require_gpu_bf16(k, "k segment")
-    _require_gpu_bf16(v, "v segment")
+    _require_gpu_bf16(k, "k segment", dtype)
+    _require_gpu_bf16(v, "v segment", dtype)
     assert k.dim() == 3 and v.shape == k.shape and k.stride() == v.stride() and k.shape[2] == HEAD_DIM
     s.k = k.data_ptr()
     s.v = v.data_ptr()
@@ -371,18 +376,22 @@ def decode_state_add(dev_states: torch.Tensor, d_full: int, d_str: int, d_pos: i
 
 def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
                  stream: Optional[HeadClass], scale: float):
-    """q, out: [S, Hq, D] views.  MFMA flash attention over both head classes."""
+    """q, out: [S, Hq, D] views, bf16 or fp16 (the segments of ``full`` / ``stream`` must have the same
+    element type).  MFMA flash attention over both head classes."""
     lib = load_library()
-    _require_gpu_bf16(q, "q")
-    _require_gpu_bf16(out, "out")
+    if q.dtype not in (torch.bfloat16, torch.float16):
+        raise DuoHipError(f"q must be bfloat16 or float16, got {q.dtype}")
+    _require_gpu_bf16(q, "q", q.dtype)
+    _require_gpu_bf16(out, "out", q.dtype)
     assert q.dim() == 3 and out.shape == q.shape
+    fn = lib.duo_attn_prefill_f16 if q.dtype == torch.float16 else lib.duo_attn_prefill_bf16
     _check(
-        lib.duo_attn_prefill_bf16(
+        fn(
             q.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(), out.stride(0), out.stride(1), q.shape[0],
             int(group), byref(full) if full is not None else None,
             byref(stream) if stream is not None else None, float(scale), q.shape[2], _stream_ptr(),
         ),
-        "duo_attn_prefill_bf16",
+        "duo_attn_prefill_f16" if q.dtype == torch.float16 else "duo_attn_prefill_bf16",
     )
 
 

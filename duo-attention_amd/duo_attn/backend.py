@@ -45,17 +45,20 @@ class HipBackend:
     def stream_compress(self, k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recent: int) -> int:
         return self._hip.stream_compress(k_pool, v_pool, k_new, v_new, cur_len, sink, recent)
 
-    def _cls(self, desc: ClassDesc):
+    def _cls(self, desc: ClassDesc, dtype=torch.bfloat16):
         if desc is None or desc[0] <= 0:
             return None
         n_kv, q_off, a, b = desc
         h = self._hip
-        return h.make_class(n_kv, q_off, h.make_seg(*(a or (None, None))), h.make_seg(*(b or (None, None))))
+        return h.make_class(n_kv, q_off, h.make_seg(*(a or (None, None)), dtype=dtype),
+                            h.make_seg(*(b or (None, None)), dtype=dtype))
 
     # -- the flash_attn_func calls of reference llama.py:364-421
     def attention(self, q, out, group: int, full: ClassDesc, stream: ClassDesc, scale: float):
-        fc, sc = self._cls(full), self._cls(stream)
+        fc, sc = self._cls(full, q.dtype), self._cls(stream, q.dtype)
         if q.shape[0] == 1:
+            if q.dtype != torch.bfloat16:
+                raise NotImplementedError("single-token attention is bf16 (static pools) or INT4 (attn_decode_int4)")
             self._hip.attn_decode(q[0], out[0], group, fc, sc, scale)
         else:
             self._hip.attn_prefill(q, out, group, fc, sc, scale)

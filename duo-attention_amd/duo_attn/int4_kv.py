@@ -163,6 +163,37 @@ class DuoAttentionStaticINT4KVCache:
                 total += c.quantized_data.numel() + 2 * c.scale_zero.numel()
         return total
 
+    # ---------------------------------------------------------------- chunked-prefill attention
+    def prefill_attention(self, layer_idx, query_states, key_states, value_states, scale=None):
+        """The attention of reference demo/w8a8kv4_llama.py:226-274 for q_len > 1, called AFTER ``put()``:
+        * first chunk (the cache held nothing before this put): every head causal over the chunk's own,
+          un-quantised K/V (:226-234);
+        * later chunks: retrieval heads over the dequantised full pool, streaming heads over the
+          dequantised streaming pool (both already contain the chunk's quantised rows), bottom-right
+          causal (:236-274).
+        query_states [B, S, Hq, 128], key/value_states [B, S, Hkv, 128], fp16, after RoPE.  The pools are
+        dequantised into this object's fp16 scratch (as the reference's ``get`` does) and read by the fp16
+        MFMA kernel; ``compress()`` is the caller's next step, as in the reference."""
+        from .backend import get_backend
+
+        be = get_backend()
+        B, S = query_states.shape[0], query_states.shape[1]
+        nf, ns = self.num_full_kv_head_list[layer_idx], self.num_streaming_kv_head_list[layer_idx]
+        n, m = self.kv_seq_len_list[layer_idx], self.streaming_kv_seq_len_list[layer_idx]
+        G = self.num_kv_groups
+        scale = self.head_dim ** -0.5 if scale is None else scale
+        out = torch.empty_like(query_states)
+        if n == S:      # first chunk
+            for b in range(B):
+                be.attention(query_states[b], out[b], G, (nf + ns, 0, None, (key_states[b], value_states[b])), None, scale)
+            return out
+        fk, fv, sk, sv = self.get(layer_idx)
+        for b in range(B):
+            full = (nf, 0, (fk[b, :n - S], fv[b, :n - S]), (fk[b, n - S:n], fv[b, n - S:n])) if nf else None
+            stream = (ns, nf * G, (sk[b, :m - S], sv[b, :m - S]), (sk[b, m - S:m], sv[b, m - S:m])) if ns else None
+            be.attention(query_states[b], out[b], G, full, stream, scale)
+        return out
+
     # ---------------------------------------------------------------- fused decode attention
     def decode_attention(self, layer_idx, query_states, scale=None):
         """query_states [B, 1, Hq, 128] fp16 (after RoPE, after put()): attention of the decode branch

@@ -25,6 +25,7 @@
  *                             all heads causal) and llama.py:392-421 (later
  *                             chunks, one call per head class)
  *   duo_decode_layer_bf16     llama.py:332-425 for q_len == 1 (whole decode step of a layer)
+ *   duo_attn_prefill_f16      flash_attn_func of the INT4 demo's prefill, demo/w8a8kv4_llama.py:226-274
  *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
  *   duo_int4_quantize / duo_int4_dequantize_f16 / duo_int4_stream_compress /
  *   duo_attn_decode_int4_f16  demo/quantize_int4.cu:9-178, demo/int4_kv.py:261-492
@@ -206,6 +207,14 @@ int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t
 /* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
  * q/out: [S, n_q_heads, 128] with the given token/head strides.               */
 int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride,
+                          int64_t q_head_stride, void *out,
+                          int64_t out_token_stride, int64_t out_head_stride,
+                          int32_t n_tokens, int32_t group,
+                          const duo_head_class *full, const duo_head_class *stream_cls,
+                          float scale, int32_t head_dim, void *stream);
+/* fp16 twin (q, K, V, out fp16): the chunked-prefill attention of the INT4 path over dequantised pools
+ * (flash_attn_func at demo/w8a8kv4_llama.py:226-274) and of fp16 models.  Same layouts and semantics. */
+int duo_attn_prefill_f16(const void *q, int64_t q_token_stride,
                           int64_t q_head_stride, void *out,
                           int64_t out_token_stride, int64_t out_head_stride,
                           int32_t n_tokens, int32_t group,

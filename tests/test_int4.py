@@ -236,3 +236,83 @@ def test_int4_cache_put_compress_decode_flow():
             else:
                 ref_str[l] = [a[:0] for a in ref_str[l]]
     assert cache.memory_usage == sum(2 * 68 * (nf * 700 + (Hkv - nf) * (W + chunk)) for nf in counts)
+
+
+@gpu
+@pytest.mark.parametrize("S,group,nf,ns,la,ls", [(2, 4, 1, 1, 3, 2), (100, 4, 1, 3, 1000, 384), (257, 4, 2, 0, 300, 0),
+                                                  (300, 4, 0, 2, 0, 384), (513, 1, 2, 2, 77, 10), (700, 8, 1, 0, 129, 0)])
+def test_fp16_prefill_kernel(S, group, nf, ns, la, ls):
+    """duo_attn_prefill_f16 (the MFMA prefill kernel instantiated for fp16) against the oracle, both head
+    classes, pool + chunk as two segments."""
+    from duo_attn.backend import HipBackend
+    from helpers import attn_close
+    from oracle.duo_oracle import flash_attn_func_ref
+
+    g = torch.Generator().manual_seed(S + la)
+    Hq = (nf + ns) * group
+    r = lambda *shape: torch.randn(*shape, generator=g).to(torch.float16)
+    q, kn, vn = r(S, Hq, 128), r(S, nf + ns, 128), r(S, nf + ns, 128)
+    out = torch.full((S, Hq, 128), float("nan"), dtype=torch.float16, device=DEV)
+    ref, bud = torch.empty(S, Hq, 128), torch.empty(S, Hq, 128)
+    kw = dict(round_p=False, out_dtype=torch.float32, return_budget=True)
+    full = stream = None
+    knd, vnd = kn.to(DEV), vn.to(DEV)
+    if nf:
+        fk, fv = r(la, nf, 128), r(la, nf, 128)
+        full = (nf, 0, (fk.to(DEV), fv.to(DEV)) if la else None, (knd[:, :nf], vnd[:, :nf]))
+        o, b = flash_attn_func_ref(q[None, :, :nf * group], torch.cat([fk, kn[:, :nf]])[None], torch.cat([fv, vn[:, :nf]])[None], **kw)
+        ref[:, :nf * group], bud[:, :nf * group] = o[0], b[0]
+    if ns:
+        sk, sv = r(ls, ns, 128), r(ls, ns, 128)
+        stream = (ns, nf * group, (sk.to(DEV), sv.to(DEV)) if ls else None, (knd[:, nf:], vnd[:, nf:]))
+        o, b = flash_attn_func_ref(q[None, :, nf * group:], torch.cat([sk, kn[:, nf:]])[None], torch.cat([sv, vn[:, nf:]])[None], **kw)
+        ref[:, nf * group:], bud[:, nf * group:] = o[0], b[0]
+    HipBackend().attention(q.to(DEV), out, group, full, stream, 128 ** -0.5)
+    attn_close(out, ref, f"fp16 prefill S={S}", bud)
+
+
+@gpu
+def test_int4_cache_chunked_prefill_attention():
+    """DuoAttentionStaticINT4KVCache.prefill_attention: first chunk over the raw chunk, later chunks over the
+    dequantised pools (incl. the chunk's own quantised rows), against the oracle on oracle-dequantised data
+    (reference demo/w8a8kv4_llama.py:219-278)."""
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+    from helpers import attn_close
+    from oracle.duo_oracle import flash_attn_func_ref
+
+    counts, Hq, Hkv, sink, recent, chunk = [1, 3, 0, 4], 16, 4, 16, 48, 300
+    G = Hq // Hkv
+    model = ShapeModel(len(counts), Hq, Hkv, 128, device=DEV, dtype=torch.float16)
+    cache = DuoAttentionStaticINT4KVCache(model, heads_from_counts(counts, Hkv), 1, 900, sink, recent, chunk)
+    g = torch.Generator().manual_seed(5)
+    W = sink + recent
+    dq = lambda x: torch.from_numpy(dequantize_int4_ref(*quantize_int4_ref(x.float().numpy())).astype(np.float32))
+    hist = [dict(fk=torch.zeros(0, nf, 128), fv=torch.zeros(0, nf, 128), sk=torch.zeros(0, Hkv - nf, 128),
+                 sv=torch.zeros(0, Hkv - nf, 128)) for nf in counts]
+    kw = dict(round_p=False, out_dtype=torch.float32, return_budget=True)
+    for ci, S in enumerate((300, 257, 64)):
+        for l, nf in enumerate(counts):
+            q = torch.randn(1, S, Hq, 128, generator=g).to(torch.float16)
+            k = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16)
+            v = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16)
+            cache.put(l, k.to(DEV), v.to(DEV), dequantize=False)
+            out = cache.prefill_attention(l, q.to(DEV), k.to(DEV), v.to(DEV))
+            h = hist[l]
+            h["fk"], h["fv"] = torch.cat([h["fk"], dq(k[0, :, :nf])]), torch.cat([h["fv"], dq(v[0, :, :nf])])
+            h["sk"], h["sv"] = torch.cat([h["sk"], dq(k[0, :, nf:])]), torch.cat([h["sv"], dq(v[0, :, nf:])])
+            ref, bud = torch.empty(S, Hq, 128), torch.empty(S, Hq, 128)
+            if ci == 0:
+                o, b = flash_attn_func_ref(q, k, v, **kw)
+                ref, bud = o[0], b[0]
+            else:
+                if nf:
+                    o, b = flash_attn_func_ref(q[:, :, :nf * G], h["fk"][None], h["fv"][None], **kw)
+                    ref[:, :nf * G], bud[:, :nf * G] = o[0], b[0]
+                if Hkv - nf:
+                    o, b = flash_attn_func_ref(q[:, :, nf * G:], h["sk"][None], h["sv"][None], **kw)
+                    ref[:, nf * G:], bud[:, nf * G:] = o[0], b[0]
+            attn_close(out[0], ref, f"int4 chunk {ci} layer {l}", bud)
+            cache.compress(l)
+            if h["sk"].shape[0] > W:        # the reference keeps sink + recent rows of the streaming pool
+                h["sk"] = torch.cat([h["sk"][:sink], h["sk"][-recent:]])
+                h["sv"] = torch.cat([h["sv"][:sink], h["sv"][-recent:]])
