@@ -72,8 +72,14 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 
     const int lenA = C.a.len;
     const int nA = (lenA + KVBLK - 1) / KVBLK;
+    // segment B may be longer than the query block: the S queries are its LAST S rows (bottom-right
+    // causal alignment, as flash_attn_func with seqlen_q < seqlen_k) — query i sees B keys 0 .. i + qoff.
+    // qoff > 0 is how a chunk is processed in row blocks (layer-pipeline wavefront): queries [r0, r1) of
+    // the chunk against chunk rows [0, r1).
+    const int lenB = C.b.len;
+    const int qoff = lenB - S;
     const int last_q = min(q0 + QBLK - 1, S - 1);
-    const int nB = last_q / KVBLK + 1;
+    const int nB = (last_q + qoff) / KVBLK + 1;
     const int nT = nA + nB;
 
     f32x16 o[4];
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     const DmaLane dmaB = dma_lane(tid, C.b.token_stride);
 
     auto issue_dma = [&](int t, int slot_) {
-        const TileSrc ts_ = tile_src(C, kvh, t, nA, S);
+        const TileSrc ts_ = tile_src(C, kvh, t, nA, lenB);
         const uint32_t dst = smem_lds + slot_ * STAGE_BYTES;
         if (ts_.cnt == KVBLK) stage_dma_full<8>(ts_, t < nA ? dmaA : dmaB, dst, tid);
         else stage_dma_tail<8>(ts_, dst, tid);
@@ -133,9 +139,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #endif
         const bool inB = t >= nA;
         const int key0 = inB ? (t - nA) * KVBLK : t * KVBLK;   // first key of the tile in its segment
-        const int cnt = inB ? min(KVBLK, S - key0) : min(KVBLK, lenA - key0);
+        const int cnt = inB ? min(KVBLK, lenB - key0) : min(KVBLK, lenA - key0);
         // a causal tile that starts after this wave's last row contributes nothing
-        const bool skip = inB && key0 > wq0 + 31;
+        const bool skip = inB && key0 > wq0 + qoff + 31;
 
         if (!skip) {
             // ---- S^T = K . Q^T  (two 32-key blocks) ---------------------------
@@ -154,9 +160,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             }
             __builtin_amdgcn_s_setprio(0);
             // ---- mask ----------------------------------------------------------
-            const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0) : (cnt < KVBLK);
+            const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0 + qoff) : (cnt < KVBLK);
             if (need_mask) {
-                const int lim = inB ? min(my_q - key0, cnt - 1) : cnt - 1;   // last visible key (tile-local)
+                const int lim = inB ? min(my_q + qoff - key0, cnt - 1) : cnt - 1;   // last visible key (tile-local)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
@@ -366,7 +372,7 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     for (int c = 0; c < 2; ++c) {
         DuoClassDev &C = P.cls[c];
         if (C.n_kv_heads <= 0) { C.n_kv_heads = 0; continue; }
-        if (C.b.len != n_tokens || !C.b.k || !C.b.v) return DUO_EINVAL;   // segB is the chunk itself
+        if (C.b.len < n_tokens || !C.b.k || !C.b.v) return DUO_EINVAL;   // segB ends with the query rows
         if (C.a.len < 0 || (C.a.len > 0 && (!C.a.k || !C.a.v))) return DUO_EINVAL;
         if ((C.a.token_stride | C.a.head_stride | C.b.token_stride | C.b.head_stride) & 7) {
             // rows must be 16-byte aligned for the dwordx4 tile loads

@@ -205,7 +205,10 @@ int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t
                          int32_t d_pos, int32_t str_cap, void *stream);
 
 /* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
- * q/out: [S, n_q_heads, 128] with the given token/head strides.               */
+ * q/out: [S, n_q_heads, 128] with the given token/head strides.  Per head class: segA rows are all
+ * visible; segB (len >= S) ends with the S query rows — query i sees segB rows 0 .. i + (len - S)
+ * (bottom-right causal alignment, as flash_attn_func with seqlen_q < seqlen_k).  len == S is the
+ * chunked-prefill call of llama.py:366-421; len > S processes a chunk in row blocks.          */
 int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride,
                           int64_t q_head_stride, void *out,
                           int64_t out_token_stride, int64_t out_head_stride,

@@ -286,6 +286,24 @@ def test_prefill_first_chunk(S, group, nkv):
     attn_close(out, ref, f"first chunk S={S}", bud)
 
 
+@pytest.mark.parametrize("S,lenA,lenB,group", [(300, 100, 500, 4), (256, 0, 1024, 4), (77, 384, 78, 1), (512, 1000, 513, 2)])
+def test_prefill_query_block_shorter_than_segment_b(S, lenA, lenB, group):
+    """segment B longer than the query block: the S queries are its last S rows (bottom-right alignment,
+    flash_attn_func with seqlen_q < seqlen_k) — a chunk processed in row blocks."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(S + lenB)
+    q = _rand((S, group, D), g)
+    ka, va = _rand((lenA, 1, D), g), _rand((lenA, 1, D), g)
+    kb, vb = _rand((lenB, 1, D), g), _rand((lenB, 1, D), g)
+    out = torch.full((S, group, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    segA = (ka.to(DEV), va.to(DEV)) if lenA else None
+    HipBackend().attention(q.to(DEV), out, group, (1, 0, segA, (kb.to(DEV), vb.to(DEV))), None, D ** -0.5)
+    ref, bud = flash_attn_func_ref(q[None], torch.cat([ka, kb])[None], torch.cat([va, vb])[None], round_p=False,
+                                   out_dtype=torch.float32, return_budget=True)
+    attn_close(out, ref[0], f"row block S={S} lenB={lenB}", bud[0])
+
+
 def test_prefill_without_transpose_read_matches():
     """ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
     h = _hip()
