@@ -1004,15 +1004,14 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     hipStream_t st = (hipStream_t)stream;
     if (mfma) {
         static const int mode = [] {
-            const char *e = getenv("DUO_INT4_DECODE_MODE");    // 0 exact 3-op, 1 voted fma (default), 2 fma always (unsafe)
+            const char *e = getenv("DUO_INT4_DECODE_MODE");    // 0: always the 3-instruction form; 1: voted fma form (default)
             const int x = e ? atoi(e) : 1;
-            return (x >= 0 && x <= 2) ? x : 1;
+            return x == 0 ? 0 : 1;
         }();
         dim3 grid(nblk), block(256);
 #define DUO_I4_LAUNCH(W_)                                                                                   \
     do {                                                                                                    \
         if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 0>), grid, block, 0, st, P);     \
-        else if (mode == 2) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 2>), grid, block, 0, st, P); \
         else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 1>), grid, block, 0, st, P);               \
     } while (0)
         if (occ == 2) DUO_I4_LAUNCH(2);
