@@ -50,7 +50,9 @@ class DuoAttentionStaticINT4KVCache:
         self.num_heads = cfg.num_attention_heads
         self.num_kv_heads = cfg.num_key_value_heads
         self.num_kv_groups = self.num_heads // self.num_kv_heads
-        self.head_dim = cfg.hidden_size // self.num_heads
+        # (an explicit config.head_dim wins over hidden_size // num_heads — they differ in some checkpoints
+        # and in a tensor-parallel shard, where the head count is per rank)
+        self.head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // self.num_heads
         self.group_size = GROUP_SIZE
         self.num_full_kv_head_list, self.num_streaming_kv_head_list = [], []
         self.streaming_key_caches, self.streaming_value_caches = [], []

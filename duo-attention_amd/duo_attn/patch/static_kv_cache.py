@@ -42,7 +42,9 @@ class DuoAttentionStaticKVCache:
         self.num_heads = model.config.num_attention_heads
         self.num_kv_heads = model.config.num_key_value_heads
         self.num_kv_groups = self.num_heads // self.num_kv_heads
-        self.head_dim = model.config.hidden_size // self.num_heads
+        # (an explicit config.head_dim wins over hidden_size // num_heads — they differ in some checkpoints
+        # and in a tensor-parallel shard, where the head count is per rank)
+        self.head_dim = getattr(model.config, "head_dim", None) or model.config.hidden_size // self.num_heads
 
         self.num_full_kv_head_list = [0] * self.num_layers
         self.num_streaming_kv_head_list = [0] * self.num_layers

@@ -4,7 +4,7 @@ In scope: ``parse_args`` (same flag names so scripts/efficiency.
 style invocations keep working), ``get_model``, ``get_tokenizer``, ``to_device``
 (single device and the layer-pipeline branch), ``load_attn_pattern``,
 ``sparsify_attention_heads``, ``seed_everything``, ``save_full_attention_heads``.
-The third-party ``tensor_parallel`` branch of ``to_device`` is out of scope.
+The third-party ``tensor_parallel`` branch of ``to_device`` is replaced by ``duo_attn.tp`` (one process per GPU).
 """
 import argparse
 import json
@@ -151,8 +151,10 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
             return model.to(f"cuda:{device[0]}")
         if enable_tp:
             raise NotImplementedError(
-                "Head-parallel tensor parallelism lives in the third-party `tensor_parallel` package in "
-                "the reference (utils.py:206-227) and is outside this repo's hot-path scope."
+                "The reference shards an already patched model with the third-party `tensor_parallel` package "
+                "(utils.py:206-227).  Here tensor parallelism is one process per GPU: call "
+                "duo_attn.tp.shard_model_for_tp(model, full_attention_heads) on every rank BEFORE "
+                "enable_*_duo_attention*_eval, and pass the pattern it returns to the enabler and the KV cache."
             )
         if enable_pp:
             import torch.distributed as dist

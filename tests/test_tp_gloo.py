@@ -1,0 +1,123 @@
+"""Head-parallel tensor parallelism (duo_attn/tp.py) on CPU: world size 2, gloo, oracle as device backend.
+The sharded model (balanced retrieval-head assignment, column/row-sliced projections, two all-reduces per
+layer) must reproduce the single-process patched model: chunked prefill + decode through the static cache."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, "duo-attention_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _tiny():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=3, num_attention_heads=8,
+                      num_key_value_heads=4, head_dim=128, vocab_size=97, max_position_embeddings=2048,
+                      rope_theta=10000.0, attn_implementation="eager", tie_word_embeddings=False)
+    return LlamaForCausalLM(cfg).float().eval()
+
+
+HEADS = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 1.0, 0.0, 1.0]])
+CHUNKS = [23, 17, 1, 1]
+
+
+def _run(model, heads, max_size=64):
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+
+    enable_llama_duo_attention_static_kv_cache_eval(model, heads.copy())
+    cache = DuoAttentionStaticKVCache(model, heads, 1, max_size, 4, 8)
+    ids = torch.randint(0, 97, (1, sum(CHUNKS)), generator=torch.Generator().manual_seed(1))
+    outs, pos = [], 0
+    with torch.no_grad():
+        for c in CHUNKS:
+            outs.append(model(input_ids=ids[:, pos:pos + c], past_key_values=cache, use_cache=True).logits)
+            pos += c
+    return torch.cat(outs, 1)
+
+
+def _worker(rank, world, port, q):
+    _paths()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from duo_attn import backend
+        from duo_attn.tp import shard_model_for_tp
+        from oracle.duo_oracle import OracleBackend
+
+        backend._set_backend_for_testing(OracleBackend(round_p=False))
+        model = _tiny()
+        local = shard_model_for_tp(model, HEADS)
+        assert local.shape == (3, 2) and (np.diff(local, axis=1) <= 0).all()     # retrieval heads first
+        out = _run(model, local)
+        if rank == 0:
+            q.put(out.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tp2_equals_single_process():
+    _paths()
+    from duo_attn import backend
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend(round_p=False))
+    try:
+        want = _run(_tiny(), HEADS).numpy()
+    finally:
+        backend._set_backend_for_testing(None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # fp32 model; the two-way sums of the all-reduces change the rounding order only
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4), np.abs(got - want).max()
+
+
+def test_balanced_head_assignment():
+    _paths()
+    from duo_attn.tp import balanced_head_assignment
+
+    counts = [1, 1, 2, 2, 2, 4, 2, 4, 6, 4, 5, 3, 2, 6, 5, 5, 5, 6, 3, 5, 6, 3, 3, 6, 4, 5, 3, 4, 6, 5, 8, 2]
+    rng = np.random.RandomState(0)
+    heads = np.zeros((32, 8))
+    for l, c in enumerate(counts):
+        heads[l, rng.permutation(8)[:c]] = 1.0
+    for tp in (2, 4, 8):
+        a = balanced_head_assignment(heads, tp)
+        tot = [0] * tp
+        for l in range(32):
+            assert sorted(h for r in a[l] for h in r) == list(range(8))          # a partition of the layer's heads
+            nr = [sum(heads[l, h] > 0.5 for h in a[l][r]) for r in range(tp)]
+            assert max(nr) - min(nr) <= 1                                          # even within the layer
+            for r in range(tp):
+                assert len(a[l][r]) == 8 // tp
+                k = [heads[l, h] for h in a[l][r]]
+                assert k == sorted(k, reverse=True)                                # retrieval heads first
+                tot[r] += nr[r]
+        assert max(tot) - min(tot) <= 1, tot                                       # and across the whole model
+        # the reference's contiguous split for comparison: rank r takes heads [r*per, (r+1)*per)
+        per = 8 // tp
+        ref = [sum(heads[l, r * per:(r + 1) * per].sum() for l in range(32)) for r in range(tp)]
+        assert max(tot) <= max(ref)
+    with pytest.raises(ValueError):
+        balanced_head_assignment(heads, 3)
