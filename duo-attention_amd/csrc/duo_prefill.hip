@@ -148,7 +148,40 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             f32x16 sc[2];
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_s_setprio(1);
-            // kk outer, key block inner: consecutive MFMAs alternate between the two accumulators
+            // kk outer, key block inner: consecutive MFMAs alternate between the two accumulators.
+            // The K fragments of k-step kk+1 are requested BEFORE the MFMAs of k-step kk (two register
+            // sets); left to hipcc, each step's two ds_read_b128 are issued into the same registers only after
+            // the previous step's MFMAs, so every step pays the LDS latency.  asm reads + counted lgkmcnt, as
+            // for the V^T reads below.
+#ifndef DUO_K_BUILTIN
+            {
+                constexpr int KO = SOFF >= 32768 ? 0 : SOFF;          // 16-bit ds offset field
+                u32x4 kf[2][2];
+#define DUO_K_READ(dst, kk_, bb_)                                                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(koff[kk_] + (SOFF >= 32768 ? SOFF : 0)),  \
+                 "n"(KO + (bb_) * 8192) : "memory")
+                __builtin_amdgcn_sched_barrier(0);
+                DUO_K_READ(kf[0][0], 0, 0);
+                DUO_K_READ(kf[0][1], 0, 1);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    if (kk < 7) {
+                        DUO_K_READ(kf[(kk + 1) & 1][0], kk + 1, 0);
+                        DUO_K_READ(kf[(kk + 1) & 1][1], kk + 1, 1);
+                        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb)
+                        sc[bb] = mfma32x32x16<F16>(*reinterpret_cast<const bf16x8 *>(&kf[kk & 1][bb]), qfrag[kk],
+                                                   kk == 0 ? zero16 : sc[bb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef DUO_K_READ
+            }
+#else
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
@@ -158,6 +191,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     sc[bb] = mfma32x32x16<F16>(kf, qfrag[kk], kk == 0 ? zero16 : sc[bb]);
                 }
             }
+#endif
             __builtin_amdgcn_s_setprio(0);
             // ---- mask ----------------------------------------------------------
             const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0 + qoff) : (cnt < KVBLK);
@@ -180,7 +214,14 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 t1 = fmaxf(fmaxf(t1, sc[1][r]), sc[1][r + 1]);
             }
             float tmax = fmaxf(fmaxf(t0, t1), fmaxf(sc[0][15], sc[1][15]));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            // row max over both 32-key halves: lanes l and l^32 hold the two halves of a query row.
+            // v_permlane32_swap exchanges the upper half of one register with the lower half of another in the
+            // VALU — no trip through the LDS crossbar (ds_bpermute) on the per-tile critical path
+            {
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                const u32x2_t sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+                tmax = fmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
+            }
             // Deferred rescale: while no row of the wave grows its max by more than 2^kDeferLog2 the
             // old reference point is kept (P <= 2^kDeferLog2, exact in fp32/bf16 ranges) and the
             // 64-register O rescale is skipped.  First tile: mrow = -inf forces the rescale path.

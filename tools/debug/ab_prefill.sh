@@ -1,0 +1,8 @@
+#!/bin/bash
+# same-box A/B of prefill kernel builds: libs under duo-attention_amd/lib/ab/lib_<tag>.so
+for rep in 1 2; do
+  for v in "$@"; do
+    echo -n "$v  "
+    DUO_ATTN_HIP_LIB=$PWD/duo-attention_amd/lib/ab/lib_$v.so python tools/bench_kernels.py prefill --nf 4 --past 65536 --chunk 16384 --reps 4 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.3f ms  %.0f TF/s (best %.0f)' % (d['avg_ms'], d['tflops_avg'], d['tflops_best']))"
+  done
+done
