@@ -233,12 +233,20 @@ def duo_attention_forward_one_way_reordered(
                       (streaming_key_states[b], streaming_value_states[b])) if ns > 0 else None
             be.attention(query_states[b], attn_output[b], groups, full, stream, scale)
 
-    # the tuple format's contract: the returned cache holds past ++ new (:202-223)
-    if past_full_KV is not None:
-        full_key_states = torch.cat([past_full_KV[:bsz], full_key_states], dim=1)
-        full_value_states = torch.cat([past_full_KV[bsz:], full_value_states], dim=1)
+    # the tuple format's contract: the returned cache holds past ++ new (:202-223).  The streaming part is
+    # at most sink+recent+q_len rows: concatenated as in the reference.  The retrieval part is the whole
+    # context — re-concatenating it costs O(N) reads and writes per generated token (twice: K/V cat, then the
+    # K-on-V stack), several times the attention's own traffic at 128K.  Here it lives in a growing arena
+    # owned by the module and the tuple element handed back is a VIEW of it: linear generation appends q_len
+    # rows in place.  A past that is not the arena's current view (first call, a re-used older tuple, a
+    # foreign tensor) is copied into a fresh arena, so branching callers stay correct.
+    if past_streaming_KV is not None:
         streaming_key_states = torch.cat([past_streaming_KV[:bsz], streaming_key_states], dim=1)
         streaming_value_states = torch.cat([past_streaming_KV[bsz:], streaming_value_states], dim=1)
+    full_kv_out = None
+    if use_cache:
+        full_kv_out = _tuple_full_kv_append(self, past_key_value[0] if past_key_value is not None else None,
+                                            full_key_states, full_value_states)
 
     attn_output = attn_output.reshape(bsz, q_len, num_heads * head_dim)
     attn_output = self.o_proj(attn_output)
@@ -255,13 +263,40 @@ def duo_attention_forward_one_way_reordered(
 
     past_key_value = (
         (
-            torch.cat([full_key_states, full_value_states], dim=0).transpose(1, 2),
+            full_kv_out,
             torch.cat([streaming_key_states, streaming_value_states], dim=0).transpose(1, 2),
         )
         if use_cache
         else None
     )
     return attn_output, None, past_key_value
+
+
+def _tuple_full_kv_append(module, past_full, new_k, new_v):
+    """Retrieval-head cache of the tuple format, ``[2B, nf, N, D]`` (K stacked on V, head-major,
+    reference llama.py:168-171,292-301), grown in place.  ``past_full``: the tuple element of the previous
+    call or None; ``new_k/new_v``: ``[B, q, nf, D]``.  Returns the ``[2B, nf, N+q, D]`` view."""
+    bsz, q, nf, D = new_k.shape
+    N = 0 if past_full is None else past_full.shape[2]
+    arena = getattr(module, "_duo_full_kv_arena", None)
+    fits = (
+        arena is not None and past_full is not None and arena["len"] == N
+        and past_full.data_ptr() == arena["buf"].data_ptr() and past_full.shape[:2] == arena["buf"].shape[:2]
+        and past_full.stride() == arena["buf"].stride() and N + q <= arena["buf"].shape[2]
+        and past_full.dtype == new_k.dtype
+    )
+    if not fits:
+        cap = N + q + max(1024, (N + q) // 2)       # 1.5x growth: amortised O(1) copies per appended row
+        buf = torch.empty(2 * bsz, nf, cap, D, device=new_k.device, dtype=new_k.dtype)
+        if N > 0:
+            buf[:, :, :N].copy_(past_full)
+        arena = {"buf": buf, "len": N}
+        module._duo_full_kv_arena = arena
+    buf = arena["buf"]
+    buf[:bsz, :, N:N + q].copy_(new_k.transpose(1, 2))
+    buf[bsz:, :, N:N + q].copy_(new_v.transpose(1, 2))
+    arena["len"] = N + q
+    return buf[:, :, :N + q]
 
 
 # =============================================================================

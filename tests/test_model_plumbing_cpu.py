@@ -89,6 +89,36 @@ def test_reordering_is_invisible_when_window_covers_context(family, exact_backen
     assert past[0][0].shape == (2, 1, 40, 128) and past[0][1].shape == (2, 1, 40, 128)
 
 
+def test_tuple_cache_grows_in_place_and_survives_branching(exact_backend):
+    """The retrieval part of the tuple cache is a view of a growing arena: linear generation appends in
+    place (no O(N) re-concatenation per token), and a caller that goes back to an OLDER tuple and continues
+    differently still gets the right answer (the stale view is copied into a fresh arena)."""
+    from duo_attn.patch import enable_duo_attention_eval
+
+    ref = tiny("llama", seed=6)
+    model = copy.deepcopy(ref)
+    enable_duo_attention_eval(model, np.ones((2, 2)), 4, 8)
+    ids = torch.randint(0, 97, (1, 30), generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        out = model(input_ids=ids[:, :20], use_cache=True)
+        past20 = out.past_key_values
+        base_ptr = past20[0][0].data_ptr()
+        o21 = model(input_ids=ids[:, 20:21], past_key_values=past20, use_cache=True)
+        o22 = model(input_ids=ids[:, 21:22], past_key_values=o21.past_key_values, use_cache=True)
+        # in place: same storage, longer view; the older tuples are still intact views
+        assert o22.past_key_values[0][0].data_ptr() == base_ptr and o22.past_key_values[0][0].shape[2] == 22
+        assert past20[0][0].shape[2] == 20 and o21.past_key_values[0][0].shape[2] == 21
+        torch.testing.assert_close(o22.logits, hf_last_logits(ref, ids[:, :22]), rtol=2e-4, atol=2e-4)
+        # branch: continue from the 20-token cache with a DIFFERENT token
+        alt = (ids[:, 20:21] + 1) % 97
+        b21 = model(input_ids=alt, past_key_values=past20, use_cache=True)
+        want = hf_last_logits(ref, torch.cat([ids[:, :20], alt], 1))
+        torch.testing.assert_close(b21.logits, want, rtol=2e-4, atol=2e-4)
+        # ... and the first branch can still be continued from its own latest tuple
+        o23 = model(input_ids=ids[:, 22:23], past_key_values=o22.past_key_values, use_cache=True)
+        torch.testing.assert_close(o23.logits, hf_last_logits(ref, ids[:, :23]), rtol=2e-4, atol=2e-4)
+
+
 def test_streaming_heads_truncate_and_change_logits(exact_backend):
     from duo_attn.patch import enable_duo_attention_eval
 
