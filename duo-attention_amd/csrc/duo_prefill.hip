@@ -30,6 +30,8 @@
 //   * causal tiles beyond a wave's last row are skipped per wave; blocks are
 //     ordered heaviest-first, and the q heads that share a kv head are mapped to
 //     the same XCD (block id % 8) so K/V tiles are shared through one L2.
+#include <algorithm>
+#include <cstdlib>
 #include "duo_prefill_common.h"
 
 namespace {
@@ -49,6 +51,11 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
     const DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    // key-range split (retrieval class only): the splits of one (q tile, q head) are adjacent block ids
+    const int ks = ci == 0 ? P.ksplit : 1;
+    const int split = b % ks;
+    const int part_id = b;            // index of this workgroup's partial in the workspace
+    b /= ks;
     const int nq_c = C.n_kv_heads * P.group;
     const int tile = P.n_qtiles - 1 - b / nq_c;   // heaviest (latest) tiles first
     const int p = b % nq_c;
@@ -80,7 +87,10 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     const int qoff = lenB - S;
     const int last_q = min(q0 + QBLK - 1, S - 1);
     const int nB = (last_q + qoff) / KVBLK + 1;
-    const int nT = nA + nB;
+    const int nT_all = nA + nB;
+    // this workgroup's share of the tile sequence (segment A tiles, then the causal tiles of segment B)
+    const int t_begin = (int)((int64_t)split * nT_all / ks);
+    const int nT = (int)((int64_t)(split + 1) * nT_all / ks);   // exclusive end: the loops below run [t_begin, nT)
 
     f32x16 o[4];
 #pragma unroll
@@ -110,9 +120,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 
     // ---- prologue: tiles 0 and 1 in flight, wait for tile 0 only ---------------
     // (the Q loads above are older in the VMEM queue, so either wait also covers them)
-    issue_dma(0, 0);
-    if (nT > 1) {
-        issue_dma(1, 1);
+    if (t_begin < nT) issue_dma(t_begin, 0);
+    if (t_begin + 1 < nT) {
+        issue_dma(t_begin + 1, 1);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,7 +237,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             // 64-register O rescale is skipped.  First tile: mrow = -inf forces the rescale path.
             if (!__all((tmax - mrow) * c <= kDeferLog2)) {
                 const float mnew = fmaxf(mrow, tmax);
-                const float alpha = fast_exp2((mrow - mnew) * c);
+                // (a row that has seen no key yet — possible when a key-range split starts on causal tiles
+                // beyond it — keeps m = -inf; -inf - -inf must not reach exp2)
+                const float alpha = mnew == -INFINITY ? 1.f : fast_exp2((mrow - mnew) * c);
                 lsum *= alpha;
                 mrow = mnew;
 #pragma unroll
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
-            const float mc = mrow * c;
+            const float mc = mrow == -INFINITY ? 0.f : mrow * c;   // all scores -inf: p = exp2(-inf - 0) = 0
             float psum = 0.f;
             bf16x8 pf[4];   // P^T B operands of the four PV k-steps (step = 2*bb + s)
 #pragma unroll
@@ -356,14 +368,31 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    for (int t = 0; t < nT; t += NSTAGE) {
+    for (int t = t_begin; t < nT; t += NSTAGE) {
         tile_body(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nT) tile_body(std::integral_constant<int, 1>{}, t + 1);
         if (t + 2 < nT) tile_body(std::integral_constant<int, 2>{}, t + 2);
     }
 
-    // ---- epilogue: O^T / l -> out[q][qh][d] -----------------------------------
+    // ---- epilogue: O^T / l -> out[q][qh][d], or the un-normalised partial -> workspace ---------
     lsum += __shfl_xor(lsum, 32);
+    if (ks > 1) {
+        const int64_t row = (int64_t)part_id * QBLK + wave * 32 + l31;
+        float *wo = P.ws_o + row * DUO_HEAD_DIM;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = 32 * db + 8 * rq + 4 * hi;
+                const f32x4 w = {o[db][4 * rq + 0], o[db][4 * rq + 1], o[db][4 * rq + 2], o[db][4 * rq + 3]};
+                *reinterpret_cast<f32x4 *>(wo + d) = w;
+            }
+        if (hi == 0) {
+            P.ws_ml[row * 2 + 0] = mrow;
+            P.ws_ml[row * 2 + 1] = lsum;
+        }
+        return;
+    }
     const float inv = 1.f / lsum;
     if (my_q < S) {
         bf16_t *op = P.out + (int64_t)my_q * P.o_ts + (int64_t)qh * P.o_hs;
@@ -380,18 +409,92 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     }
 }
 
+// Combine the `ksplit` partials of one (q tile, q head): out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
+// Block = (q tile, q head of the retrieval class) in the prefill kernel's block order; thread = 32 rows x 8
+// column groups of 16 dims per pass, 8 passes.
+template <bool F16>
+__global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillParams P) {
+    const DuoClassDev C = P.cls[0];
+    const int nq_c = C.n_kv_heads * P.group;
+    const int b = blockIdx.x;
+    const int tile = P.n_qtiles - 1 - b / nq_c;
+    const int p = b % nq_c;
+    const int kvh = p % C.n_kv_heads;
+    const int g = p / C.n_kv_heads;
+    const int qh = C.q_head_offset + kvh * P.group + g;
+    const int ks = P.ksplit;
+    const int j = threadIdx.x & 7;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int r = pass * 32 + (threadIdx.x >> 3);
+        const int q = tile * QBLK + r;
+        if (q >= P.S) continue;
+        const int64_t row0 = (int64_t)b * ks * QBLK + r;     // split s: + s * QBLK
+        float M = -INFINITY;
+        for (int s = 0; s < ks; ++s) M = fmaxf(M, P.ws_ml[(row0 + (int64_t)s * QBLK) * 2]);
+        float L = 0.f;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ks; ++s) {
+            const int64_t row = row0 + (int64_t)s * QBLK;
+            const float m = P.ws_ml[row * 2], l = P.ws_ml[row * 2 + 1];
+            if (m == -INFINITY) continue;      // this split saw no key of the row: nothing to add
+            const float w = fast_exp2((m - M) * P.scale_log2e);
+            L = fmaf(l, w, L);
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(P.ws_o + row * DUO_HEAD_DIM + 16 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + src[i] * w;
+        }
+        const float inv = 1.f / L;
+        bf16_t *op = P.out + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 w2;
+            w2.x = cvt_pk16<F16>(acc[i].x * inv, acc[i].y * inv);
+            w2.y = cvt_pk16<F16>(acc[i].z * inv, acc[i].w * inv);
+            *reinterpret_cast<u32x2 *>(op + 4 * i) = w2;
+        }
+    }
+}
+
 }  // namespace
 
 static uint32_t g_debug_flags = 0;
 extern "C" void duo_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
 extern "C" uint32_t duo_get_debug_flags(void) { return g_debug_flags; }
 
+// Key-range splits of the retrieval class.  One workgroup per CU is resident (96 KiB of LDS), so a launch
+// whose long workgroups (retrieval q heads x q tiles) are fewer than the CUs — small chunks, layers with
+// one or two retrieval kv heads — or not a multiple of them leaves CUs idle for the whole launch while
+// the streaming-head workgroups are short.  With k splits the long work becomes L0*k workgroups of 1/k the
+// length: pick the k that minimises rounds(L0*k) / k, with a small charge per split for the merge pass.
+constexpr int64_t kPrefillPartialBytes = (int64_t)QBLK * (DUO_HEAD_DIM + 2) * sizeof(float);
+static int prefill_choose_ksplit(int long_wgs, int min_tiles, int64_t workspace_bytes) {
+    static const int forced = [] {
+        const char *e = getenv("DUO_PREFILL_KSPLIT");   // tuning / test knob: force a split count
+        return e ? atoi(e) : 0;
+    }();
+    if (long_wgs <= 0 || workspace_bytes <= 0) return 1;
+    const int kmax = (int)std::min<int64_t>(8, std::min<int64_t>(min_tiles, workspace_bytes / (kPrefillPartialBytes * long_wgs)));
+    if (forced > 0) return std::max(1, std::min(forced, kmax));
+    int best = 1;
+    double best_cost = 1e30;
+    for (int k = 1; k <= kmax; ++k) {
+        const double rounds = (double)((long_wgs * k + 255) / 256);
+        const double cost = rounds / k + 0.03 * (k - 1);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = k; }
+    }
+    return best;
+}
+
+extern "C" int64_t duo_attn_prefill_workspace_bytes(void) { return 1024 * kPrefillPartialBytes; }
+
 template <bool F16>
 static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_stride,
                         void *out, int64_t out_token_stride, int64_t out_head_stride,
                         int32_t n_tokens, int32_t group, const duo_head_class *full,
                         const duo_head_class *stream_cls, float scale, int32_t head_dim,
-                        void *stream) {
+                        void *workspace, int64_t workspace_bytes, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (q == nullptr || out == nullptr || group <= 0 || n_tokens < 0) return DUO_EINVAL;
     if (n_tokens == 0) return 0;
@@ -421,10 +524,24 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         }
         nblk += C.n_kv_heads * group * P.n_qtiles;
     }
+    // split the retrieval class when that fills the chip better (needs the caller's workspace)
+    const int long_wgs = P.cls[0].n_kv_heads * group * P.n_qtiles;
+    P.ksplit = 1;
+    P.ws_o = nullptr;
+    P.ws_ml = nullptr;
+    if (workspace && long_wgs > 0) {
+        const int min_tiles = (P.cls[0].a.len + KVBLK - 1) / KVBLK + 1;   // tiles of the first q tile
+        P.ksplit = prefill_choose_ksplit(long_wgs, min_tiles, workspace_bytes);
+        if (P.ksplit > 1) {
+            P.ws_o = (float *)workspace;
+            P.ws_ml = P.ws_o + (int64_t)long_wgs * P.ksplit * QBLK * DUO_HEAD_DIM;
+            nblk += long_wgs * (P.ksplit - 1);
+        }
+    }
     if ((q_token_stride | q_head_stride) & 7) return DUO_EINVAL;
     if ((out_token_stride | out_head_stride) & 3) return DUO_EINVAL;
     if (nblk == 0) return 0;
-    P.nblk_full = P.cls[0].n_kv_heads * group * P.n_qtiles;
+    P.nblk_full = long_wgs * P.ksplit;
 
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
@@ -439,6 +556,10 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
     else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
     DUO_HIP_CHECK_LAUNCH();
+    if (P.ksplit > 1) {
+        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs), dim3(256), 0, st, P);
+        DUO_HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -448,7 +569,18 @@ extern "C" int duo_attn_prefill_bf16(const void *q, int64_t q_token_stride, int6
                                      const duo_head_class *stream_cls, float scale, int32_t head_dim,
                                      void *stream) {
     return prefill_impl<false>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
-                               group, full, stream_cls, scale, head_dim, stream);
+                               group, full, stream_cls, scale, head_dim, nullptr, 0, stream);
+}
+
+// Same, with a caller-owned workspace (duo_attn_prefill_workspace_bytes()) that lets the launcher split the
+// retrieval class over key ranges when its workgroups would not fill the chip.
+extern "C" int duo_attn_prefill_ws_bf16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                        void *out, int64_t out_token_stride, int64_t out_head_stride,
+                                        int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                        const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                        void *workspace, int64_t workspace_bytes, void *stream) {
+    return prefill_impl<false>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                               group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream);
 }
 
 // fp16 twin (q, K, V, out all fp16): the attention of the INT4 path's chunked prefill over dequantised pools
@@ -459,5 +591,14 @@ extern "C" int duo_attn_prefill_f16(const void *q, int64_t q_token_stride, int64
                                     const duo_head_class *stream_cls, float scale, int32_t head_dim,
                                     void *stream) {
     return prefill_impl<true>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
-                              group, full, stream_cls, scale, head_dim, stream);
+                              group, full, stream_cls, scale, head_dim, nullptr, 0, stream);
+}
+
+extern "C" int duo_attn_prefill_ws_f16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                       void *out, int64_t out_token_stride, int64_t out_head_stride,
+                                       int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                       const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                       void *workspace, int64_t workspace_bytes, void *stream) {
+    return prefill_impl<true>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                              group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream);
 }

@@ -28,6 +28,12 @@ struct PrefillParams {
     DuoClassDev cls[2];
     float scale_log2e;
     uint32_t flags;
+    // key-range splits of the retrieval class (class 0): each (q tile, q head) is covered by `ksplit`
+    // workgroups that walk disjoint ranges of its K/V tiles and leave un-normalised partials (O, m, l) in
+    // the workspace for duo_prefill_merge_kernel.  1 = no split (the workgroup writes `out` itself).
+    int32_t ksplit;
+    float *ws_o;     // [block][256 rows][128] fp32
+    float *ws_ml;    // [block][256 rows][2]   (row max in score units, row sum)
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;

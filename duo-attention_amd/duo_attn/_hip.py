@@ -118,6 +118,17 @@ _SIGNATURES = {
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
          POINTER(HeadClass), c_float, c_int32, c_void_p],
     ),
+    "duo_attn_prefill_workspace_bytes": (c_int64, []),
+    "duo_attn_prefill_ws_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
+         POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_attn_prefill_ws_f16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
+         POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p],
+    ),
     "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "duo_int4_quantize": (
         ctypes.c_int,
@@ -374,6 +385,19 @@ def decode_state_add(dev_states: torch.Tensor, d_full: int, d_str: int, d_pos: i
                                     int(str_cap), _stream_ptr()), "duo_decode_state_add")
 
 
+_prefill_ws = {}
+
+
+def prefill_workspace(device) -> torch.Tensor:
+    """fp32 workspace for the key-range splits of the prefill kernel, allocated once per device."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _prefill_ws.get(key)
+    if ws is None:
+        ws = torch.empty(load_library().duo_attn_prefill_workspace_bytes() // 4, dtype=torch.float32, device=device)
+        _prefill_ws[key] = ws
+    return ws
+
+
 def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
                  stream: Optional[HeadClass], scale: float):
     """q, out: [S, Hq, D] views, bf16 or fp16 (the segments of ``full`` / ``stream`` must have the same
@@ -384,14 +408,16 @@ def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[
     _require_gpu_bf16(q, "q", q.dtype)
     _require_gpu_bf16(out, "out", q.dtype)
     assert q.dim() == 3 and out.shape == q.shape
-    fn = lib.duo_attn_prefill_f16 if q.dtype == torch.float16 else lib.duo_attn_prefill_bf16
+    fn = lib.duo_attn_prefill_ws_f16 if q.dtype == torch.float16 else lib.duo_attn_prefill_ws_bf16
+    ws = prefill_workspace(q.device)
     _check(
         fn(
             q.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(), out.stride(0), out.stride(1), q.shape[0],
             int(group), byref(full) if full is not None else None,
-            byref(stream) if stream is not None else None, float(scale), q.shape[2], _stream_ptr(),
+            byref(stream) if stream is not None else None, float(scale), q.shape[2],
+            ws.data_ptr(), ws.numel() * 4, _stream_ptr(),
         ),
-        "duo_attn_prefill_f16" if q.dtype == torch.float16 else "duo_attn_prefill_bf16",
+        "duo_attn_prefill_ws_f16" if q.dtype == torch.float16 else "duo_attn_prefill_ws_bf16",
     )
 
 

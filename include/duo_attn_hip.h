@@ -224,6 +224,23 @@ int duo_attn_prefill_f16(const void *q, int64_t q_token_stride,
                           const duo_head_class *full, const duo_head_class *stream_cls,
                           float scale, int32_t head_dim, void *stream);
 
+/* Prefill with a caller-owned workspace: lets the launcher split the retrieval class over KEY RANGES when its
+ * long workgroups (retrieval q heads x 256-row q tiles) would not fill the 256 CUs — small chunks, layers with
+ * one or two retrieval kv heads.  Each split leaves un-normalised partials in the workspace and a second
+ * launch merges them.  Results are the same up to fp32 summation order.  duo_attn_prefill_workspace_bytes()
+ * is the size that never limits the split choice; a smaller (or NULL) workspace only limits / disables it. */
+int64_t duo_attn_prefill_workspace_bytes(void);
+int duo_attn_prefill_ws_bf16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                             void *out, int64_t out_token_stride, int64_t out_head_stride,
+                             int32_t n_tokens, int32_t group, const duo_head_class *full,
+                             const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                             void *workspace, int64_t workspace_bytes, void *stream);
+int duo_attn_prefill_ws_f16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
+                            void *out, int64_t out_token_stride, int64_t out_head_stride,
+                            int32_t n_tokens, int32_t group, const duo_head_class *full,
+                            const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                            void *workspace, int64_t workspace_bytes, void *stream);
+
 /* ---- INT4 KV pools (BASELINE config 5): the reference's only native code,
  * demo/quantize_int4.cu, and the attention over its pools ---------------------
  * Row = one (token, kv head): 128 values -> 64 packed bytes (even element in the

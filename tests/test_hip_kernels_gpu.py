@@ -304,6 +304,40 @@ def test_prefill_query_block_shorter_than_segment_b(S, lenA, lenB, group):
     attn_close(out, ref[0], f"row block S={S} lenB={lenB}", bud[0])
 
 
+def test_prefill_key_range_splits_agree_with_single_pass():
+    """duo_attn_prefill_ws_bf16 (workspace: the retrieval class may be split over key ranges, partials merged
+    by a second launch) against duo_attn_prefill_bf16 (one workgroup walks all of a q tile's keys): same
+    attention, fp32 summation order aside.  Shape chosen so that the launcher does split (8 long workgroups)."""
+    from ctypes import byref
+
+    h = _hip()
+    lib = h.load_library()
+    g = torch.Generator().manual_seed(77)
+    S, group, lenA = 300, 4, 5000
+    q = _rand((S, group, D), g).to(DEV)
+    ka, va = _rand((lenA, 1, D), g).to(DEV), _rand((lenA, 1, D), g).to(DEV)
+    kb, vb = _rand((S, 1, D), g).to(DEV), _rand((S, 1, D), g).to(DEV)
+    cls = h.make_class(1, 0, h.make_seg(ka, va), h.make_seg(kb, vb))
+    out_split = torch.empty_like(q)
+    h.attn_prefill(q, out_split, group, cls, None, D ** -0.5)
+    out_single = torch.empty_like(q)
+    rc = lib.duo_attn_prefill_bf16(q.data_ptr(), q.stride(0), q.stride(1), out_single.data_ptr(), out_single.stride(0),
+                                   out_single.stride(1), S, group, byref(cls), None, D ** -0.5, D,
+                                   torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    a, b = out_split.float().cpu(), out_single.float().cpu()
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    # The two differ by more than summation order: each pass rounds P to bf16 relative to ITS running
+    # maximum, so the P-rounding noise (budgeted in attn_close) is drawn twice.  Both must meet the oracle bar,
+    # and each other within twice that noise.
+    ref, bud = flash_attn_func_ref(q.cpu()[None], torch.cat([ka, kb]).cpu()[None], torch.cat([va, vb]).cpu()[None],
+                                   round_p=False, out_dtype=torch.float32, return_budget=True)
+    attn_close(out_split, ref[0], "split", bud[0])
+    attn_close(out_single, ref[0], "single", bud[0])
+    rms = b.pow(2).mean().sqrt()
+    assert (a - b).pow(2).mean().sqrt() <= 5e-3 * rms
+
+
 def test_prefill_without_transpose_read_matches():
     """ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
     h = _hip()
