@@ -14,6 +14,10 @@ Unpinnable residue (said here once): the reference builds that file with nvcc --
 (demo/int4_kv.py:46-56), so its division may be the approximate __fdividef and ptxas may contract
 hmul+hadd into one fma.f16; neither can be reproduced without the CUDA toolchain.  This oracle is
 the source-level semantics with IEEE fp32 division and separate fp16 roundings.
+
+PARITY UNPINNED for this file: the reference ships no vectors for the INT4 kernels and its CUDA source
+cannot be built or run here (no nvcc, no CUDA device), so the oracle is a reading of the source, checked
+only against itself (tests/test_int4.py: layout, error bound, constant rows) — not against reference output.
 """
 import numpy as np
 
