@@ -107,6 +107,25 @@ class HotPath:
 
         return duo_static_attention_core(q[:, :S], k[:, :S], v[:, :S], self.cache, li, pos0, ROPE_SCALE, ROPE_THETA)
 
+    # ---- N > 1: a chunk goes through the stages in ROW BLOCKS (pipeline wavefront) -------------------
+    # Row r of a chunk needs only rows <= r of the same chunk, so stage s+1 can start on the first block of a
+    # chunk while stage s is still working on its later blocks: the pipeline fills in block-sized steps
+    # (makespan ~ n*m + P - 1 block slots for n chunks of m blocks) instead of chunk-sized ones.  The chunk's
+    # semantics are unchanged (duo_static_attention_row_block).
+    def set_row_blocks(self, rows):
+        self.block_rows = rows
+        self.blocks = [(ci, r0, min(rows, c - r0)) for ci, (_, c) in enumerate(self.chunks) for r0 in range(0, c, rows)]
+
+    def prefill_block_stage(self, i, x):
+        from duo_attn.patch._duo import duo_static_attention_row_block
+
+        ci, r0, n = self.blocks[i]
+        c = self.chunks[ci][1]
+        for li in range(len(self.counts)):
+            duo_static_attention_row_block(self.q_c[:, r0:r0 + n], self.k_c[:, r0:r0 + n], self.v_c[:, r0:r0 + n],
+                                           self.cache, li, r0, c, ROPE_SCALE, ROPE_THETA)
+        return x if x is not None else self.hidden_c[:, :n]
+
     def prefill_stage(self, i, x):
         s, c = self.chunks[i]
         for li in range(len(self.counts)):
@@ -129,12 +148,15 @@ def sync_all(world):
 def run_job(hp: HotPath, pipe, n_decode, world, device, handoff=None):
     """One whole job; returns (t_total, t_prefill, t_decode) seconds (wall, max over ranks not yet taken)."""
     handoff = handoff or device
-    pre = hp.prefill_stage if handoff == device else (lambda i, x: hp.prefill_stage(i, x).to(handoff))
+    blocked = getattr(hp, "blocks", None)
+    pre_fn = hp.prefill_block_stage if blocked else hp.prefill_stage
+    pre = pre_fn if handoff == device else (lambda i, x: pre_fn(i, x).to(handoff))
     dec = hp.decode_stage if handoff == device else (lambda i, x: hp.decode_stage(i, x).to(handoff))
     hp.cache.clear()
     sync_all(world)
     t0 = time.perf_counter()
-    pipe.run([(1, c, HIDDEN) for _, c in hp.chunks], pre, handoff)
+    shapes = [(1, n, HIDDEN) for _, _, n in hp.blocks] if blocked else [(1, c, HIDDEN) for _, c in hp.chunks]
+    pipe.run(shapes, pre, handoff)
     sync_all(world)
     t1 = time.perf_counter()
     # batch-1 decode is autoregressive: token i+1 enters stage 0 only after token i left the last stage
@@ -273,6 +295,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=16384)
     ap.add_argument("--decode-tokens", type=int, default=128)
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--row-block", type=int, default=-1,
+                    help="N > 1: query rows per pipeline item (a chunk is handed through the stages in row blocks); "
+                         "0 = whole chunks, -1 = automatic (4096 rows on 2 GPUs, 2048 on more)")
     ap.add_argument("--no-full-baseline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
@@ -327,6 +352,15 @@ def main():
         return (t / steps).tolist()
 
     hp = HotPath(counts, lr, args.ctx, args.chunk, device)
+    # (DUO_BENCH_FORCE_BLOCKS=1: row blocks on one GPU too — measures what the finer launches cost)
+    if args.row_block < 0:
+        # finer blocks fill the pipeline sooner but run the kernels at smaller launches (one GPU, whole job:
+        # 4096-row blocks 94 %, 2048 89 %, 1024 78 % of the whole-chunk prefill rate): with P stages the
+        # fill costs ~(P-1) block slots, so more stages want smaller blocks
+        args.row_block = 4096 if world <= 2 else 2048
+    use_blocks = args.row_block > 0 and (world > 1 or os.environ.get("DUO_BENCH_FORCE_BLOCKS") == "1")
+    if use_blocks:
+        hp.set_row_blocks(args.row_block)
     t_job, t_pre, t_dec = timed(hp, args.steps, args.warmup)
 
     # HBM-side traffic per launch is a PMC measurement (rocprofv3 --pmc FETCH_SIZE, its own pass, x2 gfx950
@@ -362,6 +396,8 @@ def main():
     full = None
     if not args.no_full_baseline:
         hpf = HotPath([HKV] * L, lr, args.ctx, args.chunk, device)
+        if use_blocks:
+            hpf.set_row_blocks(args.row_block)
         f_job, f_pre, f_dec = timed(hpf, 1, 0)
         full = {"job_tok_s": n_tok / f_job, "prefill_tok_s": args.ctx / f_pre,
                 "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": all_ranks_sum(hpf.cache.memory_usage)}
@@ -393,7 +429,8 @@ def main():
                 "seq_len": args.ctx,
                 "prefill_chunk": args.chunk,
                 "decode_tokens": args.decode_tokens,
-                "parallelism": f"layer-pipeline pp{world}" if world > 1 else "single GPU",
+                "parallelism": (f"layer-pipeline pp{world}, {args.row_block}-row wavefront" if use_blocks
+                                else f"layer-pipeline pp{world}") if world > 1 else "single GPU",
             },
             "prefill_tok_s": args.ctx / t_pre,
             "decode_tok_s": args.decode_tokens / t_dec,

@@ -99,6 +99,58 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
     kv_cache.update_streaming_kv(layer_idx, sk, sv)
     return attn_output
 
+def duo_static_attention_row_block(query_states, key_states, value_states, kv_cache, layer_idx, r0, chunk_len,
+                                   rope_scale, rope_theta):
+    """Rows ``[r0, r0 + n)`` of a prefill chunk of ``chunk_len`` rows — the same mathematics as
+    ``duo_static_attention_core`` on the whole chunk, issued block by block in row order.
+
+    Why: in a layer pipeline a stage can start on the first rows of a chunk as soon as the previous stage
+    has produced them (causality: row r only needs rows <= r of its own chunk), so the pipeline fills in
+    row-block steps instead of whole-chunk steps.  Semantics are the chunk's, not a smaller chunk's: a
+    streaming head still sees the pool as it was at the START of the chunk plus every earlier row of the
+    chunk (reference llama.py:374-421), which is why the chunk's streaming K/V rows are kept in a staging
+    buffer until the last block, when the pool update runs once on the whole chunk (:423-425).
+    q [B,n,Hq,D], k/v [B,n,Hkv,D] (un-rotated); blocks of one chunk must come in order, ``r0 == 0`` first."""
+    bsz, n, num_heads, head_dim = query_states.shape
+    num_kv = key_states.shape[2]
+    groups = num_heads // num_kv
+    nf = kv_cache.num_full_kv_head_list[layer_idx]
+    ns = num_kv - nf
+    r1 = r0 + n
+    if r1 > chunk_len:
+        raise ValueError(f"row block [{r0}, {r1}) exceeds the chunk of {chunk_len} rows")
+    st = kv_cache.begin_chunk(layer_idx, chunk_len) if r0 == 0 else kv_cache.chunk_state(layer_idx)
+    if st["next_row"] != r0 or st["chunk_len"] != chunk_len:
+        raise ValueError(f"row blocks out of order: expected row {st['next_row']} of a {st['chunk_len']}-row chunk")
+    past_l = st["past"]
+    be = get_backend()
+    apply_rope_inplace(query_states, key_states, past_l + r0, rope_scale, rope_theta)
+    fk, fv, sk, sv = kv_cache.split_kv(layer_idx, key_states, value_states)
+    kv_cache.put_full_kv(layer_idx, fk, fv)                 # lands at rows past_l + r0 .. of the full pool
+    stage_k, stage_v = st["stage_k"], st["stage_v"]
+    if ns > 0:
+        stage_k[:, r0:r1].copy_(sk)
+        stage_v[:, r0:r1].copy_(sv)
+    attn_output = torch.empty_like(query_states)
+    scale = head_dim ** -0.5
+    pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
+    ck, cv = kv_cache.get_streaming_kv(layer_idx)           # unchanged until the chunk's last block
+    for b in range(bsz):
+        if past_l == 0:     # first chunk: every head causal over the chunk's own rows (:364-372)
+            full = (nf, 0, None, (pk[b, :r1], pv[b, :r1])) if nf > 0 else None
+            stream = (ns, nf * groups, None, (stage_k[b, :r1], stage_v[b, :r1])) if ns > 0 else None
+        else:
+            full = (nf, 0, (pk[b, :past_l], pv[b, :past_l]),
+                    (pk[b, past_l:past_l + r1], pv[b, past_l:past_l + r1])) if nf > 0 else None
+            stream = (ns, nf * groups, (ck[b], cv[b]), (stage_k[b, :r1], stage_v[b, :r1])) if ns > 0 else None
+        be.attention(query_states[b], attn_output[b], groups, full, stream, scale)
+    st["next_row"] = r1
+    if r1 == chunk_len:
+        kv_cache.update_streaming_kv(layer_idx, stage_k[:, :chunk_len], stage_v[:, :chunk_len])
+        kv_cache.end_chunk(layer_idx)
+    return attn_output
+
+
 def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, layer_idx, pos0, rope_scale,
                        rope_theta):
     """q_len == 1 after a prefill: the same steps as the general path below (RoPE, put_full_kv, the two

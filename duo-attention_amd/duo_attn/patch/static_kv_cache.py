@@ -172,6 +172,29 @@ class DuoAttentionStaticKVCache:
             self.kv_seq_len_list[i] = max(0, self.kv_seq_len_list[i] - num_tokens)
             self.streaming_kv_seq_len_list[i] = max(0, self.streaming_kv_seq_len_list[i] - num_tokens)
 
+    # ---- a prefill chunk processed in row blocks (duo_static_attention_row_block) ------------------
+    def begin_chunk(self, layer_idx, chunk_len):
+        """Start a chunk of ``chunk_len`` rows on this layer: remember the cache length at its start and make
+        sure the layer's staging buffer for the chunk's streaming K/V rows is large enough."""
+        if not hasattr(self, "_chunk_state"):
+            self._chunk_state = {}
+        st = self._chunk_state.get(layer_idx)
+        ns = self.num_streaming_kv_head_list[layer_idx]
+        if st is None or st["stage_k"].shape[1] < chunk_len:
+            st = {"stage_k": self._alloc(chunk_len, ns), "stage_v": self._alloc(chunk_len, ns)}
+            self._chunk_state[layer_idx] = st
+        st.update(past=self.kv_seq_len_list[layer_idx], chunk_len=chunk_len, next_row=0, open=True)
+        return st
+
+    def chunk_state(self, layer_idx):
+        st = getattr(self, "_chunk_state", {}).get(layer_idx)
+        if st is None or not st.get("open"):
+            raise ValueError("no chunk in progress on this layer: the first row block must start at row 0")
+        return st
+
+    def end_chunk(self, layer_idx):
+        self._chunk_state[layer_idx]["open"] = False
+
     # ---- device-side counters (SURVEY §8 f3: a decode step that can be captured in a HIP graph) --------
     # The reference keeps the lengths as Python ints only (static_kv_cache.py:44-45), so every launch
     # bakes them in.  With the device state enabled each layer also has {full_len, str_len, pos, pad}

@@ -494,3 +494,47 @@ def test_device_state_add_clamps():
     assert st.cpu().tolist() == [[6, 4, 6, 0], [1, 12, 8, 0], [101, 12, 101, 0]]
     h.decode_state_add(st, -7, -7, -7, 12)
     assert st.cpu().tolist() == [[0, 0, 0, 0], [0, 5, 1, 0], [94, 5, 94, 0]]
+
+
+def test_row_blocks_equal_whole_chunk_on_gpu():
+    """duo_static_attention_row_block with the HIP kernels: chunks processed in row blocks (512 rows; the
+    prefill kernel then runs with segment B longer than its query block, and with key-range splits) against
+    the same chunks processed whole — outputs within the P-rounding noise, pools and counters identical."""
+    from duo_attn.patch._duo import duo_static_attention_core, duo_static_attention_row_block
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    counts, Hq, Hkv, sink, recent = [1, 3, 0, 4], 16, 4, 16, 48
+    chunks, rows = [1536, 1024, 700], 512
+    g = torch.Generator().manual_seed(31)
+    mk = lambda S, h: _rand((1, S, h, D), g)
+    data = [[(mk(S, Hq), mk(S, Hkv), mk(S, Hkv)) for _ in counts] for S in chunks]
+
+    def run(by_blocks):
+        model = ShapeModel(len(counts), Hq, Hkv, D, device=DEV)
+        cache = DuoAttentionStaticKVCache(model, heads_from_counts(counts, Hkv), 1, sum(chunks) + 8, sink, recent)
+        outs = []
+        for ci, S in enumerate(chunks):
+            pos = cache.kv_seq_len
+            for li in range(len(counts)):
+                q, k, v = (t.to(DEV) for t in data[ci][li])
+                if by_blocks:
+                    parts = [duo_static_attention_row_block(q[:, r0:r0 + rows], k[:, r0:r0 + rows], v[:, r0:r0 + rows],
+                                                            cache, li, r0, S, 1.0, 1e4) for r0 in range(0, S, rows)]
+                    outs.append(torch.cat(parts, 1))
+                else:
+                    outs.append(duo_static_attention_core(q, k, v, cache, li, pos, 1.0, 1e4))
+        return outs, cache
+
+    whole, c0 = run(False)
+    blocked, c1 = run(True)
+    for a, b in zip(whole, blocked):
+        a, b = a.float().cpu(), b.float().cpu()
+        assert torch.isfinite(b).all()
+        assert (a - b).pow(2).mean().sqrt() <= 5e-3 * a.pow(2).mean().sqrt()
+    assert c0.kv_seq_len_list == c1.kv_seq_len_list and c0.streaming_kv_seq_len_list == c1.streaming_kv_seq_len_list
+    for l in range(len(counts)):
+        n, m = c0.kv_seq_len_list[l], c0.streaming_kv_seq_len_list[l]
+        for x, y, ln in ((c0.full_key_states_list, c1.full_key_states_list, n), (c0.full_value_states_list, c1.full_value_states_list, n),
+                         (c0.streaming_key_states_list, c1.streaming_key_states_list, m),
+                         (c0.streaming_value_states_list, c1.streaming_value_states_list, m)):
+            assert torch.equal(x[l][:, :ln], y[l][:, :ln])

@@ -118,3 +118,66 @@ def test_procedural_semantics_equal_closed_form_mask(N, S):
             s = s.masked_fill(~vis, float("-inf"))
             exp = torch.softmax(s, -1) @ V[0, :, h].float()
             torch.testing.assert_close(outs[0, :, 2 * h + gq], exp, rtol=1e-5, atol=1e-5)
+
+
+def test_row_blocks_equal_whole_chunk(oracle_backend):
+    """duo_static_attention_row_block: a chunk processed in row blocks (pipeline wavefront) gives the chunk's
+    result, not a smaller chunk's — outputs, both pools and all counters — for the first chunk and for later
+    chunks, through the streaming window's fill -> slide transition."""
+    import torch
+    from helpers import ShapeModel, heads_from_counts
+    from duo_attn.patch._duo import duo_static_attention_core, duo_static_attention_row_block
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    counts, Hq, Hkv, D, sink, recent = [1, 2, 0, 4], 8, 4, 128, 3, 9
+    chunks, blocks = [40, 24, 33], [[16, 16, 8], [8, 16], [33]]
+    g = torch.Generator().manual_seed(3)
+    mk = lambda S, h: torch.randn(1, S, h, D, generator=g).to(torch.bfloat16)
+    data = [[(mk(S, Hq), mk(S, Hkv), mk(S, Hkv)) for _ in counts] for S in chunks]
+
+    def run(by_blocks):
+        model = ShapeModel(len(counts), Hq, Hkv, D)
+        cache = DuoAttentionStaticKVCache(model, heads_from_counts(counts, Hkv), 1, 128, sink, recent)
+        outs = []
+        for ci, S in enumerate(chunks):
+            pos = cache.kv_seq_len
+            for li in range(len(counts)):
+                q, k, v = (t.clone() for t in data[ci][li])
+                if by_blocks:
+                    r0, parts = 0, []
+                    for n in blocks[ci]:
+                        parts.append(duo_static_attention_row_block(q[:, r0:r0 + n], k[:, r0:r0 + n], v[:, r0:r0 + n],
+                                                                    cache, li, r0, S, 1.0, 1e4))
+                        r0 += n
+                    outs.append(torch.cat(parts, 1))
+                else:
+                    outs.append(duo_static_attention_core(q, k, v, cache, li, pos, 1.0, 1e4))
+        return outs, cache
+
+    whole, c0 = run(False)
+    blocked, c1 = run(True)
+    for a, b in zip(whole, blocked):
+        torch.testing.assert_close(a.float(), b.float(), rtol=0, atol=2 ** -7 * 4)   # bf16 outputs, same math
+    assert c0.kv_seq_len_list == c1.kv_seq_len_list and c0.streaming_kv_seq_len_list == c1.streaming_kv_seq_len_list
+    for l in range(len(counts)):
+        n, m = c0.kv_seq_len_list[l], c0.streaming_kv_seq_len_list[l]
+        assert torch.equal(c0.full_key_states_list[l][:, :n], c1.full_key_states_list[l][:, :n])
+        assert torch.equal(c0.full_value_states_list[l][:, :n], c1.full_value_states_list[l][:, :n])
+        assert torch.equal(c0.streaming_key_states_list[l][:, :m], c1.streaming_key_states_list[l][:, :m])
+        assert torch.equal(c0.streaming_value_states_list[l][:, :m], c1.streaming_value_states_list[l][:, :m])
+
+
+def test_row_blocks_must_come_in_order(oracle_backend):
+    import pytest
+    import torch
+    from helpers import ShapeModel, heads_from_counts
+    from duo_attn.patch._duo import duo_static_attention_row_block
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    cache = DuoAttentionStaticKVCache(ShapeModel(1, 4, 2, 128), heads_from_counts([1], 2), 1, 64, 2, 4)
+    t = lambda n, h: torch.zeros(1, n, h, 128, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        duo_static_attention_row_block(t(4, 4), t(4, 2), t(4, 2), cache, 0, 4, 16, 1.0, 1e4)   # no block at row 0 yet
+    duo_static_attention_row_block(t(4, 4), t(4, 2), t(4, 2), cache, 0, 0, 16, 1.0, 1e4)
+    with pytest.raises(ValueError):
+        duo_static_attention_row_block(t(4, 4), t(4, 2), t(4, 2), cache, 0, 8, 16, 1.0, 1e4)   # skips rows 4..7
