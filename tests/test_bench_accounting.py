@@ -1,0 +1,37 @@
+"""The algorithmic work figures bench.py divides by, checked on CPU against the closed forms:
+decode bytes per token and prefill FLOPs of the 128K job, duo pattern vs all-full."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_decode_bytes_per_token():
+    b = _bench()
+    counts = b.LLAMA3_8B_FULL_KV_HEADS
+    assert len(counts) == 32 and sum(counts) == 128
+    N = 131072
+    duo = sum(b.decode_bytes(counts, N))
+    full = sum(b.decode_bytes([8] * 32, N))
+    # 128 retrieval kv heads x (N+1) rows + 128 streaming x 385 rows, 512 B per row (K and V)
+    assert duo == (128 * (N + 1) + 128 * 385) * 512
+    assert abs(duo / 1e9 - 8.615) < 0.01 and abs(full / 1e9 - 17.18) < 0.01
+    assert abs(full / duo - 1.994) < 0.002
+
+
+def test_prefill_flops_of_the_job():
+    b = _bench()
+    counts = b.LLAMA3_8B_FULL_KV_HEADS
+    tot = lambda c, C: sum(sum(row) for row in b.prefill_flops(c, 131072, C))
+    full = tot([8] * 32, 16384)
+    assert abs(full / 4.504e15 - 1) < 2e-3                      # chunking does not change full attention
+    assert abs(tot([8] * 32, 4096) / full - 1) < 1e-9
+    for C, want in ((4096, 2.335e15), (16384, 2.545e15), (32000, 2.800e15)):
+        assert abs(tot(counts, C) / want - 1) < 2e-3, (C, tot(counts, C))
