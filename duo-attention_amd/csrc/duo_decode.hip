@@ -441,12 +441,14 @@ struct MergeParams {
     int32_t qh_begin[2], qh_end[2], splits[2];
 };
 
-// One workgroup (256 threads) per q head: 8 split lanes x 32 dim quads.  Two passes so that the
-// accumulation has no serial max/rescale chain and its loads can all be in flight:
+// Four workgroups (256 threads) per q head, one per 32-dim quarter: 32 split lanes x 8 dim quads, so the
+// ~128 partials of a retrieval head are ONE batch of four loads per thread instead of four dependent
+// batches.  Two passes so that the accumulation has no serial max/rescale chain:
 //   1. M = max over the splits' m (every thread scans a strided share of the <= 1024 floats);
 //   2. each split lane sums w_s * acc_s and w_s * l_s with w_s = exp2(m_s - M), 4 splits per step.
 __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
-    int qh = blk;
+    int qh = blk >> 2;
+    const int quarter = blk & 3;
     int splits;
     {
         const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
@@ -458,14 +460,15 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
             splits = P.splits[1];
         }
     }
-    const int sl = threadIdx.x >> 5;  // 0..7
-    const int dq = threadIdx.x & 31;  // dims 4dq..4dq+3
+    const int sl = threadIdx.x >> 3;  // 0..31
+    const int dq = threadIdx.x & 7;   // dims 32*quarter + 4dq .. +3
+    const int d0 = 32 * quarter + 4 * dq;
     const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
-    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + dq * 4;
+    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
 
     __shared__ float red[4];
-    __shared__ float slm[8][32];
-    __shared__ f32x4 so[8][32];
+    __shared__ float slm[32][8];
+    __shared__ f32x4 so[32][8];
 
     float M = kNegSentinel;
     for (int s = threadIdx.x; s < splits; s += 256) M = fmaxf(M, ml[s * 2]);
@@ -478,12 +481,12 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
     float Lsum = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     int s = sl;
-    for (; s + 24 < splits; s += 32) {       // 4 splits (stride 8) per step
+    for (; s + 96 < splits; s += 128) {       // 4 splits (stride 32) per step
         float w[4], l[4];
         f32x4 a[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int su = s + 8 * u;
+            const int su = s + 32 * u;
             w[u] = ml[su * 2];
             l[u] = ml[su * 2 + 1];
             a[u] = *reinterpret_cast<const f32x4 *>(ac + (int64_t)su * DUO_HEAD_DIM);
@@ -495,7 +498,7 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
             o = o + a[u] * wu;
         }
     }
-    for (; s < splits; s += 8) {
+    for (; s < splits; s += 32) {
         const float wu = fast_exp2(ml[s * 2] - M);
         Lsum = fmaf(ml[s * 2 + 1], wu, Lsum);
         o = o + *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM) * wu;
@@ -507,7 +510,7 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
         float LL = 0.f;
         f32x4 oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             LL += slm[i][dq];
             oo = oo + so[i][dq];
         }
@@ -515,12 +518,12 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
         u32x2 w;
         w.x = pack_bf16x2(oo.x * inv, oo.y * inv);
         w.y = pack_bf16x2(oo.z * inv, oo.w * inv);
-        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + dq * 4) = w;
+        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + d0) = w;
     }
 }
 
-// Epilogue launch of a decode step: blocks [0, n_merge) merge the split-KV partials of one q head
-// each; blocks [n_merge, n_merge + n_compress) run the streaming-pool sink+recent update of one
+// Epilogue launch of a decode step: blocks [0, n_merge) merge the split-KV partials of one q-head quarter
+// each (n_merge = 4 x q heads with more than one split); blocks [n_merge, n_merge + n_compress) run the streaming-pool sink+recent update of one
 // (head, K|V) each (absent when the caller updates the pool separately).
 __global__ __launch_bounds__(256) void duo_decode_post_kernel(const MergeParams M, int n_merge,
                                                              const CompressParams C) {
@@ -676,7 +679,7 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
     if (D.n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
         CompressParams none{};
-        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(D.n_merge), dim3(256), 0, st, D.M, D.n_merge, none);
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge), dim3(256), 0, st, D.M, 4 * D.n_merge, none);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -750,7 +753,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
         n_compress = 2 * ns;
     }
     if (D.n_merge + n_compress > 0) {
-        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(D.n_merge + n_compress), dim3(256), 0, st, D.M, D.n_merge, C);
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge + n_compress), dim3(256), 0, st, D.M, 4 * D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;
