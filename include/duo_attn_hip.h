@@ -92,7 +92,11 @@ const char *duo_error_string(int code);
 /* bit 0: prefill uses scalar LDS gathers instead of ds_read_b64_tr_b16 for V
  *        (slow, debugging aid for the transpose-read layout);
  * bit 1: decode skips the merge launch (output invalid; lets a profiler or a
- *        HIP-event pair bracket the split-KV kernel alone).                   */
+ *        HIP-event pair bracket the split-KV kernel alone);
+ * bit 2: decode K/V loads temporal instead of non-temporal;  bit 3: no register prefetch;
+ * bit 4: INT4 decode on the scalar-FMA kernel instead of the matrix-core one;
+ * bit 5 / bit 6: INT4 / bf16 decode consume their loads without the arithmetic (output
+ *        invalid: the memory-side ceiling of the launch).  Measurement aids only.    */
 void duo_set_debug_flags(uint32_t flags);
 uint32_t duo_get_debug_flags(void);
 
