@@ -212,4 +212,9 @@ def sparsify_attention_heads(full_attention_heads, threshold=None, sparsity=None
 
 
 def save_full_attention_heads(full_attention_heads, output_filename):
-    np.savetxt(output_filename, np.array(full_attention_heads), delimiter="\t")
+    heads = full_attention_heads
+    if hasattr(heads, "detach"):           # torch tensor (or a list of them, below) -> numpy, no copy keyword games
+        heads = heads.detach().float().cpu().numpy()
+    elif isinstance(heads, (list, tuple)):
+        heads = [h.detach().float().cpu().numpy() if hasattr(h, "detach") else h for h in heads]
+    np.savetxt(output_filename, np.asarray(heads), delimiter="\t")

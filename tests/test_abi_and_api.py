@@ -144,3 +144,36 @@ int main() {
         got = [int(x) for x in subprocess.run([os.path.join(d, "t")], capture_output=True, text=True, check=True).stdout.split()]
     A = _hip.DecodeLayerArgs
     assert got == [ctypes.sizeof(A), A.k.offset, A.full_k.offset, A.str_len.offset, A.pos.offset, A.scale.offset]
+
+
+def test_pattern_files_round_trip(tmp_path):
+    """save_full_attention_heads -> load_full_attention_heads / load_attn_pattern (reference utils.py:326-350,
+    patch/__init__.py:110-121): the TSV + config.json layout the shipped attn_patterns use."""
+    import json
+
+    import numpy as np
+    from duo_attn.patch import load_full_attention_heads
+    from duo_attn.utils import load_attn_pattern, save_full_attention_heads, sparsify_attention_heads
+
+    heads = np.random.RandomState(0).rand(4, 8)
+    save_full_attention_heads(torch.tensor(heads), str(tmp_path / "full_attention_heads.tsv"))
+    (tmp_path / "config.json").write_text(json.dumps({"sink_size": 64, "recent_size": 256}))
+    got, sink, recent = load_attn_pattern(str(tmp_path))
+    assert (sink, recent) == (64, 256) and got.shape == (4, 8)
+    assert np.allclose(got, heads, atol=1e-6)
+    again = np.asarray(load_full_attention_heads(str(tmp_path)))
+    assert np.allclose(again, heads, atol=1e-6)
+    binar, sp = sparsify_attention_heads(got.copy(), None, 0.5)
+    assert set(np.unique(binar)) <= {0.0, 1.0} and abs(sp - 0.5) < 0.07
+
+
+def test_to_device_contract():
+    """single device passes through; a device list without a mode is an error; TP points at duo_attn.tp"""
+    from duo_attn.utils import to_device
+
+    m = torch.nn.Linear(2, 2)
+    assert to_device(m, "cpu") is m
+    with pytest.raises(ValueError):
+        to_device(m, [0, 1])
+    with pytest.raises(NotImplementedError, match="shard_model_for_tp"):
+        to_device(m, [0, 1], enable_tp=True)
