@@ -41,6 +41,11 @@ class DecodeStepGraph:
         # host mirror moved while the Python code ran
         kv_cache.kv_seq_len_list[:], kv_cache.streaming_kv_seq_len_list[:] = host
         kv_cache.sync_device_state()
+        self._expected = self._host_counters()
+
+    def _host_counters(self):
+        c = self.cache
+        return (tuple(c.kv_seq_len_list), tuple(c.streaming_kv_seq_len_list))
 
     def _body(self):
         c = self.cache
@@ -55,8 +60,16 @@ class DecodeStepGraph:
         return out
 
     def replay(self):
-        """one decode step; returns the (static) output of ``step_fn`` captured at construction"""
+        """one decode step; returns the (static) output of ``step_fn`` captured at construction.
+
+        The kernels of the captured step read the cache lengths from HBM.  Anything that moved the HOST counters
+        since the last replay without going through the graph — ``clear()``, ``evict_last()``, an eager prefill of
+        the next prompt (``put_full_kv`` / ``update_streaming_kv``) — leaves that device copy stale, so the host
+        counters are compared with what the last replay left and re-uploaded when they differ (one small H2D
+        copy, outside the graph).  The same graph therefore serves prompt after prompt."""
         c = self.cache
+        if self._host_counters() != self._expected:
+            c.sync_device_state()
         if max(c.kv_seq_len_list) + 1 > c.max_size:
             raise ValueError(
                 f"Trying to put 1 KVs into a cache with max size {c.max_size}, current size: {max(c.kv_seq_len_list)}."
@@ -68,4 +81,5 @@ class DecodeStepGraph:
             c.streaming_kv_seq_len_list[i] = min(c.streaming_kv_seq_len_list[i] + 1, W)
         if self.evict_after:
             c.evict_last(self.evict_after)
+        self._expected = self._host_counters()
         return self.output

@@ -241,10 +241,11 @@ def static_forward_ref(q, k, v, cache: StaticCacheRef, layer_idx: int, pos0: int
 
 
 def tuple_forward_ref(q, k, v, past: Optional[Tuple[torch.Tensor, torch.Tensor]], nf: int, sink: int,
-                      recent: int, round_p=True, out_dtype=None):
+                      recent: int, round_p=True, out_dtype=None, return_budget=False):
     """Post-RoPE part of llama_duo_attention_forward_one_way_reordered (reference llama.py:146-306).
     q [B,S,Hq,D], k/v [B,S,Hkv,D] already rotated.  past = (full_KV [2B,nf,N,D],
-    streaming_KV [2B,ns,n,D]) or None.  Returns (attn_output [B,S,Hq,D], new past)."""
+    streaming_KV [2B,ns,n,D]) or None.  Returns (attn_output [B,S,Hq,D], new past) — plus the P-rounding
+    error budget of flash_attn_func_ref when ``return_budget``."""
     B, S, Hq, D = q.shape
     Hkv = k.shape[2]
     G = Hq // Hkv
@@ -256,20 +257,22 @@ def tuple_forward_ref(q, k, v, past: Optional[Tuple[torch.Tensor, torch.Tensor]]
         fv = torch.cat([pf[B:], fv], dim=1)
         sk = torch.cat([ps[:B], sk], dim=1)
         sv = torch.cat([ps[B:], sv], dim=1)
+    kw = dict(causal=True, round_p=round_p, out_dtype=out_dtype, return_budget=True)
     if S == kv_seq_len:
-        out = flash_attn_func_ref(q, k, v, causal=True, round_p=round_p, out_dtype=out_dtype)
+        out, bud = flash_attn_func_ref(q, k, v, **kw)
     else:
         outs = []
         if nf > 0:
-            outs.append(flash_attn_func_ref(q[:, :, :nf * G], fk, fv, round_p=round_p, out_dtype=out_dtype))
+            outs.append(flash_attn_func_ref(q[:, :, :nf * G], fk, fv, **kw))
         if Hkv - nf > 0:
-            outs.append(flash_attn_func_ref(q[:, :, nf * G:], sk, sv, round_p=round_p, out_dtype=out_dtype))
-        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)
+            outs.append(flash_attn_func_ref(q[:, :, nf * G:], sk, sv, **kw))
+        out = outs[0][0] if len(outs) == 1 else torch.cat([o[0] for o in outs], dim=2)
+        bud = outs[0][1] if len(outs) == 1 else torch.cat([o[1] for o in outs], dim=2)
     if sk.shape[1] > sink + recent:
         sk = torch.cat([sk[:, :sink], sk[:, -recent:]], dim=1)
         sv = torch.cat([sv[:, :sink], sv[:, -recent:]], dim=1)
     new_past = (torch.cat([fk, fv], dim=0).transpose(1, 2), torch.cat([sk, sv], dim=0).transpose(1, 2))
-    return out, new_past
+    return (out, new_past, bud) if return_budget else (out, new_past)
 
 
 def rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:

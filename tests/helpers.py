@@ -25,6 +25,11 @@ def heads_from_counts(counts, num_kv_heads):
     return [[1.0] * nf + [0.0] * (num_kv_heads - nf) for nf in counts]
 
 
+# measured error of every attn_close call of the session (what -> numbers); tests/conftest.py writes it to
+# gpurun_out/parity_report.json at the end of a GPU run, and the round's copy is committed as profiles/parity_rNN.json
+PARITY_LOG = {}
+
+
 def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: torch.Tensor = None):
     """Parity bar for bf16 attention outputs against the EXACT-P fp32 oracle.
 
@@ -47,10 +52,21 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
     tol = 1e-3 * r.abs() + (2.0 ** -8) * r.abs() + 1e-3 * rms
     if budget is not None:
         tol = tol + (2.0 ** -8) * budget.float().cpu()
+    err_rms = (o - r).pow(2).mean().sqrt()
+    if what and o.numel():
+        PARITY_LOG[what] = {
+            "n": int(o.numel()),
+            "max_abs_err": float(err.max()),
+            "rms_err": float(err_rms),
+            "rms_ref": float(rms),
+            "rms_err_over_rms_ref": float(err_rms / rms) if float(rms) > 0 else 0.0,
+            "rms_bar": 2.5e-3,
+            "worst_err_over_elementwise_tol": float((err / tol.clamp_min(1e-30)).max()),
+            "p_rounding_budget": budget is not None,
+        }
     bad = err > tol
     assert not bad.any(), (
         f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max():.3e} "
         f"at ref {r.flatten()[err.argmax()]:.3e}, rms {rms:.3e}"
     )
-    err_rms = (o - r).pow(2).mean().sqrt()
     assert err_rms <= 2.5e-3 * rms, f"{what}: rms err {err_rms:.3e} vs rms(ref) {rms:.3e}"

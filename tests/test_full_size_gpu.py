@@ -190,8 +190,13 @@ def test_constant_value_rows_give_that_vector_at_128k():
 
 def test_cfg5_int4_decode_3m_tokens():
     """int4 pools, 3.3M cached tokens, one layer with 2 retrieval + 2 streaming kv heads: against exact fp32
-    attention over pools dequantised in torch with the reference's two fp16 roundings."""
+    attention over pools dequantised by the oracle (oracle/int4_oracle.py, pinned to the reference's own
+    kernel by tests/test_int4_golden.py; its torch form runs on the device, and a sample of rows is
+    re-checked here against the numpy form)."""
+    import numpy as np
+
     from duo_attn import _hip
+    from oracle.int4_oracle import dequantize_int4_ref, dequantize_int4_torch
 
     g = torch.Generator(device=DEV).manual_seed(11)
     G, nf, ns, N, W = 4, 2, 2, 3_300_000, 384
@@ -204,10 +209,8 @@ def test_cfg5_int4_decode_3m_tokens():
         sz[..., 1] = (torch.randn(h, T, generator=g, device=DEV)).to(torch.float16)
         return q, sz.permute(1, 0, 2)
 
-    def dequant(qp, sz):     # [T, 64] u8, [T, 2] f16 -> [T, 128] fp16 values as fp32
-        hi, lo = (qp >> 4).to(torch.float16), (qp & 15).to(torch.float16)
-        n = torch.stack([hi, lo], -1).reshape(qp.shape[0], 128)
-        return ((n * sz[:, :1]) + sz[:, 1:2]).float()       # fp16 multiply, then fp16 add: two roundings
+    def dequant(qp, sz):     # [T, 64] u8, [T, 2] f16 -> [T, 128] fp16 values as fp32: the oracle's function
+        return dequantize_int4_torch(qp, sz).float()
 
     q = _randn((Hq, D), g, torch.float16)
     out = torch.empty_like(q)
@@ -218,6 +221,10 @@ def test_cfg5_int4_decode_3m_tokens():
     full = _hip.make_int4_pool(fkq, fksz, fvq, fvsz, N, 0)
     stream = _hip.make_int4_pool(skq, sksz, svq, svsz, W, nf * G)
     _hip.attn_decode_int4(q, out, G, full, stream, scale)
+    rows = torch.randint(0, N, (8192,), generator=g, device=DEV)
+    sp, ssz = fkq[rows, 0].cpu(), fksz[rows, 0].cpu()
+    assert np.array_equal(dequantize_int4_torch(fkq[rows, 0], fksz[rows, 0]).cpu().numpy().view(np.uint16),
+                          dequantize_int4_ref(sp.numpy(), ssz[:, 0].numpy(), ssz[:, 1].numpy()).view(np.uint16))
     ref = torch.empty(Hq, D, device=DEV)
     bud = torch.empty_like(ref)
     one = torch.ones(1, dtype=torch.long, device=DEV)

@@ -487,6 +487,49 @@ def test_graph_replayed_decode_equals_eager(evict):
         assert torch.equal(a, b)
 
 
+def test_graph_reused_after_clear_and_new_prefill_equals_eager():
+    """the device-side lengths must follow host-side changes made outside the graph.  One captured
+    graph serves a second prompt of a different length (clear, eager prefill, replay) and a rewind
+    (evict_last), each time bit-equal to the eager decode of the same state."""
+    from duo_attn.graph import DecodeStepGraph
+    from duo_attn.patch._duo import duo_static_attention_core
+
+    counts, Hq, Hkv, sink, recent = [1, 3, 0, 4], 16, 4, 4, 12
+    cache_e, step_e, outs_e = _decode_loop_setup(counts, Hq, Hkv, sink, recent, 13, 96, seed=23)
+    cache_g, step_g, outs_g = _decode_loop_setup(counts, Hq, Hkv, sink, recent, 13, 96, seed=23)
+    graph = DecodeStepGraph(cache_g, step_g, evict_after=0)
+
+    def both(n):
+        for s in range(n):
+            step_e()
+            graph.replay()
+            torch.cuda.synchronize()
+            for a, b in zip(outs_g, outs_e):
+                assert torch.equal(a, b), f"step {s}"
+        assert cache_g.kv_seq_len_list == cache_e.kv_seq_len_list
+        assert cache_g.device_state.cpu()[:, 0].tolist() == cache_e.kv_seq_len_list
+        assert cache_g.device_state.cpu()[:, 1].tolist() == cache_e.streaming_kv_seq_len_list
+
+    both(3)
+    # second prompt: longer than the first, prefilled eagerly in two chunks on both caches
+    g = torch.Generator().manual_seed(99)
+    mk = lambda S, h: _rand((1, S, h, D), g)
+    for c in (cache_e, cache_g):
+        c.clear()
+    for S in (29, 12):
+        pos = cache_e.kv_seq_len
+        for li in range(len(counts)):
+            q, k, v = mk(S, Hq), mk(S, Hkv), mk(S, Hkv)
+            for c in (cache_e, cache_g):
+                duo_static_attention_core(q.clone().to(DEV), k.clone().to(DEV), v.clone().to(DEV), c, li, pos, 1.0, 1e4)
+    both(4)
+    for c in (cache_e, cache_g):     # rewind three tokens on the host side only
+        c.evict_last(3)
+    both(2)
+    for a, b in zip(_pool_snapshot(cache_g), _pool_snapshot(cache_e)):
+        assert torch.equal(a, b)
+
+
 def test_device_state_add_clamps():
     h = _hip()
     st = torch.tensor([[5, 3, 5, 0], [0, 12, 7, 0], [100, 11, 100, 0]], dtype=torch.int32, device=DEV)

@@ -1,0 +1,191 @@
+"""GPU: the TUPLE-cache path on the HIP backend, numerically pinned.
+
+(1) duo_attention_forward_one_way_reordered on the HIP backend against tests/golden/tuple_a.npz — outputs of the
+    reference's own tuple forward (llama.py:146-306): per-step attention output with the bf16-P budget of the
+    static twin, retrieval / streaming caches bit for bit.
+(2) a HuggingFace Llama patched with enable_duo_attention_eval, sink + recent SMALLER than the context (so the
+    streaming segment really is sink ++ recent, evicting): every attention call the model makes is recorded and
+    recomputed with the oracle's flash_attn_func_ref; logits against the same patched model driven by the oracle.
+(3) enable_tuple_kv_cache alone (the full-attention baseline, tuple_kv_cache.py:38-120) against the unpatched HF
+    model, with the same per-call oracle check.
+"""
+import copy
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import attn_close
+from oracle.duo_oracle import OracleBackend, flash_attn_func_ref, tuple_forward_ref
+from test_golden_and_model_gpu import _rel, tiny
+from test_oracle_golden import _hf_cos_sin, bf16, load, split_hidden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Sel(torch.nn.Module):
+    def __init__(self, lo, hi):
+        super().__init__()
+        self.lo, self.hi = lo, hi
+
+    def forward(self, x):
+        return x[..., self.lo:self.hi].clone()
+
+
+def test_hip_tuple_forward_reproduces_reference_golden():
+    from duo_attn.patch._duo import duo_attention_forward_one_way_reordered as fwd
+
+    g = load("tuple_a.npz")
+    Hq, Hkv, D, sink, recent, nf = (int(x) for x in g["dims"])
+    theta = float(g["theta"])
+    m = torch.nn.Module()
+    m.config = types.SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=Hq * D)
+    m.head_dim = D
+    m.q_proj, m.k_proj, m.v_proj, m.o_proj = (torch.nn.Identity(), Sel(0, Hkv * D),
+                                              Sel(Hq * D - Hkv * D, Hq * D), torch.nn.Identity())
+    m.sink_size, m.recent_size = sink, recent
+    m.register_buffer("full_attention_heads", torch.tensor([1.0] * nf + [0.0] * (Hkv - nf)))
+    m = m.to(DEV)
+    past, ref_past, pos = None, None, 0
+    steps = [int(s) for s in g["steps"]]
+    assert sum(steps) > sink + recent, "the fixture must evict, or the streaming path is not exercised"
+    from duo_attn.patch.tuple_kv_cache import hf_apply_rotary_pos_emb
+
+    for si, S in enumerate(steps):
+        h = bf16(g[f"h_{si}"])
+        cos, sin = _hf_cos_sin(theta, D, pos, S)
+        out, _, past = fwd(m, h.to(DEV), past_key_value=past, use_cache=True,
+                           position_embeddings=(cos.to(DEV), sin.to(DEV)))
+        # budget (sum_j p_j |v_j|) from the oracle on the same inputs
+        q, k, v = split_hidden(h, Hq, Hkv, D)
+        q, k = hf_apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)
+        exact, ref_past, bud = tuple_forward_ref(q, k, v, ref_past, nf, sink, recent, round_p=False,
+                                                 out_dtype=torch.float32, return_budget=True)
+        golden = bf16(g[f"o_{si}"]).view(1, S, Hq, D).float()
+        attn_close(out.view(1, S, Hq, D), exact, f"tuple step {si} vs oracle", bud if S > 1 else None)
+        attn_close(out.view(1, S, Hq, D), golden, f"tuple step {si} vs reference golden",
+                   (bud if S > 1 else 0 * bud) + golden.abs())
+        pos += S
+    # the caches are data movement + HF's bf16 rotary: bit-identical to the reference's
+    assert torch.equal(past[0].cpu(), bf16(g["past_full"]))
+    assert torch.equal(past[1].cpu(), bf16(g["past_stream"]))
+
+
+class Recorder:
+    """Wraps the HIP backend and keeps a CPU copy of every attention call (inputs and result)."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.calls = []
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def attention(self, q, out, group, full, stream, scale):
+        self.inner.attention(q, out, group, full, stream, scale)
+
+        def cp(desc):
+            if desc is None or desc[0] <= 0:
+                return None
+            n, off, a, b = desc
+            cpu = lambda seg: None if seg is None else (seg[0].detach().cpu().clone(), seg[1].detach().cpu().clone())
+            return n, off, cpu(a), cpu(b)
+
+        self.calls.append((q.detach().cpu().clone(), out.detach().cpu().clone(), group, cp(full), cp(stream), scale))
+
+
+def check_calls_against_oracle(calls, what):
+    """every recorded attention call == flash_attn_func over cat(segA, segB), bottom-right causal"""
+    assert calls
+    for ci, (q, out, group, full, stream, scale) in enumerate(calls):
+        for desc in (full, stream):
+            if desc is None:
+                continue
+            n, off, a, b = desc
+            ks = [t[0] for t in (a, b) if t is not None and t[0].shape[0] > 0]
+            vs = [t[1] for t in (a, b) if t is not None and t[0].shape[0] > 0]
+            kk, vv = torch.cat(ks, 0), torch.cat(vs, 0)
+            qq = q[:, off:off + n * group]
+            exact, bud = flash_attn_func_ref(qq[None], kk[None], vv[None], causal=True, softmax_scale=scale,
+                                             round_p=False, out_dtype=torch.float32, return_budget=True)
+            attn_close(out[None, :, off:off + n * group], exact, f"{what}: call {ci}", bud if q.shape[0] > 1 else None)
+
+
+def test_tuple_model_with_evicting_window_matches_oracle():
+    from duo_attn import backend
+    from duo_attn.patch import enable_duo_attention_eval
+
+    base = tiny("llama", seed=5)
+    heads = np.array([[0.0, 1.0], [1.0, 0.0], [0.0, 0.0]])
+    sink, recent = 16, 48                                  # window 64 << 500-token context
+    model = copy.deepcopy(base)
+    enable_duo_attention_eval(model, heads.copy(), sink, recent)
+    ids = torch.randint(0, 211, (1, 500), generator=torch.Generator().manual_seed(6)).to(DEV)
+    chunks = (200, 150, 149, 1)
+    rec = Recorder(backend.HipBackend())
+    backend._set_backend_for_testing(rec)
+    try:
+        past, pos, logits = None, 0, []
+        with torch.no_grad():
+            for c in chunks:
+                o = model(input_ids=ids[:, pos:pos + c], past_key_values=past, use_cache=True)
+                past = o.past_key_values
+                logits.append(o.logits.float().cpu())
+                pos += c
+    finally:
+        backend._set_backend_for_testing(None)
+    # cache shapes: retrieval part grows, streaming part is capped at sink + recent
+    assert past[0][0].shape == (2, 1, 500, 128) and past[0][1].shape == (2, 1, 64, 128)
+    assert past[2][0].shape == (2, 0, 500, 128) and past[2][1].shape == (2, 2, 64, 128)
+    # streaming segment handed to the kernel after the first chunk is the truncated window, not the context
+    later = [c for c in rec.calls if c[4] is not None and c[4][2] is not None]
+    assert later and all(c[4][2][0].shape[0] <= sink + recent for c in later)
+    check_calls_against_oracle(rec.calls, "duo tuple model")
+
+    # the same patched model driven by the oracle on the CPU (host path pinned by test_oracle_golden.py)
+    cpu_model = copy.deepcopy(base).to("cpu")
+    enable_duo_attention_eval(cpu_model, heads.copy(), sink, recent)
+    backend._set_backend_for_testing(OracleBackend())
+    try:
+        past, pos = None, 0
+        with torch.no_grad():
+            for i, c in enumerate(chunks):
+                o = cpu_model(input_ids=ids[:, pos:pos + c].cpu(), past_key_values=past, use_cache=True)
+                past = o.past_key_values
+                pos += c
+                assert _rel(logits[i], o.logits) < 2e-2, (i, _rel(logits[i], o.logits))
+    finally:
+        backend._set_backend_for_testing(None)
+    # and it is NOT full attention: the unpatched model's logits differ clearly once the window has evicted
+    with torch.no_grad():
+        want = base(input_ids=ids).logits[:, -1:, :]
+    assert _rel(logits[-1], want.cpu()) > 5e-2
+
+
+@pytest.mark.parametrize("family", ["llama", "mistral"])
+def test_tuple_full_attention_baseline_matches_hf(family):
+    from duo_attn import backend
+    from duo_attn.patch.tuple_kv_cache import enable_tuple_kv_cache
+
+    ref = tiny(family, seed=7)
+    model = copy.deepcopy(ref)
+    enable_tuple_kv_cache(model)
+    ids = torch.randint(0, 211, (1, 420), generator=torch.Generator().manual_seed(8)).to(DEV)
+    rec = Recorder(backend.HipBackend())
+    backend._set_backend_for_testing(rec)
+    try:
+        past, pos = None, 0
+        with torch.no_grad():
+            for c in (260, 157, 1, 1, 1):
+                out = model(input_ids=ids[:, pos:pos + c], past_key_values=past, use_cache=True)
+                past = out.past_key_values
+                pos += c
+                want = ref(input_ids=ids[:, :pos]).logits[:, -1:, :]
+                assert out.logits.shape == want.shape and out.logits.dtype == torch.float32
+                assert _rel(out.logits, want) < 3e-2, (c, _rel(out.logits, want))
+    finally:
+        backend._set_backend_for_testing(None)
+    assert len(past) == 3 and past[0][0].shape == (1, 2, 420, 128) and past[0][1].shape == (1, 2, 420, 128)
+    check_calls_against_oracle(rec.calls, f"{family} full-attention tuple baseline")
