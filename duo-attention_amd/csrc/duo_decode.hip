@@ -58,7 +58,17 @@ struct DecodeParams {
     int64_t app_ts, app_hs;
     float pos;
     float inv_freq[64];
+    // ---- single-launch step (duo_decode_step_bf16): merge + streaming-pool update folded into this kernel.
+    //      tickets[2*h] counts the workgroups of kv head h (global index: retrieval heads, then streaming heads)
+    //      that have published their partial, tickets[2*h+1] the mergers that have finished; tickets[1023] is
+    //      a give-up flag.  All zero on entry, all zero again on exit.
+    int32_t one_launch;
+    int32_t *tickets;
+    uint32_t ws_bytes;       // bytes of the partial workspace behind ws_ml (buffer-descriptor bound)
 };
+
+constexpr int kTicketWords = DUO_DECODE_TICKET_BYTES / 4;
+constexpr int kSpinLimit = 1 << 22;   // polls (with s_sleep) before a merger gives up: far beyond any real wait
 
 __device__ __forceinline__ void unpack8(const u32x4 &w, float (&f)[8]) {
     f[0] = bf16_lo(w.x); f[1] = bf16_hi(w.x);
@@ -170,10 +180,125 @@ __device__ __forceinline__ void consume_rows(const u32x4 (&kbuf)[4], const u32x4
     }
 }
 
+struct MergeParams {
+    const float *ws_ml;
+    const float *ws_acc;
+    bf16_t *out;
+    int64_t out_head_stride;
+    int32_t max_splits;
+    // q-head ranges [begin,end) with their split counts; ranges with <=1 split are skipped
+    int32_t qh_begin[2], qh_end[2], splits[2];
+};
+
+// Four workgroups (256 threads) per q head, one per 32-dim quarter: 32 split lanes x 8 dim quads, so the
+// ~128 partials of a retrieval head are ONE batch of loads per thread (m, l and four accumulator dims of its
+// four splits, issued together).  No separate pass for the global maximum: every split lane reduces its own
+// splits against its own running maximum, and the 32 lanes are combined through LDS with their maxima.
+// SC1: the partials were published write-through by other workgroups of the SAME launch (single-launch
+// step) — read them with sc1 loads (served by L2 / memory, never by this CU's possibly stale L1).
+template <bool SC1>
+__device__ __forceinline__ void duo_decode_merge_task(const float *ws_ml, const float *ws_acc, uint32_t ws_bytes,
+                                                      bf16_t *out, int64_t out_head_stride, int max_splits, int qh,
+                                                      int quarter, int splits) {
+    const int sl = threadIdx.x >> 3;  // 0..31
+    const int dq = threadIdx.x & 7;   // dims 32*quarter + 4dq .. +3
+    const int d0 = 32 * quarter + 4 * dq;
+    const float *ml = ws_ml + (int64_t)qh * max_splits * 2;
+    const float *ac = ws_acc + (int64_t)qh * max_splits * DUO_HEAD_DIM + d0;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ws_ml, 0, ws_bytes, 0x00020000);
+    const uint32_t ml_off = (uint32_t)((const char *)ml - (const char *)ws_ml);
+    const uint32_t ac_off = (uint32_t)((const char *)ac - (const char *)ws_ml);
+    auto ld_ml = [&](int s_) -> u32x2 {
+        if constexpr (SC1) return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ml_off + s_ * 8, 0, 16));
+        else return *reinterpret_cast<const u32x2 *>(ml + s_ * 2);
+    };
+    auto ld_ac = [&](int s_) -> f32x4 {
+        if constexpr (SC1) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ac_off + s_ * (DUO_HEAD_DIM * 4), 0, 16));
+        else return *reinterpret_cast<const f32x4 *>(ac + (int64_t)s_ * DUO_HEAD_DIM);
+    };
+
+    __shared__ float sm[32];
+    __shared__ float slm[32][8];
+    __shared__ f32x4 so[32][8];
+
+    float m = kNegSentinel, Lsum = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+    for (; s + 96 < splits; s += 128) {       // 4 splits (stride 32) per step, all 8 loads in flight together
+        u32x2 w[4];
+        f32x4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = ld_ml(s + 32 * u);
+            a[u] = ld_ac(s + 32 * u);
+        }
+        float mx = m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, __uint_as_float(w[u].x));
+        const float f = fast_exp2(m - mx);
+        Lsum *= f;
+        o = o * f;
+        m = mx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wu = fast_exp2(__uint_as_float(w[u].x) - m);
+            Lsum = fmaf(__uint_as_float(w[u].y), wu, Lsum);
+            o = o + a[u] * wu;
+        }
+    }
+    for (; s < splits; s += 32) {
+        const u32x2 w = ld_ml(s);
+        const f32x4 a = ld_ac(s);
+        const float mx = fmaxf(m, __uint_as_float(w.x));
+        const float f = fast_exp2(m - mx), wu = fast_exp2(__uint_as_float(w.x) - mx);
+        Lsum = fmaf(__uint_as_float(w.y), wu, Lsum * f);
+        o = o * f + a * wu;
+        m = mx;
+    }
+    if (dq == 0) sm[sl] = m;
+    slm[sl][dq] = Lsum;
+    so[sl][dq] = o;
+    __syncthreads();
+    if (sl == 0) {
+        float M = sm[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) M = fmaxf(M, sm[i]);
+        float LL = 0.f;
+        f32x4 oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float f = fast_exp2(sm[i] - M);   // lanes without a split: exp2(-1e30 - M) = 0
+            LL = fmaf(slm[i][dq], f, LL);
+            oo = oo + so[i][dq] * f;
+        }
+        const float inv = 1.f / LL;
+        u32x2 w;
+        w.x = pack_bf16x2(oo.x * inv, oo.y * inv);
+        w.y = pack_bf16x2(oo.z * inv, oo.w * inv);
+        *reinterpret_cast<u32x2 *>(out + (int64_t)qh * out_head_stride + d0) = w;
+    }
+}
+
+// block of the stand-alone epilogue launch -> (q head, 32-dim quarter)
+__device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
+    int qh = blk >> 2;
+    int splits;
+    const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
+    if (qh < n0) {
+        qh += P.qh_begin[0];
+        splits = P.splits[0];
+    } else {
+        qh = qh - n0 + P.qh_begin[1];
+        splits = P.splits[1];
+    }
+    duo_decode_merge_task<false>(P.ws_ml, P.ws_acc, 0, P.out, P.out_head_stride, P.max_splits, qh, blk & 3, splits);
+}
+
+
 // grid.x = (kv head, split) pairs of the full class then of the streaming class
 // grid.y = group / GT
 template <int GT, bool NT, bool PREFETCH, bool FUSED>
-__global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P) {
+__global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P, const CompressParams CP) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar loop control
     const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
@@ -403,122 +528,126 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     }
     __syncthreads();
 
-    for (int idx = threadIdx.x; idx < GT * DUO_HEAD_DIM; idx += 256) {
-        const int g = idx >> 7;
-        const int d = idx & 127;
-        float M = s_ml[0][g][0];
+    const bool publish = FUSED && P.one_launch && splits > 1;
+    if (!publish) {
+        for (int idx = threadIdx.x; idx < GT * DUO_HEAD_DIM; idx += 256) {
+            const int g = idx >> 7;
+            const int d = idx & 127;
+            float M = s_ml[0][g][0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
-        float Lsum = 0.f, o = 0.f;
+            for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
+            float Lsum = 0.f, o = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float sc = fast_exp2(s_ml[w][g][0] - M);
-            Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
-            o = fmaf(s_acc[w][g][d], sc, o);
-        }
-        const int qh = qh0 + g;
-        if (splits == 1) {
-            // single split: this workgroup saw every key of the head
-            P.out[(int64_t)qh * P.out_head_stride + d] = (bf16_t)f32_to_bf16_bits(o / Lsum);
-        } else {
-            const int64_t slot = (int64_t)qh * P.max_splits + split;
-            P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
-            if (d == 0) {
-                P.ws_ml[slot * 2 + 0] = M;
-                P.ws_ml[slot * 2 + 1] = Lsum;
+            for (int w = 0; w < 4; ++w) {
+                const float sc = fast_exp2(s_ml[w][g][0] - M);
+                Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
+                o = fmaf(s_acc[w][g][d], sc, o);
+            }
+            const int qh = qh0 + g;
+            if (splits == 1) {
+                // single split: this workgroup saw every key of the head
+                P.out[(int64_t)qh * P.out_head_stride + d] = (bf16_t)f32_to_bf16_bits(o / Lsum);
+            } else {
+                const int64_t slot = (int64_t)qh * P.max_splits + split;
+                P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
+                if (d == 0) {
+                    P.ws_ml[slot * 2 + 0] = M;
+                    P.ws_ml[slot * 2 + 1] = Lsum;
+                }
             }
         }
+    } else {
+        // Single-launch step: the partial is PUBLISHED to other workgroups of this launch — write-through
+        // (sc1) 16-byte stores, so no release fence (an L2 write-back per workgroup) is needed; same values
+        // as the loop above, four dims per thread.
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.ws_ml, 0, P.ws_bytes, 0x00020000);
+        const uint32_t acc_base = (uint32_t)((const char *)P.ws_acc - (const char *)P.ws_ml);
+        for (int idx = threadIdx.x; idx < GT * (DUO_HEAD_DIM / 4); idx += 256) {
+            const int g = idx >> 5;
+            const int d = (idx & 31) * 4;
+            float M = s_ml[0][g][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
+            float Lsum = 0.f;
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float sc = fast_exp2(s_ml[w][g][0] - M);
+                Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
+                o.x = fmaf(s_acc[w][g][d + 0], sc, o.x);
+                o.y = fmaf(s_acc[w][g][d + 1], sc, o.y);
+                o.z = fmaf(s_acc[w][g][d + 2], sc, o.z);
+                o.w = fmaf(s_acc[w][g][d + 3], sc, o.w);
+            }
+            const uint32_t slot = (uint32_t)(qh0 + g) * P.max_splits + split;
+            u32x4 ow = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ow, rsrc, acc_base + (slot * DUO_HEAD_DIM + d) * 4, 0, 16);
+            if (d == 0) {
+                const unsigned long long ml = ((unsigned long long)__float_as_uint(Lsum) << 32) | __float_as_uint(M);
+                __hip_atomic_store(reinterpret_cast<unsigned long long *>(P.ws_ml + (size_t)slot * 2), ml,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
     }
-}
 
-struct MergeParams {
-    const float *ws_ml;
-    const float *ws_acc;
-    bf16_t *out;
-    int64_t out_head_stride;
-    int32_t max_splits;
-    // q-head ranges [begin,end) with their split counts; ranges with <=1 split are skipped
-    int32_t qh_begin[2], qh_end[2], splits[2];
-};
-
-// Four workgroups (256 threads) per q head, one per 32-dim quarter: 32 split lanes x 8 dim quads, so the
-// ~128 partials of a retrieval head are ONE batch of four loads per thread instead of four dependent
-// batches.  Two passes so that the accumulation has no serial max/rescale chain:
-//   1. M = max over the splits' m (every thread scans a strided share of the <= 1024 floats);
-//   2. each split lane sums w_s * acc_s and w_s * l_s with w_s = exp2(m_s - M), 4 splits per step.
-__device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
-    int qh = blk >> 2;
-    const int quarter = blk & 3;
-    int splits;
-    {
-        const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
-        if (qh < n0) {
-            qh += P.qh_begin[0];
-            splits = P.splits[0];
+    // ---- single-launch step: the merge of the partials and the streaming-pool update happen here ---------
+    // (grid.y == 1 is guaranteed by the launcher, so the workgroups of a kv head are exactly its `splits`)
+    if constexpr (FUSED) {
+        if (!P.one_launch) return;
+        bool do_compress = false;
+        if (splits == 1) {
+            // this workgroup saw every cached row of the head; its waves left the scan through the barrier above
+            do_compress = ci == 1;
         } else {
-            qh = qh - n0 + P.qh_begin[1];
-            splits = P.splits[1];
+            // The partial went out write-through and drained above; after the barrier one lane takes the head's
+            // ticket (MI355X inter-workgroup hand-off, form R1).  The LAST min(splits, 4 GT) arrivals of the head
+            // stay as mergers: merger j takes the (q head, 32-dim quarter) tasks j, j + NM, ...; every merger
+            // first waits until all `splits` partials are published (bounded spin).
+            __shared__ int s_ticket;
+            int32_t *cnt = P.tickets + 2 * ((ci ? P.cls[0].n_kv_heads : 0) + kvh);
+            __syncthreads();
+            if (threadIdx.x == 0)
+                s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int n = s_ticket;
+            const int n_tasks = 4 * GT;
+            const int NM = min(splits, n_tasks);
+            if (n < splits - NM) return;
+            const int j = n - (splits - NM);
+            if (threadIdx.x == 0) {
+                int spins = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < splits) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit) {   // never seen; better a flagged wrong answer than a hung GPU
+                        __hip_atomic_store(P.tickets + kTicketWords - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                // no acquire fence: the partials were stored sc1 and are read back with sc1 loads
+            }
+            __syncthreads();
+            for (int task = j; task < n_tasks; task += NM) {
+                duo_decode_merge_task<true>(P.ws_ml, P.ws_acc, P.ws_bytes, P.out, P.out_head_stride, P.max_splits,
+                                            qh0 + (task >> 2), task & 3, splits);
+                __syncthreads();
+            }
+            do_compress = ci == 1 && j == 0;   // (a streaming class scanned in splits: an all-streaming layer)
+            // the last merger to finish re-arms the head's tickets for the next launch
+            if (threadIdx.x == 0) {
+                const int d = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d == NM - 1) {
+                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
-    }
-    const int sl = threadIdx.x >> 3;  // 0..31
-    const int dq = threadIdx.x & 7;   // dims 32*quarter + 4dq .. +3
-    const int d0 = 32 * quarter + 4 * dq;
-    const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
-    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
-
-    __shared__ float red[4];
-    __shared__ float slm[32][8];
-    __shared__ f32x4 so[32][8];
-
-    float M = kNegSentinel;
-    for (int s = threadIdx.x; s < splits; s += 256) M = fmaxf(M, ml[s * 2]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = M;
-    __syncthreads();
-    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-
-    float Lsum = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    int s = sl;
-    for (; s + 96 < splits; s += 128) {       // 4 splits (stride 32) per step
-        float w[4], l[4];
-        f32x4 a[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int su = s + 32 * u;
-            w[u] = ml[su * 2];
-            l[u] = ml[su * 2 + 1];
-            a[u] = *reinterpret_cast<const f32x4 *>(ac + (int64_t)su * DUO_HEAD_DIM);
+        if (do_compress && CP.n_heads > 0) {
+            // sink+recent update of this streaming head's K and V rows (every read of the pool by this launch
+            // is behind us: this workgroup's own scan, or — split scan — all arrivals of the head)
+            duo_stream_compress_block(CP, 2 * kvh);
+            duo_stream_compress_block(CP, 2 * kvh + 1);
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float wu = fast_exp2(w[u] - M);
-            Lsum = fmaf(l[u], wu, Lsum);
-            o = o + a[u] * wu;
-        }
-    }
-    for (; s < splits; s += 32) {
-        const float wu = fast_exp2(ml[s * 2] - M);
-        Lsum = fmaf(ml[s * 2 + 1], wu, Lsum);
-        o = o + *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM) * wu;
-    }
-    slm[sl][dq] = Lsum;
-    so[sl][dq] = o;
-    __syncthreads();
-    if (sl == 0) {
-        float LL = 0.f;
-        f32x4 oo = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            LL += slm[i][dq];
-            oo = oo + so[i][dq];
-        }
-        const float inv = 1.f / LL;
-        u32x2 w;
-        w.x = pack_bf16x2(oo.x * inv, oo.y * inv);
-        w.y = pack_bf16x2(oo.z * inv, oo.w * inv);
-        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + d0) = w;
     }
 }
 
@@ -588,6 +717,8 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.group = group;
     P.dbg = duo_get_debug_flags();
     P.fused = 0;
+    P.one_launch = 0;
+    P.tickets = nullptr;
     P.dev_state = nullptr;
     P.scale_log2e = scale * 1.4426950408889634f;
     const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
@@ -620,6 +751,8 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.max_splits = need > 1 ? need : 1;
     P.ws_ml = (float *)workspace;
     P.ws_acc = P.ws_ml ? P.ws_ml + (int64_t)n_q_heads * P.max_splits * 2 : nullptr;
+    P.ws_bytes = (uint32_t)std::min<int64_t>((int64_t)n_q_heads * P.max_splits * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float),
+                                             0xffffffffll);
     P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
     D.nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
     D.gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
@@ -640,7 +773,7 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
 }
 
 template <bool FUSED>
-static int decode_launch_split(const DecodePlan &D, hipStream_t st) {
+static int decode_launch_split(const DecodePlan &D, const CompressParams &CP, hipStream_t st) {
     if (D.nblk <= 0) return 0;
     const DecodeParams &P = D.P;
     dim3 grid(D.nblk, P.group / D.gt), block(256);
@@ -649,10 +782,10 @@ static int decode_launch_split(const DecodePlan &D, hipStream_t st) {
     const bool pf = !(fl & 8u);        // debug bit 3: no register prefetch of the next 16 tokens
 #define DUO_LAUNCH_DECODE(GT_)                                                                                      \
     do {                                                                                                            \
-        if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true, FUSED>), grid, block, 0, st, P);   \
-        else if (nt) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, false, FUSED>), grid, block, 0, st, P);   \
-        else if (pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, true, FUSED>), grid, block, 0, st, P);   \
-        else hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, false, FUSED>), grid, block, 0, st, P);          \
+        if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true, FUSED>), grid, block, 0, st, P, CP);   \
+        else if (nt) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, false, FUSED>), grid, block, 0, st, P, CP);   \
+        else if (pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, true, FUSED>), grid, block, 0, st, P, CP);   \
+        else hipLaunchKernelGGL((duo_decode_split_kernel<GT_, false, false, FUSED>), grid, block, 0, st, P, CP);          \
     } while (0)
     if (D.gt == 4) DUO_LAUNCH_DECODE(4);
     else if (D.gt == 2) DUO_LAUNCH_DECODE(2);
@@ -674,7 +807,7 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
                          workspace_bytes, D);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    rc = decode_launch_split<false>(D, st);
+    rc = decode_launch_split<false>(D, CompressParams{}, st);
     if (rc) return rc;
     // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
     if (D.n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
@@ -689,7 +822,7 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
 // both head classes with RoPE of q / the new key row and the retrieval-pool append folded in, then
 // merge + streaming-pool update.  See include/duo_attn_hip.h.
 static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream_len, const int32_t *dev_state,
-                             void *workspace, int64_t workspace_bytes, void *stream) {
+                             void *workspace, int64_t workspace_bytes, void *tickets, void *stream) {
     if (!a) return DUO_EINVAL;
     if (a->head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     const int nf = a->n_full, nkv = a->n_kv_heads, ns = nkv - nf;
@@ -734,10 +867,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
     D.P.pos = (float)a->pos;
     D.P.dev_state = dev_state;
     memcpy(D.P.inv_freq, inv_freq, sizeof(inv_freq));
-    rc = decode_launch_split<true>(D, st);
-    if (rc) return rc;
-
-    // ---- launch 2: merge + streaming-pool update -------------------------------------------------
+    // ---- streaming-pool update parameters (launch 2, or folded into launch 1) -----------------------
     CompressParams C{};
     int n_compress = 0;
     const int T = a->str_len + 1;
@@ -752,6 +882,18 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
         memcpy(C.inv_freq, inv_freq, sizeof(inv_freq));
         n_compress = 2 * ns;
     }
+    // Single launch (duo_decode_step_bf16): the kernel merges and updates the streaming pool itself.  Needs one
+    // workgroup row per kv head (group == GT), the ticket area, and room for every head's two counters.
+    const bool one = tickets != nullptr && group == D.gt && 2 * nkv < kTicketWords - 1 && !(duo_get_debug_flags() & 2u);
+    if (one) {
+        D.P.one_launch = 1;
+        D.P.tickets = (int32_t *)tickets;
+        return decode_launch_split<true>(D, C, st);
+    }
+    rc = decode_launch_split<true>(D, CompressParams{}, st);
+    if (rc) return rc;
+
+    // ---- launch 2: merge + streaming-pool update -------------------------------------------------
     if (D.n_merge + n_compress > 0) {
         hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge + n_compress), dim3(256), 0, st, D.M, 4 * D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
@@ -761,7 +903,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
 
 extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
-    return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, stream);
+    return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, nullptr, stream);
 }
 
 // Same step with the lengths and the position read on the device (see include/duo_attn_hip.h): the
@@ -776,7 +918,23 @@ extern "C" int duo_decode_layer_dev_bf16(const duo_decode_layer_args *a, const d
     if (plan.n_full > 0 && plan.full_len + 1 > plan.full_capacity) plan.full_len = plan.full_capacity - 1;
     if (plan.str_len < 1) plan.str_len = 1;
     return decode_layer_impl(&plan, nullptr, reinterpret_cast<const int32_t *>(dev_state), workspace, workspace_bytes,
-                             stream);
+                             nullptr, stream);
+}
+
+// The whole step in ONE launch: the split-KV scan as above, and behind an arrival ticket per kv head the last
+// workgroups to finish merge the partials and run the streaming pool's sink+recent update (see the end of
+// duo_decode_split_kernel).  dev_state == NULL: lengths from `a` (eager); else read on the device (graph replay).
+extern "C" int duo_decode_step_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
+                                    const duo_decode_state *dev_state, void *workspace, int64_t workspace_bytes,
+                                    void *tickets, void *stream) {
+    if (!a || !tickets) return DUO_EINVAL;
+    if (!dev_state) return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, tickets, stream);
+    duo_decode_layer_args plan = *a;
+    if (plan.full_len < 1) plan.full_len = 1;
+    if (plan.n_full > 0 && plan.full_len + 1 > plan.full_capacity) plan.full_len = plan.full_capacity - 1;
+    if (plan.str_len < 1) plan.str_len = 1;
+    return decode_layer_impl(&plan, new_stream_len, reinterpret_cast<const int32_t *>(dev_state), workspace,
+                             workspace_bytes, tickets, stream);
 }
 
 namespace {

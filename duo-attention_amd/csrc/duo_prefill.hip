@@ -100,6 +100,18 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     float mrow = -INFINITY;
     float lsum = 0.f;
     const float c = P.scale_log2e;
+#ifdef DUO_PSUM_MFMA
+    // Row sums on the matrix pipe: one more accumulator fed with an all-ones A operand, osum^T[d][q] =
+    // sum_k 1 * P^T[k][q] — every register of a lane holds its query row's running sum over BOTH 32-key
+    // halves (the MFMA reduces over lanes l and l^32), of the bf16-rounded P that also enters P.V.  Replaces
+    // 32 v_add_f32 per lane and tile by 4 MFMAs on a pipe that is half idle.
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+    bf16x8 ones_frag;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ones_frag[r] = F16 ? (short)0x3C00 : (short)0x3F80;
+#endif
 
     // ---- loop invariants: LDS read offsets and DMA lane offsets -----------------
     const uint32_t smem_lds = lds_addr(smem);
@@ -136,6 +148,14 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     for (int kk = 0; kk < 8; ++kk) asm volatile("" ::"v"(qfrag[kk]));
     __builtin_amdgcn_sched_barrier(0);
 
+#ifdef DUO_STATIC_PRIO
+    // static priority for the second-dispatched half of the workgroup (waves 4-7 lose VALU arbitration to the
+    // older half on every segment); no per-cluster flips
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#define DUO_SETPRIO(x)
+#else
+#define DUO_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
     // One tile.  SLOT (= t % 3) is a compile-time constant so that every LDS address of the body is
     // a loop-invariant VGPR plus an immediate: the tile loop is unrolled by the ring depth.
     auto tile_body = [&](auto slot_c, int t) {
@@ -157,7 +177,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             // ---- S^T = K . Q^T  (two 32-key blocks) ---------------------------
             f32x16 sc[2];
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_s_setprio(1);
+            DUO_SETPRIO(1);
             // kk outer, key block inner: consecutive MFMAs alternate between the two accumulators.
             // The K fragments of k-step kk+1 are requested BEFORE the MFMAs of k-step kk (two register
             // sets); left to hipcc, each step's two ds_read_b128 are issued into the same registers only after
@@ -202,7 +222,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 }
             }
 #endif
-            __builtin_amdgcn_s_setprio(0);
+            DUO_SETPRIO(0);
             // ---- mask ----------------------------------------------------------
             const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0 + qoff) : (cnt < KVBLK);
             if (need_mask) {
@@ -216,6 +236,10 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     }
             }
             // ---- online softmax (lane = one query row; partner lane^32 holds the other keys)
+#ifdef DUO_MEAS_ALT_MAX
+            // MEASUREMENT ONLY (not overflow-safe): row max / rescale decision on every other tile
+            if (!((t & 1) && t > t_begin + 1 && !need_mask)) {
+#endif
             float t0 = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
             float t1 = fmaxf(fmaxf(sc[1][0], sc[1][1]), sc[1][2]);
 #pragma unroll
@@ -240,13 +264,20 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 // (a row that has seen no key yet — possible when a key-range split starts on causal tiles
                 // beyond it — keeps m = -inf; -inf - -inf must not reach exp2)
                 const float alpha = mnew == -INFINITY ? 1.f : fast_exp2((mrow - mnew) * c);
+#ifdef DUO_PSUM_MFMA
+                osum[0] *= alpha;      // only register 0 is ever read back
+#else
                 lsum *= alpha;
+#endif
                 mrow = mnew;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
+#ifdef DUO_MEAS_ALT_MAX
+            }
+#endif
             const float mc = mrow == -INFINITY ? 0.f : mrow * c;   // all scores -inf: p = exp2(-inf - 0) = 0
             float psum = 0.f;
             bf16x8 pf[4];   // P^T B operands of the four PV k-steps (step = 2*bb + s)
@@ -259,7 +290,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     pv[r] = sc[bb][r] - mc;
 #else
                     pv[r] = fast_exp2(fmaf(sc[bb][r], c, -mc));
+#ifndef DUO_PSUM_MFMA
                     psum += pv[r];
+#endif
 #endif
                 }
 #pragma unroll
@@ -272,7 +305,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     pf[2 * bb + s] = *reinterpret_cast<bf16x8 *>(&w);
                 }
             }
+#ifndef DUO_PSUM_MFMA
             lsum += psum;
+#endif
 
             // ---- O^T += V^T . P^T ----------------------------------------------
             // k-step `step` covers keys 32*bb + 16*s + {4hi..4hi+3, 8+4hi..8+4hi+3}: key quads
@@ -291,10 +326,13 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 DUO_TR_STEP(vb, va_, VO, 1);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
+                DUO_SETPRIO(1);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[0], o[db]);
+#ifdef DUO_PSUM_MFMA
+                osum = mfma32x32x16<F16>(ones_frag, pf[0], osum);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(va, va_, VO, 2);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -302,6 +340,9 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[1], o[db]);
+#ifdef DUO_PSUM_MFMA
+                osum = mfma32x32x16<F16>(ones_frag, pf[1], osum);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(vb, va_, VO, 3);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -309,18 +350,24 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[2], o[db]);
+#ifdef DUO_PSUM_MFMA
+                osum = mfma32x32x16<F16>(ones_frag, pf[2], osum);
+#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[3], o[db]);
-                __builtin_amdgcn_s_setprio(0);
+#ifdef DUO_PSUM_MFMA
+                osum = mfma32x32x16<F16>(ones_frag, pf[3], osum);
+#endif
+                DUO_SETPRIO(0);
 #else
                 // alternative (-DDUO_PV_BUILTIN): builtin transpose reads scheduled by hipcc — measured
                 // 1.5 % slower than the hand-pipelined asm reads above (same run, nf=4 past=64K).
                 typedef __attribute__((ext_vector_type(4))) short s16x4;
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                __builtin_amdgcn_s_setprio(1);
+                DUO_SETPRIO(1);
 #pragma unroll
                 for (int step = 0; step < 4; ++step)
 #pragma unroll
@@ -333,7 +380,11 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                         vf[4] = y[0]; vf[5] = y[1]; vf[6] = y[2]; vf[7] = y[3];
                         o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
                     }
-                __builtin_amdgcn_s_setprio(0);
+#ifdef DUO_PSUM_MFMA
+#pragma unroll
+                for (int step = 0; step < 4; ++step) osum = mfma32x32x16<F16>(ones_frag, pf[step], osum);
+#endif
+                DUO_SETPRIO(0);
 #endif
             } else {
                 // debugging aid (duo_set_debug_flags bit 0): scalar LDS gathers instead of the transpose read
@@ -352,6 +403,10 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                         }
                         o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
                     }
+#ifdef DUO_PSUM_MFMA
+#pragma unroll
+                for (int step = 0; step < 4; ++step) osum = mfma32x32x16<F16>(ones_frag, pf[step], osum);
+#endif
             }
         }
 
@@ -375,7 +430,11 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     }
 
     // ---- epilogue: O^T / l -> out[q][qh][d], or the un-normalised partial -> workspace ---------
+#ifdef DUO_PSUM_MFMA
+    lsum = osum[0];                        // already summed over both key halves
+#else
     lsum += __shfl_xor(lsum, 32);
+#endif
     if (ks > 1) {
         const int64_t row = (int64_t)part_id * QBLK + wave * 32 + l31;
         float *wo = P.ws_o + row * DUO_HEAD_DIM;

@@ -107,6 +107,9 @@ _SIGNATURES = {
     "duo_decode_layer_dev_bf16": (
         ctypes.c_int, [POINTER(DecodeLayerArgs), c_void_p, c_void_p, c_int64, c_void_p],
     ),
+    "duo_decode_step_bf16": (
+        ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
+    ),
     "duo_decode_state_add": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "duo_attn_prefill_bf16": (
         ctypes.c_int,
@@ -289,19 +292,38 @@ def stream_compress(k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recen
 
 
 _DECODE_MAX_SPLITS = 512
+DECODE_TICKET_BYTES = 4096      # DUO_DECODE_TICKET_BYTES
 _workspaces = {}
+_tickets = {}
+
+
+def _stream_key(device: torch.device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return (idx, torch.cuda.current_stream(idx).cuda_stream)
 
 
 def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
-    """Per-device fp32 scratch for the split-KV partials (allocated once, reused every layer)."""
-    lib = load_library()
-    need = lib.duo_attn_decode_workspace_bytes(int(n_q_heads), _DECODE_MAX_SPLITS)
-    key = (device.type, device.index)
+    """fp32 scratch for the split-KV partials: one buffer per (device, stream, q-head count), allocated once and
+    never replaced or freed — concurrent streams do not share partials, and a captured graph's launches keep
+    pointing at live memory whatever other models decode later."""
+    key = _stream_key(device) + (int(n_q_heads),)
     ws = _workspaces.get(key)
-    if ws is None or ws.numel() * 4 < need:
+    if ws is None:
+        need = load_library().duo_attn_decode_workspace_bytes(int(n_q_heads), _DECODE_MAX_SPLITS)
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def decode_tickets(device: torch.device) -> torch.Tensor:
+    """Arrival tickets of the single-launch decode step (duo_decode_step_bf16): zero-filled once per
+    (device, stream); every launch leaves them zeroed."""
+    key = _stream_key(device)
+    t = _tickets.get(key)
+    if t is None:
+        t = torch.zeros(DECODE_TICKET_BYTES // 4, dtype=torch.int32, device=device)
+        _tickets[key] = t
+    return t
 
 
 def attn_decode(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
@@ -350,22 +372,35 @@ def _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, st
     return a
 
 
+# The single-launch step (duo_decode_step_bf16) is bit-identical to the two-launch form but measured 2-3 % SLOWER per
+# decode step on MI355X (profiles/r2_decode_one_launch.md): publishing partials to other workgroups of the same
+# launch costs more than the kernel boundary it removes.  Two launches stay the default; DUO_DECODE_ONE_LAUNCH=1
+# (or two_launch=False) selects the single launch.
+_TWO_LAUNCH_DEFAULT = os.environ.get("DUO_DECODE_ONE_LAUNCH", "0") != "1"
+
+
 def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
-                 rope_scale, rope_theta, scale) -> int:
-    """Fused decode step of one layer (one batch row).  q/out [Hq, D]; k/v [Hkv, D] new rows;
-    full_k/full_v [T, nf, D] and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
+                 rope_scale, rope_theta, scale, two_launch: bool = _TWO_LAUNCH_DEFAULT) -> int:
+    """Fused decode step of one layer (one batch row): scan + epilogue launch pair (default), or everything in
+    ONE launch (``two_launch=False``, see the note above).  q/out [Hq, D]; k/v [Hkv, D] new rows; full_k/full_v [T, nf, D]
+    and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
     lib = load_library()
     a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
                            rope_scale, rope_theta, scale)
     ws = decode_workspace(q.device, q.shape[0])
     new_len = c_int32(0)
-    _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
-           "duo_decode_layer_bf16")
+    if two_launch:
+        _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+               "duo_decode_layer_bf16")
+    else:
+        _check(lib.duo_decode_step_bf16(byref(a), byref(new_len), None, ws.data_ptr(), ws.numel() * 4,
+                                        decode_tickets(q.device).data_ptr(), _stream_ptr()), "duo_decode_step_bf16")
     return int(new_len.value)
 
 
 def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink, recent,
-                     plan_pos, rope_scale, rope_theta, scale, dev_state: torch.Tensor) -> None:
+                     plan_pos, rope_scale, rope_theta, scale, dev_state: torch.Tensor,
+                     two_launch: bool = _TWO_LAUNCH_DEFAULT) -> None:
     """The same step with lengths / position read from ``dev_state`` (int32 [4] on the GPU:
     full_len, str_len, pos, pad) — graph-capturable; the ``plan_*`` values only size the grid."""
     lib = load_library()
@@ -373,8 +408,12 @@ def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k,
     a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink,
                            recent, plan_pos, rope_scale, rope_theta, scale)
     ws = decode_workspace(q.device, q.shape[0])
-    _check(lib.duo_decode_layer_dev_bf16(byref(a), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
-           "duo_decode_layer_dev_bf16")
+    if two_launch:
+        _check(lib.duo_decode_layer_dev_bf16(byref(a), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                             _stream_ptr()), "duo_decode_layer_dev_bf16")
+    else:
+        _check(lib.duo_decode_step_bf16(byref(a), None, dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                        decode_tickets(q.device).data_ptr(), _stream_ptr()), "duo_decode_step_bf16")
 
 
 def decode_state_add(dev_states: torch.Tensor, d_full: int, d_str: int, d_pos: int, str_cap: int) -> None:

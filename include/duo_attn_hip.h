@@ -208,6 +208,24 @@ int duo_decode_layer_dev_bf16(const duo_decode_layer_args *args, const duo_decod
 int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t d_full, int32_t d_str,
                          int32_t d_pos, int32_t str_cap, void *stream);
 
+/* ---- the same step in ONE launch ------------------------------------------------------------------
+ * duo_decode_layer_bf16 / _dev_bf16 issue two launches (scan, then merge + streaming update).  Here both
+ * are folded into the scan kernel: every workgroup publishes its split-KV partial (agent-scope release) and
+ * takes a ticket of its kv head; the last min(splits, 4 * group) arrivals of a head wait until all of its
+ * partials are published (bounded spin, agent-scope acquire) and merge one (q head, 32-dim quarter) each;
+ * a streaming head's workgroup runs that head's sink+recent pool update after its own scan.  Replaces the
+ * reference's ~12 launches per layer and step (llama.py:332-425) with one; results are bit-identical to
+ * the two-launch form (same partials, same merge arithmetic).
+ * `tickets`: DUO_DECODE_TICKET_BYTES of device memory, ZERO-FILLED ONCE by the caller and owned by one
+ * stream at a time; every launch leaves it zeroed again.  dev_state NULL: lengths / position from `args`
+ * (*new_stream_len is written); non-NULL: read on the device as duo_decode_layer_dev_bf16 does.
+ * Falls back to the two launches when group is not 1, 2 or 4 (a kv head's q heads then span several
+ * workgroup rows).                                                                                   */
+#define DUO_DECODE_TICKET_BYTES 4096
+int duo_decode_step_bf16(const duo_decode_layer_args *args, int32_t *new_stream_len,
+                         const duo_decode_state *dev_state, void *workspace, int64_t workspace_bytes,
+                         void *tickets, void *stream);
+
 /* ---- prefill / chunked prefill (S >= 1): MFMA flash attention --------------
  * q/out: [S, n_q_heads, 128] with the given token/head strides.  Per head class: segA rows are all
  * visible; segB (len >= S) ends with the S query rows — query i sees segB rows 0 .. i + (len - S)

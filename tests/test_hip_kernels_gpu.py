@@ -209,10 +209,12 @@ FUSED_CASES = [
 ]
 
 
+@pytest.mark.parametrize("two_launch", [False, True])
 @pytest.mark.parametrize("case", FUSED_CASES)
-def test_decode_layer_fused(case):
-    """duo_decode_layer_bf16 (two launches: scan with RoPE + retrieval append folded in, then merge +
-    streaming update) against the oracle's step-by-step restatement of llama.py:332-425 for q_len == 1."""
+def test_decode_layer_fused(case, two_launch):
+    """duo_decode_step_bf16 (ONE launch: scan with RoPE + retrieval append folded in, merge + streaming update
+    behind per-head arrival tickets) and duo_decode_layer_bf16 (the same as two launches) against the oracle's
+    step-by-step restatement of llama.py:332-425 for q_len == 1."""
     from oracle.duo_oracle import OracleBackend
 
     group, nf, ns, full_len, str_len, sink, recent, pos = case
@@ -229,7 +231,8 @@ def test_decode_layer_fused(case):
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     out = torch.full((Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
     n = h.decode_layer(qd, kd, vd, out, nf, fkd, fvd, full_len, skd, svd, str_len, sink, recent, pos, rscale,
-                       theta, D ** -0.5)
+                       theta, D ** -0.5, two_launch=two_launch)
+    assert int(h.decode_tickets(torch.device(DEV)).abs().sum()) == 0     # re-armed (and no give-up flag)
     # inputs are read-only
     assert torch.equal(qd.cpu(), q) and torch.equal(kd.cpu(), k) and torch.equal(vd.cpu(), v)
 
@@ -262,6 +265,45 @@ def test_decode_layer_fused(case):
     # the device rotates q/k with its own sincos: allow the 1-ulp bf16 input differences through the
     # attention tolerance (rms floor)
     attn_close(out, ref, f"fused decode {case}", None)
+
+
+@pytest.mark.parametrize("group,nf,ns,full_len", [(4, 4, 4, 70000), (4, 1, 7, 131072), (4, 0, 8, 0), (1, 8, 24, 9000),
+                                                  (2, 3, 5, 33333), (4, 8, 0, 20000)])
+def test_single_launch_step_is_bit_identical_to_two_launches(group, nf, ns, full_len):
+    """Same partials, same merge arithmetic: the one-launch step must reproduce the two-launch step bit for
+    bit — outputs and both pools — also when launched back to back many times (ticket re-arming, the merge
+    reading partials other CUs wrote into the SAME workspace addresses one launch earlier)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(full_len % 977 + nf)
+    sink, recent = 128, 256
+    nkv, Hq, W = nf + ns, (nf + ns) * group, sink + recent
+    cap = full_len + 40
+
+    def fresh():
+        gg = torch.Generator().manual_seed(5)
+        _, _, fkd, fvd = _make_pool(cap, max(nf, 1), gg, True)
+        _, _, skd, svd = _make_pool(W, max(ns, 1), gg, True)
+        return fkd[:, :nf], fvd[:, :nf], skd[:, :ns], svd[:, :ns]
+
+    steps = 24
+    qs = [_rand((Hq, D), g).to(DEV) for _ in range(steps)]
+    ks = [_rand((nkv, D), g).to(DEV) for _ in range(steps)]
+    vs = [_rand((nkv, D), g).to(DEV) for _ in range(steps)]
+    results = []
+    for two in (True, False):
+        fkd, fvd, skd, svd = fresh()
+        outs = []
+        str_len = W - 5                       # crosses the fill -> slide transition of the streaming pool
+        for i in range(steps):                # back to back, no host sync in between
+            out = torch.empty(Hq, D, dtype=torch.bfloat16, device=DEV)
+            str_len = h.decode_layer(qs[i], ks[i], vs[i], out, nf, fkd, fvd, full_len + i, skd, svd, str_len, sink,
+                                     recent, full_len + i, 1.0, 5e5, D ** -0.5, two_launch=two)
+            outs.append(out)
+        torch.cuda.synchronize()
+        results.append((torch.stack(outs).cpu(), fkd.cpu().clone(), fvd.cpu().clone(), skd.cpu().clone(), svd.cpu().clone()))
+    assert int(h.decode_tickets(torch.device(DEV)).abs().sum()) == 0
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
 
 
 PREFILL_CASES = [
