@@ -157,14 +157,19 @@ def run_job(hp: HotPath, pipe, n_decode, world, device, handoff=None):
     t0 = time.perf_counter()
     shapes = [(1, n, HIDDEN) for _, _, n in hp.blocks] if blocked else [(1, c, HIDDEN) for _, c in hp.chunks]
     pipe.run(shapes, pre, handoff)
+    torch.cuda.synchronize()
+    t1_local = time.perf_counter()        # this rank's own last item done (before waiting for the others)
     sync_all(world)
     t1 = time.perf_counter()
     # batch-1 decode is autoregressive: token i+1 enters stage 0 only after token i left the last stage
     # (one [1, 1] int64 hop back per token), so the layer pipeline cannot overlap decode steps
     tok = torch.zeros(1, 1, dtype=torch.int64, device=handoff)
     pipe.run([(1, 1, HIDDEN)] * n_decode, dec, handoff, token_feedback=lambda i, t: tok)
+    torch.cuda.synchronize()
+    t2_local = time.perf_counter()
     sync_all(world)
     t2 = time.perf_counter()
+    run_job.local = (t1_local - t0, t2_local - t1)
     return t2 - t0, t1 - t0, t2 - t1
 
 
@@ -273,6 +278,17 @@ def cpu_baseline(counts, ctx, chunk, n_decode):
     total_flops = sum(sum(r) for r in prefill_flops(counts, ctx, chunk))
     pre_tok_s = ctx / (t_pre * total_flops / flops_sample)
     job_tok_s = (ctx + n_decode) / (ctx / pre_tok_s + n_decode / dec_tok_s)
+    # BASELINE configs[0] at its stated size, attention path on the host: Llama-2-7B shape (MHA, 32 kv heads), one
+    # 4096-token prompt (first chunk: every head causal, reference llama.py:364-372); 4 of the 32 identical
+    # layers are timed and the figure is scaled by 8
+    H2, N2, L2_TIMED = 32, 4096, 4
+    q = torch.randn(1, N2, H2, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, N2, H2, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, N2, H2, D, generator=g).to(torch.bfloat16)
+    t0 = time.perf_counter()
+    for _ in range(L2_TIMED):
+        flash_attn_func_ref(q, k, v)
+    t_cfg1 = (time.perf_counter() - t0) * (32 / L2_TIMED)
     return {
         "value": job_tok_s,
         "unit": "tokens/s",
@@ -280,10 +296,146 @@ def cpu_baseline(counts, ctx, chunk, n_decode):
         "kind": "port",
         "prefill_tok_s": pre_tok_s,
         "decode_tok_s": dec_tok_s,
+        "cfg1_llama2_7b_4k_prefill_tok_s": N2 / t_cfg1,
+        "cfg1_sample": f"Llama-2-7B shape, 4096-token single-chunk prefill, 32 q = kv heads: {L2_TIMED} of 32 layers timed "
+                       f"({t_cfg1 * L2_TIMED / 32:.2f} s), x{32 // L2_TIMED}",
         "sample": (f"oracle/duo_oracle.py flash_attn_func_ref on {cores} threads: decode = 1 layer, 4 retrieval kv "
                    f"heads x {N + 1} keys ({t_dec:.2f} s); prefill = 128 rows x 4 q heads vs {past + Sq} keys "
                    f"({t_pre:.2f} s); scaled to the 32-layer job by algorithmic bytes / FLOPs"),
     }
+
+
+def measure_traffic(args):
+    """FETCH_SIZE of the two attention kernels, measured now: this file re-runs itself as `--traffic-probe` (one
+    prefill pass + 4 decode steps) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` (a counter pass of its own, no
+    other trace domain), the rocpd database is read back and the per-launch mean is corrected x2 x 1024 B (FETCH_SIZE
+    counts KiB and reads half of a wide coalesced stream on gfx950 — MI355X_MICROARCH.md, HBM).  Returns
+    ({kernel: bytes per launch}, provenance string)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "unavailable: rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="duo_traffic_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", out, "-o", "t", "--", sys.executable,
+           os.path.abspath(__file__), "--traffic-probe", "--ctx", str(args.ctx), "--chunk", str(args.chunk),
+           "--layers", str(args.layers)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+        dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+        if r.returncode != 0 or not dbs:
+            return {}, f"unavailable: rocprofv3 child rc={r.returncode}: {(r.stderr or r.stdout)[-200:]!r}"
+        cur = sqlite3.connect(dbs[0]).cursor()
+        rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
+                           "where counter_name = 'FETCH_SIZE' group by kernel_name").fetchall()
+        res, n = {}, {}
+        for name, mean, cnt in rows:
+            for key in ("duo_prefill_kernel", "duo_decode_split_kernel"):
+                if key in name:
+                    res[key] = float(mean) * 1024.0 * 2.0
+                    n[key] = cnt
+        if not res:
+            return {}, "unavailable: no FETCH_SIZE rows for the attention kernels in the rocpd database"
+        return res, (f"rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run ({time.strftime('%Y-%m-%d %H:%M:%S')}), "
+                     f"mean over {n} launches, x2 gfx950 correction")
+    except Exception as e:     # a profiler problem must never cost the bench line
+        return {}, f"unavailable: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def traffic_probe(args, device):
+    """child of measure_traffic: one prefill pass and a few decode steps, nothing timed"""
+    from duo_attn.pipeline import LayerPipeline
+
+    counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
+    hp = HotPath(counts, (0, len(counts)), args.ctx, args.chunk, device)
+    run_job(hp, LayerPipeline(len(counts), rank=0, world_size=1), 4, 1, device)
+    torch.cuda.synchronize()
+
+
+def live_parity(device):
+    """Measured error of the two attention kernels at the bench workload's own sizes, against an exact-P fp32
+    attention written in plain torch on the same GPU inputs (sampled query rows; an independent computation, not the
+    oracle): prefill = the last chunk of the 131072-token context on a layer with 4 retrieval + 4 streaming kv
+    heads, decode = one token over 131072 cached rows.  rms(err)/rms(ref) of exact bf16 arithmetic with P rounded to
+    bf16 (FA2's and the MFMA kernel's) is sqrt(2) * 1.65e-3 = 2.3e-3, with fp32 P (decode) 1.65e-3."""
+    from duo_attn.backend import get_backend
+
+    be = get_backend()
+    g = torch.Generator(device=device).manual_seed(7)
+    G, nf, ns, W, scale = HQ // HKV, 4, 4, SINK + RECENT, D ** -0.5
+    rnd = lambda *sh: torch.randn(*sh, generator=g, device=device, dtype=torch.float32).to(torch.bfloat16)
+    pool = lambda h, rows: rnd(h, rows, D).permute(1, 0, 2)          # head-major storage, token-major view
+
+    def ref_rows(q_rows, K, V, vis):
+        s_ = torch.einsum("ngd,td->ngt", q_rows.float(), K.float()) * scale
+        t = torch.arange(K.shape[0], device=device)
+        s_.masked_fill_(t[None, None, :] >= vis[:, None, None], float("-inf"))
+        return torch.einsum("ngt,td->ngd", torch.softmax(s_, -1), V.float())
+
+    def stats(o, r):
+        e = (o.float() - r).abs()
+        return {"rms_err_over_rms_ref": float((o.float() - r).pow(2).mean().sqrt() / r.pow(2).mean().sqrt()),
+                "max_abs_err": float(e.max()), "rms_ref": float(r.pow(2).mean().sqrt()), "n": int(r.numel())}
+
+    S, past = 16384, 131072 - 16384
+    q, kn, vn = rnd(S, HQ, D), pool(HKV, S), pool(HKV, S)
+    fk, fv, sk, sv = pool(nf, past + S), pool(nf, past + S), pool(ns, W), pool(ns, W)
+    fk[past:] = kn[:, :nf]
+    fv[past:] = vn[:, :nf]
+    out = torch.empty_like(q)
+    be.attention(q, out, G, (nf, 0, (fk[:past], fv[:past]), (fk[past:], fv[past:])),
+                 (ns, nf * G, (sk, sv), (kn[:, nf:], vn[:, nf:])), scale)
+    rows = torch.randint(0, S, (32,), generator=g, device=device)
+    ref = torch.empty(32, HQ, D, device=device)
+    for h in range(nf):
+        ref[:, h * G:(h + 1) * G] = ref_rows(q[rows, h * G:(h + 1) * G], fk[:, h], fv[:, h], past + rows + 1)
+    for j in range(ns):
+        h = nf + j
+        ref[:, h * G:(h + 1) * G] = ref_rows(q[rows, h * G:(h + 1) * G], torch.cat([sk[:, j], kn[:, h]]),
+                                             torch.cat([sv[:, j], vn[:, h]]), W + rows + 1)
+    res = {"prefill_chunk16384_past114688": stats(out[rows], ref)}
+    # decode over the same pools: N cached rows + the new row
+    N = past + S - 1
+    q1 = rnd(1, HQ, D)
+    o1 = torch.empty_like(q1)
+    be.attention(q1, o1, G, (nf, 0, (fk[:N], fv[:N]), (fk[N:N + 1], fv[N:N + 1])),
+                 (ns, nf * G, (sk[:W - 1], sv[:W - 1]), (sk[W - 1:], sv[W - 1:])), scale)
+    one = torch.ones(1, dtype=torch.long, device=device)
+    r1 = torch.empty(1, HQ, D, device=device)
+    for h in range(nf):
+        r1[:, h * G:(h + 1) * G] = ref_rows(q1[:, h * G:(h + 1) * G], fk[:N + 1, h], fv[:N + 1, h], one * (N + 1))
+    for j in range(ns):
+        h = nf + j
+        r1[:, h * G:(h + 1) * G] = ref_rows(q1[:, h * G:(h + 1) * G], sk[:, j], sv[:, j], one * W)
+    res["decode_131072"] = stats(o1, r1)
+    res["reference"] = "exact-P fp32 softmax attention in torch on the GPU, 32 sampled query rows x 32 q heads (prefill), all q heads (decode)"
+    res["bar"] = "tests/helpers.py attn_close: rms(err) <= 2.5e-3 rms(ref) + elementwise budget; per-config figures of the GPU test-suite: profiles/parity_r2.json"
+    return res
+
+
+def model_level(args):
+    """The reference's benchmark_static protocol on the whole random-init HF model of the same shape (GEMMs included):
+    tools/benchmark_static.py, prefill 1 warm + 1 timed pass, decode through the captured HIP graph."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("duo_benchmark_static", os.path.join(ROOT, "tools", "benchmark_static.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    a = m.parse(["--max_length", str(args.ctx), "--prefilling_chunk_size", str(args.chunk), "--prefill_steps", "1",
+                 "--prefill_warmup", "1", "--decode_steps", "50", "--decode_warmup", "10", "--graph"])
+    r = m.run(a, quiet=True)
+    return {"prefill_tok_s": r["prefill_tok_s"], "decode_ms_per_token": r["avg_generation_time_ms"],
+            "decode_mode": r["decode_mode"], "kv_cache_MB": r["kv_cache_memory_MB"], "sparsity": r["sparsity"],
+            "what": "whole HF Llama-3-8B-shape model, random init, incl. hipBLASLt GEMMs (tools/benchmark_static.py --graph)"}
 
 
 def main():
@@ -301,6 +453,10 @@ def main():
     ap.add_argument("--no-full-baseline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE child run")
+    ap.add_argument("--no-model-level", action="store_true", help="skip the whole-HF-model run (tools/benchmark_static.py)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live parity check")
+    ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -325,6 +481,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
 
+    if args.traffic_probe:
+        return traffic_probe(args, device)
+
     from duo_attn.pipeline import LayerPipeline
 
     counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
@@ -343,15 +502,23 @@ def main():
             run_job(hp, pipe, args.decode_tokens, world, device, handoff)
         sync_all(world)
         t0 = time.perf_counter()
-        parts = [run_job(hp, pipe, args.decode_tokens, world, device, handoff) for _ in range(steps)]
+        parts, locs = [], []
+        for _ in range(steps):
+            parts.append(run_job(hp, pipe, args.decode_tokens, world, device, handoff))
+            locs.append(run_job.local)
         sync_all(world)
         t = torch.tensor([time.perf_counter() - t0, sum(p[1] for p in parts), sum(p[2] for p in parts)],
                          device=handoff, dtype=torch.float64)
+        each = torch.tensor([[p[1], p[2]] for p in parts], device=handoff, dtype=torch.float64)   # per job: prefill, decode
+        timed.local_jobs = [list(x) for x in locs]      # this rank's own clock: its last item done, not the barrier
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(each, op=dist.ReduceOp.MAX)
+        timed.last_jobs = each.tolist()
         return (t / steps).tolist()
 
     hp = HotPath(counts, lr, args.ctx, args.chunk, device)
+    hp_counts_cost = sum(layer_cost[lr[0]:lr[1]])
     # (DUO_BENCH_FORCE_BLOCKS=1: row blocks on one GPU too — measures what the finer launches cost)
     if args.row_block < 0:
         # finer blocks fill the pipeline sooner but run the kernels at smaller launches (one GPU, whole job:
@@ -362,26 +529,26 @@ def main():
     if use_blocks:
         hp.set_row_blocks(args.row_block)
     t_job, t_pre, t_dec = timed(hp, args.steps, args.warmup)
+    duo_jobs, duo_local = timed.last_jobs, timed.local_jobs
 
     # HBM-side traffic per launch is a PMC measurement (rocprofv3 --pmc FETCH_SIZE, its own pass, x2 gfx950
-    # correction): not obtainable live here, so the committed figures of the same build/workload are
-    # attached when the workload matches (profiles/r1_pmc_traffic.json, provenance in profiles/r1_c_final.md)
-    traffic = {}
-    tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(tpath) and world == 1 and (args.ctx, args.chunk, L) == (131072, 16384, 32):
-        with open(tpath) as f:
-            traffic = json.load(f)
+    # correction, MI355X_MICROARCH.md): taken NOW by a child run of this file under rocprofv3 (one prefill pass +
+    # a few decode steps), never pasted from an older build's profile; null with the reason when that fails
+    traffic, traffic_source = {}, "not measured (--no-traffic)"
+    if world == 1 and not args.no_traffic and not args.no_kernel_roofline:
+        traffic, traffic_source = measure_traffic(args)
     roof = roof_dec = None
     if not args.no_kernel_roofline:
         pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
         roof = {"kernel": "duo_prefill_kernel", "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK,
-                "traffic": traffic.get("duo_prefill_kernel", {}).get("traffic_bytes_per_launch"),
-                "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"]}
+                "traffic": traffic.get("duo_prefill_kernel"), "traffic_source": traffic_source,
+                "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"],
+                "algorithmic_flops_per_launch": pre["flops"] / pre["launches"]}
         roof_dec = {"kernel": "duo_decode_split_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": td / HBM_PEAK,
-                    "traffic": traffic.get("duo_decode_split_kernel", {}).get("traffic_bytes_per_launch"),
+                    "traffic": traffic.get("duo_decode_split_kernel"), "traffic_source": traffic_source,
                     "avg_launch_ms": dec["seconds"] / dec["launches"] * 1e3, "launches": dec["launches"],
                     "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"]}
     def all_ranks_sum(x):
@@ -398,14 +565,34 @@ def main():
         hpf = HotPath([HKV] * L, lr, args.ctx, args.chunk, device)
         if use_blocks:
             hpf.set_row_blocks(args.row_block)
-        f_job, f_pre, f_dec = timed(hpf, 1, 0)
+        # same protocol as the duo job (warm-up, then timed jobs): the denominator of both speed-ups
+        fsteps, fwarm = max(1, min(args.steps, 3)), min(args.warmup, 1)
+        f_job, f_pre, f_dec = timed(hpf, fsteps, fwarm)
+        fj = timed.last_jobs
         full = {"job_tok_s": n_tok / f_job, "prefill_tok_s": args.ctx / f_pre,
-                "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": all_ranks_sum(hpf.cache.memory_usage)}
+                "decode_tok_s": args.decode_tokens / f_dec, "kv_cache_bytes": all_ranks_sum(hpf.cache.memory_usage),
+                "steps": fsteps, "warmup": fwarm,
+                "prefill_tok_s_min_max": [args.ctx / max(j[0] for j in fj), args.ctx / min(j[0] for j in fj)],
+                "decode_tok_s_min_max": [args.decode_tokens / max(j[1] for j in fj), args.decode_tokens / min(j[1] for j in fj)]}
         hpf.free()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(counts, args.ctx, args.chunk, args.decode_tokens)
+    parity = live_parity(device) if (world == 1 and not args.no_parity) else None
+    mlevel = None
+    if world == 1 and not args.no_model_level and (args.ctx, L) == (131072, 32):
+        try:
+            mlevel = model_level(args)
+        except Exception as e:      # extra information: never at the price of the bench line
+            mlevel = {"error": f"{type(e).__name__}: {e}"}
+    # per-rank view of the pipeline (N > 1): stage boundaries, this rank's own prefill / decode seconds per job,
+    # bytes handed to the next stage per job
+    mine = torch.tensor([lr[0], lr[1], sum(j[0] for j in duo_local) / len(duo_local), sum(j[1] for j in duo_local) / len(duo_local),
+                         float(hp_counts_cost)], device=handoff, dtype=torch.float64)
+    per_rank = [mine.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
 
     if rank == 0:
         line = {
@@ -445,6 +632,19 @@ def main():
             "roofline": roof,
             "roofline_decode": roof_dec,
             "cpu_baseline": cpu,
+            "duo_job_spread": {"prefill_tok_s_min_max": [args.ctx / max(j[0] for j in duo_jobs), args.ctx / min(j[0] for j in duo_jobs)],
+                               "decode_tok_s_min_max": [args.decode_tokens / max(j[1] for j in duo_jobs),
+                                                        args.decode_tokens / min(j[1] for j in duo_jobs)]},
+            "decode_note": ("decode speed-up ceiling = K/V byte ratio 1.994x at exactly 50 % streaming heads "
+                            "(8.615 vs 17.18 GB/token); whole step = scan + epilogue launch per layer"),
+            "parity_live": parity,
+            "model_level": mlevel,
+            "pipeline": None if world == 1 else {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "handoff_bytes_per_job": (args.ctx + args.decode_tokens) * HIDDEN * 2 if world > 1 else 0,
+                "stages": [{"rank": r, "layers": [int(t[0]), int(t[1])], "prefill_s": float(t[2]), "decode_s": float(t[3]),
+                            "share_of_prefill_flops": float(t[4]) / sum(layer_cost)} for r, t in enumerate(per_rank)],
+            },
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -31,6 +31,7 @@
 //     ordered heaviest-first, and the q heads that share a kv head are mapped to
 //     the same XCD (block id % 8) so K/V tiles are shared through one L2.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include "duo_prefill_common.h"
 
@@ -604,13 +605,17 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
 
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
-    // (hipFuncSetAttribute is cheap but not free: once per kernel instantiation)
-    static bool attr_done[2] = {false, false};   // per instantiation of this template (per element type)
-    if (!attr_done[tr]) {
+    // hipFuncSetAttribute is cheap but not free: once per (device, kernel instantiation).  The attribute belongs to
+    // the function as loaded on ONE device, so a process that drives several GPUs (layer pipeline in one process,
+    // accelerate-style placement) must set it on each; atomics because any host thread may get here.
+    static std::atomic<bool> attr_done[64][2];   // [device][transpose-read variant], per element type (template)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return DUO_EINVAL;
+    if (dev >= 64 || !attr_done[dev][tr].load(std::memory_order_acquire)) {
         const void *fn = tr ? (const void *)duo_prefill_kernel<true, F16> : (const void *)duo_prefill_kernel<false, F16>;
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        attr_done[tr] = true;
+        if (dev < 64) attr_done[dev][tr].store(true, std::memory_order_release);
     }
     if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
     else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);

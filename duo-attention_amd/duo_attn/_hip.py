@@ -428,8 +428,8 @@ _prefill_ws = {}
 
 
 def prefill_workspace(device) -> torch.Tensor:
-    """fp32 workspace for the key-range splits of the prefill kernel, allocated once per device."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    """fp32 workspace for the key-range splits of the prefill kernel: one per (device, stream), allocated once."""
+    key = _stream_key(torch.device(device))
     ws = _prefill_ws.get(key)
     if ws is None:
         ws = torch.empty(load_library().duo_attn_prefill_workspace_bytes() // 4, dtype=torch.float32, device=device)

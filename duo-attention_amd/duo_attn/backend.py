@@ -63,7 +63,7 @@ class HipBackend:
         else:
             self._hip.attn_prefill(q, out, group, fc, sc, scale)
 
-    # -- a whole decode step of one layer (reference llama.py:332-425, q_len == 1) in three launches
+    # -- a whole decode step of one layer (reference llama.py:332-425, q_len == 1): scan + epilogue launch (or one launch)
     def decode_layer(self, q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink,
                      recent, pos, rope_scale, rope_theta, scale) -> int:
         return self._hip.decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len,

@@ -53,11 +53,20 @@ def rope_scale_and_theta(config) -> Tuple[float, float]:
     return scale, float(theta)
 
 
+def first_positions(position_ids):
+    """``position_ids[:, 0]`` as host values for the RoPE launch (one read-back): an int when every batch row
+    starts at the same position (every reference harness), else the per-row list."""
+    first = position_ids.reshape(position_ids.shape[0], -1)[:, 0].tolist()
+    return int(first[0]) if all(f == first[0] for f in first) else [int(f) for f in first]
+
+
 def duo_static_attention_core(query_states, key_states, value_states, kv_cache, layer_idx, pos0,
                               rope_scale, rope_theta):
     """The hot path proper: everything between the q/k/v projections and o_proj in reference
     llama.py:332-425 — RoPE in place, head split, full-pool append, split-head attention,
-    streaming-pool update.  q [B,S,Hq,D], k/v [B,S,Hkv,D] bf16; returns [B,S,Hq,D]."""
+    streaming-pool update.  q [B,S,Hq,D], k/v [B,S,Hkv,D] bf16; returns [B,S,Hq,D].
+    ``pos0``: position of the first new row — an int, or one int per batch row (the reference hands
+    ``position_ids[:, 0]`` to the RoPE kernel, llama.py:350-352); None = the cache length."""
     bsz, q_len, num_heads, head_dim = query_states.shape
     num_kv = key_states.shape[2]
     groups = num_heads // num_kv
@@ -169,6 +178,7 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
     attn_output = torch.empty_like(query_states)
     W = kv_cache.sink_size + kv_cache.recent_size
     new_len = min(str_len + 1, W)
+    pos_rows = list(pos0) if isinstance(pos0, (list, tuple)) else [pos0] * bsz
     if getattr(kv_cache, "use_device_state", False):
         # graph-capturable form: the kernels read full_len / str_len / pos from the layer's device state;
         # the host values passed here only size the split-KV grid
@@ -176,12 +186,12 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
             raise ValueError("device-side decode state supports batch size 1")
         be.decode_layer_dev(query_states[0, 0], key_states[0, 0], value_states[0, 0], attn_output[0, 0], nf,
                             pk[0], pv[0], cur, sk[0], sv[0], str_len, kv_cache.sink_size, kv_cache.recent_size,
-                            pos0, rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
+                            pos_rows[0], rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
     else:
         for b in range(bsz):
             new_len = be.decode_layer(query_states[b, 0], key_states[b, 0], value_states[b, 0], attn_output[b, 0], nf,
                                       pk[b], pv[b], cur, sk[b], sv[b], str_len, kv_cache.sink_size,
-                                      kv_cache.recent_size, pos0, rope_scale, rope_theta, head_dim ** -0.5)
+                                      kv_cache.recent_size, pos_rows[b], rope_scale, rope_theta, head_dim ** -0.5)
     kv_cache.kv_seq_len_list[layer_idx] = cur + 1
     kv_cache.streaming_kv_seq_len_list[layer_idx] = new_len
     return attn_output
@@ -200,8 +210,11 @@ def duo_attention_forward_one_way_reordered_static(
     output_attentions: bool = False,
     use_cache: bool = False,
     pos0: Optional[int] = None,
+    row_block: Optional[Tuple[int, int]] = None,
     **kwargs,
 ):
+    """``row_block=(r0, chunk_len)``: ``hidden_states`` are rows [r0, r0 + q_len) of a prefill chunk of
+    ``chunk_len`` rows (layer-pipeline wavefront, ``duo_static_attention_row_block``)."""
     bsz, q_len, _ = hidden_states.size()
     num_heads, num_kv, head_dim, groups = _dims(self)
 
@@ -209,11 +222,15 @@ def duo_attention_forward_one_way_reordered_static(
     key_states = self.k_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
     value_states = self.v_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
 
-    if pos0 is None and position_ids is not None:
-        pos0 = int(position_ids[0, 0])
     rope_scale, rope_theta = rope_scale_and_theta(self.config)
-    attn_output = duo_static_attention_core(query_states, key_states, value_states, kv_cache, layer_idx,
-                                            pos0, rope_scale, rope_theta)
+    if row_block is not None:
+        attn_output = duo_static_attention_row_block(query_states, key_states, value_states, kv_cache, layer_idx,
+                                                     row_block[0], row_block[1], rope_scale, rope_theta)
+    else:
+        if pos0 is None and position_ids is not None:
+            pos0 = first_positions(position_ids)
+        attn_output = duo_static_attention_core(query_states, key_states, value_states, kv_cache, layer_idx,
+                                                pos0, rope_scale, rope_theta)
 
     attn_output = attn_output.reshape(bsz, q_len, num_heads * head_dim)
     attn_output = self.o_proj(attn_output)
@@ -296,6 +313,8 @@ def duo_attention_forward_one_way_reordered(
         streaming_key_states = torch.cat([past_streaming_KV[:bsz], streaming_key_states], dim=1)
         streaming_value_states = torch.cat([past_streaming_KV[bsz:], streaming_value_states], dim=1)
     full_kv_out = None
+    if not use_cache and past_key_value is None:
+        release_tuple_arena(self)     # a cache-less call: nothing will come back for the arena
     if use_cache:
         full_kv_out = _tuple_full_kv_append(self, past_key_value[0] if past_key_value is not None else None,
                                             full_key_states, full_value_states)
@@ -324,10 +343,26 @@ def duo_attention_forward_one_way_reordered(
     return attn_output, None, past_key_value
 
 
+def release_tuple_arena(module_or_model):
+    """Free the retrieval-head arena(s) of the tuple path (up to 1.5x a layer's full KV each).  The arena lives on
+    the attention module between calls so that linear generation appends in place; call this (on a module or on
+    the whole model) when a sequence is finished and its ``past_key_values`` are dropped.  Tuples handed back
+    earlier stay valid: they are views that keep their storage alive."""
+    mods = module_or_model.modules() if hasattr(module_or_model, "modules") else [module_or_model]
+    for m in mods:
+        if getattr(m, "_duo_full_kv_arena", None) is not None:
+            m._duo_full_kv_arena = None
+
+
 def _tuple_full_kv_append(module, past_full, new_k, new_v):
     """Retrieval-head cache of the tuple format, ``[2B, nf, N, D]`` (K stacked on V, head-major,
     reference llama.py:168-171,292-301), grown in place.  ``past_full``: the tuple element of the previous
-    call or None; ``new_k/new_v``: ``[B, q, nf, D]``.  Returns the ``[2B, nf, N+q, D]`` view."""
+    call or None; ``new_k/new_v``: ``[B, q, nf, D]``.  Returns the ``[2B, nf, N+q, D]`` view.
+
+    Aliasing contract (differs from the reference's fresh ``torch.cat``): the returned tensor is a VIEW of the
+    module-owned arena.  Its own rows are never rewritten, but the storage behind it grows in place, and a
+    caller that alternates two sequences on one model makes every call copy (the arena follows the last
+    sequence).  ``release_tuple_arena`` frees it."""
     bsz, q, nf, D = new_k.shape
     N = 0 if past_full is None else past_full.shape[2]
     arena = getattr(module, "_duo_full_kv_arena", None)
@@ -363,6 +398,12 @@ def _reorder_layer(module, layer_full_attention_heads):
     module.o_proj = reorder_linear_weights(module.o_proj, layer_full_attention_heads, groups * head_dim, "in")
 
 
+def _layer_rows(model, full_attention_heads):
+    """the head-pattern rows of the layers this process holds (all of them, or a pipeline stage's block)"""
+    pp = getattr(model, "_duo_pp", None)
+    return pp.local_rows(full_attention_heads) if pp is not None else full_attention_heads
+
+
 def enable_duo_attention_eval(model, full_attention_heads, sink_size, recent_size):
     """Tuple-cache eval patch (reference llama.py:504-554)."""
     enable_tuple_kv_cache_for_model(model)
@@ -386,6 +427,7 @@ def enable_duo_attention_static_kv_cache_eval(model, full_attention_heads):
     enable_flashinfer_rmsnorm(model)
     device = next(model.parameters()).device
     dtype = next(model.parameters()).dtype
+    full_attention_heads = _layer_rows(model, full_attention_heads)
     for idx, layer in enumerate(model.model.layers):
         module = layer.self_attn
         layer_heads = torch.as_tensor(full_attention_heads[idx]).to(device=device, dtype=dtype)

@@ -34,11 +34,15 @@ def apply_rope_inplace(q: torch.Tensor, k: torch.Tensor, offsets, rope_scale: fl
                        indptr=None):
     """Rotate-half RoPE in place on q [B,S,Hq,D] and k [B,S,Hkv,D]; position = offset[b] + row.
 
-    ``offsets`` may be a python int (no device read-back) or a tensor like the reference passes
-    (``position_ids[:, 0]``)."""
+    ``offsets`` may be a python int (no device read-back), a per-row list of ints, or a tensor like the
+    reference passes (``position_ids[:, 0]``, one read-back)."""
     bsz = q.shape[0]
     if isinstance(offsets, torch.Tensor):
         offs = [int(o) for o in (offsets.expand(bsz) if offsets.numel() == 1 else offsets).tolist()]
+    elif isinstance(offsets, (list, tuple)):
+        offs = [int(o) for o in offsets]
+        if len(offs) != bsz:
+            raise ValueError(f"{len(offs)} RoPE offsets for a batch of {bsz}")
     else:
         offs = [int(offsets)] * bsz
     be = get_backend()

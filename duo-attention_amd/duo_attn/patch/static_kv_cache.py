@@ -38,7 +38,12 @@ class DuoAttentionStaticKVCache:
 
         self.device = next(model.parameters()).device
         self.dtype = next(model.parameters()).dtype
-        self.num_layers = model.config.num_hidden_layers
+        # a model sharded over pipeline stages (duo_attn.pipeline.shard_model_for_pp): this rank owns the pools of
+        # the layers it kept; `full_attention_heads` may be the whole model's pattern or already the stage's rows
+        pp = getattr(model, "_duo_pp", None)
+        if pp is not None:
+            full_attention_heads = pp.local_rows(full_attention_heads)
+        self.num_layers = len(full_attention_heads) if pp is not None else model.config.num_hidden_layers
         self.num_heads = model.config.num_attention_heads
         self.num_kv_heads = model.config.num_key_value_heads
         self.num_kv_groups = self.num_heads // self.num_kv_heads
@@ -257,6 +262,18 @@ def duo_attn_static_kv_cache_for_causal_lm_forward(
         use_cache=use_cache,
     )
     hidden_states = outputs.last_hidden_state
+    pp = getattr(self, "_duo_pp", None)
+    if pp is not None and pp.pipe.world_size > 1:
+        # layer pipeline (one process per GPU): the logits exist on the last stage.  A decode step (S == 1) hands
+        # them to every rank — the caller's argmax must agree everywhere; prefill chunks do not (that would
+        # serialise the chunk pipeline), unless asked with sync_logits=True.
+        logits = self.lm_head(hidden_states[:, -1:, :]) if pp.is_last else None
+        S = (input_ids if input_ids is not None else inputs_embeds).shape[1]
+        if S == 1 or kwargs.get("sync_logits", False):
+            B = (input_ids if input_ids is not None else inputs_embeds).shape[0]
+            dtype = next(self.model.layers[0].parameters()).dtype
+            logits = pp.broadcast_from_last(logits, (B, 1, self.config.vocab_size), dtype)
+        return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=outputs.past_key_values)
     if self.training:
         logits = self.lm_head(hidden_states).float()
     else:
@@ -300,12 +317,21 @@ def duo_attn_static_kv_cache_model_forward(
         pos0 = past_len
     else:
         position_ids = position_ids.view(-1, seq_length).long()
-        pos0 = int(position_ids[0, 0])
+        from ._duo import first_positions
 
-    if inputs_embeds is None:
-        inputs_embeds = self.embed_tokens(input_ids)
-    hidden_states = inputs_embeds
-    for idx, decoder_layer in enumerate(self.layers):
+        pos0 = first_positions(position_ids)     # per batch row when the rows differ (left-padded batches)
+
+    pp = getattr(self, "_duo_pp", None)
+    if pp is not None and not pp.is_first:
+        # layer pipeline: this stage's input is the previous stage's hidden state (RCCL point-to-point)
+        bsz = (input_ids if input_ids is not None else inputs_embeds).shape[0]
+        hidden_states = pp.recv_hidden((bsz, seq_length, self.config.hidden_size),
+                                       next(self.layers[0].parameters()).dtype)
+    else:
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids.to(self.embed_tokens.weight.device))
+        hidden_states = inputs_embeds
+    for idx, decoder_layer in enumerate(self.layers):       # (sharded model: the layers this rank kept)
         hidden_states = decoder_layer(
             hidden_states,
             position_ids=position_ids,
@@ -314,7 +340,10 @@ def duo_attn_static_kv_cache_model_forward(
             use_cache=use_cache,
             pos0=pos0,
         )[0]
-    hidden_states = self.norm(hidden_states)
+    if pp is not None and not pp.is_last:
+        pp.send_hidden(hidden_states)       # asynchronous: the next chunk starts here while this one moves on
+    else:
+        hidden_states = self.norm(hidden_states)
     return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=past_key_values)
 
 

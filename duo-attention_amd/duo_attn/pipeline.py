@@ -9,10 +9,17 @@ link (no all-reduce / all-to-all anywhere on the inference path).
 
 Chunk-level pipelining is what makes prefill scale: chunk c on stage s depends only on chunk c
 from stage s-1 and chunk c-1 on stage s, so with n chunks and P stages the makespan is
-(n + P - 1) chunk-stage slots instead of n*P.  Sends are asynchronous (double-buffered) and the receive
-of the next item is posted right behind the send of the current one, so a stage computes item i+1
-while item i leaves.  Decode at batch 1 is strictly sequential across stages (latency = sum of stages + hops);
-sharding it only multiplies KV capacity — this is reported as is.
+(n + P - 1) chunk-stage slots instead of n*P.  In that (feed-forward) mode the send of item i and the
+receive of item i+1 are issued as ONE ``batch_isend_irecv`` group, so neither waits behind the other on
+the rank's in-order RCCL communicator and a stage computes item i+1 while item i leaves.  Decode at batch 1
+is strictly sequential across stages (latency = sum of stages + hops); sharding it only multiplies KV
+capacity — this is reported as is.
+
+``PipelinedCausalLM`` is the model-level entry point (reference ``to_device(model, devices, enable_pp=True)``,
+``duo_attn/utils.py:228-283``): this rank keeps its contiguous block of decoder layers (embedding on the
+first stage, final norm + lm_head on the last), owns the dual KV pools of those layers, and streams prefill
+chunks — whole, or in row blocks for a finer wavefront — and autoregressive decode tokens through
+``LayerPipeline``.
 """
 from __future__ import annotations
 
@@ -22,6 +29,18 @@ import torch
 import torch.distributed as dist
 
 from .utils import balanced_layer_split, even_layer_split
+
+
+class _WorkGroup:
+    """the request list of one batch_isend_irecv group behind a single wait()"""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 class LayerPipeline:
@@ -102,20 +121,245 @@ class LayerPipeline:
                 outs.append(y)
                 if feedback and i + 1 < n:
                     dist.send(token_feedback(i, y), dst=0, group=self.group)
-            else:
-                if send_work[slot] is not None:
-                    send_work[slot].wait()   # the buffer of item i-2 has left
-                keep_alive[slot] = y.contiguous()
+                post_recv(i + 1)
+                continue
+            outs.append(None)
+            if send_work[slot] is not None:
+                send_work[slot].wait()   # the buffer of item i-2 has left
+            keep_alive[slot] = y.contiguous()
+            if feedback or self.is_first or i + 1 >= n:
+                # Autoregressive stream: the receive of item i+1 must be issued AFTER the send of item i — RCCL
+                # runs a rank's point-to-point ops in issue order, and a receive posted first would wait on a
+                # token that needs that very send (deadlock).  (First stage / last item: nothing to pair with.)
                 send_work[slot] = dist.isend(keep_alive[slot], dst=next_rank, group=self.group)
-                outs.append(None)
-            # The receive of item i+1 is posted AFTER the send of item i.  RCCL runs the point-to-point ops
-            # a rank issues on one communicator in issue order: a receive posted ahead of the send would hold
-            # the send back until the upstream stage has produced item i+1 — one extra item of latency per
-            # stage while the pipeline fills — and, with token feedback, would wait on a token that needs
-            # that very send (deadlock).  The hand-off (16 MB for a 2048-row block, ~0.1 ms on one xGMI
-            # link) is small against an item's compute, so not overlapping it costs little.
-            post_recv(i + 1)
+                post_recv(i + 1)
+            else:
+                # Feed-forward stream (prefill): send(i) and recv(i+1) go out as ONE group, so the receive does
+                # not queue behind the send (nor the send behind an earlier receive) on the in-order communicator.
+                nslot = (i + 1) & 1
+                recv_bufs[nslot] = torch.empty(shapes[i + 1], device=device, dtype=dtype)
+                works = dist.batch_isend_irecv([
+                    dist.P2POp(dist.isend, keep_alive[slot], next_rank, group=self.group),
+                    dist.P2POp(dist.irecv, recv_bufs[nslot], prev_rank, group=self.group),
+                ])
+                pair = _WorkGroup(works)
+                send_work[slot] = pair
+                recv_work[nslot] = pair
         for w in send_work:
             if w is not None:
                 w.wait()
         return outs
+
+
+# =============================================================================
+# model-level layer pipeline
+# =============================================================================
+class PPState:
+    """Pipeline placement of a sharded HF model (``model._duo_pp`` and ``model.model._duo_pp``): which layers this
+    rank kept, where they live, and the in-flight hand-off of the per-call mode."""
+
+    def __init__(self, pipe: LayerPipeline, device, num_layers_total: int):
+        self.pipe = pipe
+        self.device = torch.device(device)
+        self.first_layer, self.last_layer = pipe.first_layer, pipe.last_layer
+        self.num_layers_total = num_layers_total
+        self._send = None          # (work, tensor) of the last asynchronous send of the per-call mode
+
+    @property
+    def is_first(self):
+        return self.pipe.is_first
+
+    @property
+    def is_last(self):
+        return self.pipe.is_last
+
+    def local_rows(self, per_layer):
+        """slice a per-layer list (head patterns, ...) given for the WHOLE model down to this stage"""
+        per_layer = list(per_layer)
+        if len(per_layer) == self.num_layers_total:
+            return per_layer[self.first_layer:self.last_layer]
+        if len(per_layer) == self.last_layer - self.first_layer:
+            return per_layer
+        raise ValueError(f"{len(per_layer)} per-layer rows for a stage of layers [{self.first_layer}, {self.last_layer}) "
+                         f"of {self.num_layers_total}")
+
+    # ---- per-call hand-off: ``model(input_ids=chunk, past_key_values=kv)`` on every rank ---------------------
+    def recv_hidden(self, shape, dtype):
+        buf = torch.empty(shape, device=self.device, dtype=dtype)
+        dist.recv(buf, src=self.pipe.rank - 1, group=self.pipe.group)
+        return buf
+
+    def send_hidden(self, x):
+        """asynchronous: the call returns while the hidden state leaves, so this rank starts its next chunk
+        while the next stage works on this one (chunks pipeline across successive model calls)"""
+        if self._send is not None:
+            self._send[0].wait()
+        x = x.contiguous()
+        self._send = (dist.isend(x, dst=self.pipe.rank + 1, group=self.pipe.group), x)
+
+    def broadcast_from_last(self, t, shape, dtype):
+        if t is None:
+            t = torch.empty(shape, device=self.device, dtype=dtype)
+        src = self.pipe.world_size - 1
+        src = dist.get_global_rank(self.pipe.group, src) if self.pipe.group is not None else src
+        dist.broadcast(t, src=src, group=self.pipe.group)
+        return t
+
+
+def shard_model_for_pp(model, device, group=None, layer_costs=None) -> PPState:
+    """In place: keep this rank's contiguous block of decoder layers (+ ``embed_tokens`` on the first stage,
+    ``norm`` / ``lm_head`` on the last), move them to ``device``, drop the rest.  Even split like the reference
+    (``utils.py:251-271``) unless ``layer_costs`` is given.  Works before or after the DuoAttention enabler:
+    the enablers, ``DuoAttentionStaticKVCache`` and the static model forwards all honour ``model._duo_pp``."""
+    if getattr(model, "_duo_pp", None) is not None:
+        return model._duo_pp
+    inner = model.model
+    n_layers = len(inner.layers)
+    pipe = LayerPipeline(n_layers, group=group, layer_costs=layer_costs)
+    pp = PPState(pipe, device, n_layers)
+    kept = [inner.layers[i].to(pp.device) for i in range(pp.first_layer, pp.last_layer)]
+    inner.layers = torch.nn.ModuleList(kept)
+    if pp.is_first:
+        inner.embed_tokens.to(pp.device)
+    else:
+        inner.embed_tokens = None
+    if getattr(inner, "rotary_emb", None) is not None:
+        inner.rotary_emb.to(pp.device)
+    if pp.is_last:
+        inner.norm.to(pp.device)
+        model.lm_head.to(pp.device)
+    else:
+        inner.norm = None
+        model.lm_head = None
+    model._duo_pp = pp
+    inner._duo_pp = pp
+    return pp
+
+
+class _StageView:
+    """What DuoAttentionStaticKVCache reads from a model (config + one parameter for device / dtype)."""
+
+    def __init__(self, model, pp):
+        self.config = model.config
+        self._duo_pp = pp
+        self._param = next(model.model.layers[0].parameters())
+
+    def parameters(self):
+        yield self._param
+
+
+class PipelinedCausalLM:
+    """Explicit driver of a sharded, DuoAttention-static-patched HF Llama/Mistral (reference
+    ``to_device(model, devices, enable_pp=True)``, ``duo_attn/utils.py:228-283``, as one process per GPU).
+
+    Construct it on EVERY rank from the same model.  If the model is not sharded yet it is sharded here with the
+    cost-balanced split (a layer's attention work and KV bytes grow with its retrieval heads; pass
+    ``even_split_layers=True`` for the reference's even split).  ``make_kv_cache`` allocates the dual KV pools of the
+    kept layers only, so a 1M-token cache is spread over the stages.
+
+    * ``prefill(input_ids, kv, chunk, row_block=None)`` — chunked prefill, chunks streamed through the stages with
+      paired send/receive groups (row blocks of a chunk when ``row_block`` is set: same mathematics, finer wavefront);
+    * ``decode(first_token, kv, n_new)`` — greedy generation, the sampled token fed back from the last stage to the first;
+    * ``__call__(input_ids=..., past_key_values=kv)`` — one item, like the reference's ``model(...)`` call.
+    Logits exist on the last stage (``None`` elsewhere); ``decode`` returns the tokens on every rank.
+    """
+
+    def __init__(self, model, full_attention_heads, device, group=None, even_split_layers=False):
+        heads = [[float(x) for x in torch.as_tensor(h).flatten().tolist()] for h in full_attention_heads]
+        costs = None if even_split_layers else [1.0 + sum(1 for x in h if x > 0.5) / max(1, len(h)) for h in heads]
+        self.pp = shard_model_for_pp(model, device, group=group, layer_costs=costs)
+        self.pipe = self.pp.pipe
+        self.model = model
+        self.device = self.pp.device
+        self.config = model.config
+        self.heads = heads
+        self.hidden = model.config.hidden_size
+        self.dtype = next(model.model.layers[0].parameters()).dtype
+
+    # ------------------------------------------------------------------ cache
+    def make_kv_cache(self, batch_size, max_size, sink_size, recent_size):
+        from .patch.static_kv_cache import DuoAttentionStaticKVCache
+
+        return DuoAttentionStaticKVCache(_StageView(self.model, self.pp), self.heads, batch_size, max_size,
+                                         sink_size, recent_size)
+
+    # ------------------------------------------------------------------ one stage pass
+    def _stage(self, x, ids, kv, pos0, row_block=None):
+        inner = self.model.model
+        if self.pipe.is_first:
+            x = inner.embed_tokens(ids.to(self.device))
+        kw = {} if row_block is None else {"row_block": row_block}
+        for li, layer in enumerate(inner.layers):
+            x = layer(x, position_ids=None, kv_cache=kv, layer_idx=li, use_cache=True, pos0=pos0, **kw)[0]
+        return x
+
+    def _logits(self, x):
+        return self.model.lm_head(self.model.model.norm(x)[:, -1:, :])
+
+    # ------------------------------------------------------------------ prefill
+    @torch.no_grad()
+    def prefill(self, input_ids, kv, chunk, row_block=None):
+        """Chunked prefill of ``input_ids`` [B, N] (every rank passes the same tensor; only its shape matters
+        off the first stage).  Returns the logits of the last position on the last stage, None elsewhere."""
+        B, N = input_ids.shape
+        items = []        # (first token, end token, (row0, chunk_len) or None)
+        for c0 in range(0, N, chunk):
+            c1 = min(N, c0 + chunk)
+            if row_block is None or row_block >= c1 - c0:
+                items.append((c0, c1, None))
+            else:
+                for r0 in range(0, c1 - c0, row_block):
+                    items.append((c0 + r0, min(c1, c0 + r0 + row_block), (r0, c1 - c0)))
+        base = kv.kv_seq_len
+        shapes = [(B, b - a, self.hidden) for a, b, _ in items]
+        last = {}
+
+        def stage(i, x):
+            a, b, rb = items[i]
+            y = self._stage(x, input_ids[:, a:b], kv, base + a - (rb[0] if rb else 0), rb)
+            if self.pipe.is_last and i == len(items) - 1:
+                last["logits"] = self._logits(y)
+            return y
+
+        self.pipe.run(shapes, stage, self.device, self.dtype)
+        return last.get("logits")
+
+    # ------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def decode(self, first_token, kv, n_new, return_logits=False):
+        """Greedy generation of ``n_new`` tokens after ``first_token`` [B, 1] (int64, same on every rank).  Returns
+        the [B, n_new] generated tokens on every rank (with ``return_logits`` also the per-step logits, which
+        exist on the last stage only)."""
+        B = first_token.shape[0]
+        cur = {"tok": first_token.to(self.device)}
+        logits_all, toks = [], []
+        multi = self.pipe.world_size > 1
+
+        def feedback(i, t):
+            if self.pipe.is_last:
+                return toks[-1]
+            cur["tok"] = t
+
+        def stage(i, x):
+            y = self._stage(x, cur["tok"], kv, kv.kv_seq_len)
+            if self.pipe.is_last:
+                lg = self._logits(y)
+                if return_logits:
+                    logits_all.append(lg)
+                toks.append(lg[:, -1, :].argmax(-1, keepdim=True).to(torch.int64))
+                if not multi:
+                    cur["tok"] = toks[-1]
+            return y
+
+        self.pipe.run([(B, 1, self.hidden)] * n_new, stage, self.device, self.dtype,
+                      token_feedback=feedback if multi else None)
+        out = torch.cat(toks, 1) if self.pipe.is_last else None
+        if multi:
+            out = self.pp.broadcast_from_last(out, (B, n_new), torch.int64)
+        return (out, logits_all) if return_logits else out
+
+    # ------------------------------------------------------------------ reference-style single call
+    def __call__(self, input_ids=None, past_key_values=None, use_cache=True, **kw):
+        """``model(input_ids=[B, S], past_key_values=kv)`` on every rank (the sharded model's own forward):
+        ``.logits`` is [B, 1, V] on the last stage and None elsewhere for S > 1; for S == 1 it is broadcast."""
+        return self.model(input_ids=input_ids, past_key_values=past_key_values, use_cache=use_cache, **kw)

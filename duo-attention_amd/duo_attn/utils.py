@@ -143,9 +143,14 @@ def balanced_layer_split(costs, num_stages: int):
 
 
 def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_map=True, even_split_layers=True):
-    """Single device: ``model.to(device)``.  ``enable_pp`` with a device list is the layer pipeline:
-    on MI355X that is one process per GPU with RCCL point-to-point hand-off (``duo_attn.pipeline``),
-    not accelerate hooks inside one process, so here it only validates and places this rank's model."""
+    """Single device: ``model.to(device)``.  ``enable_pp`` with a device list is the layer pipeline of reference
+    utils.py:228-283 — as ONE PROCESS PER GPU (launch with torch.distributed.run): this rank keeps its contiguous
+    block of decoder layers (embedding on the first stage, norm + lm_head on the last) on ``device[rank]`` and
+    hands the hidden state to the next rank over RCCL point-to-point (``duo_attn.pipeline.shard_model_for_pp``).
+    The calls that follow in the reference's harnesses work unchanged on every rank:
+    ``enable_*_duo_attention_static_kv_cache_eval(model, heads)``, ``DuoAttentionStaticKVCache(model, heads, ...)``
+    (this rank's pools only) and ``model(input_ids=chunk, past_key_values=kv)`` (logits on the last rank; for a
+    decode step on every rank).  ``reverse_device_map`` (an accelerate hook-ordering detail) has no meaning here."""
     if isinstance(device, list):
         if len(device) == 1:
             return model.to(f"cuda:{device[0]}")
@@ -161,10 +166,16 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
 
             if not dist.is_initialized():
                 raise RuntimeError(
-                    "Layer pipeline = one process per GPU: launch with torch.distributed.run and use "
-                    "duo_attn.pipeline.LayerPipeline (RCCL p2p over xGMI)."
+                    "Layer pipeline = one process per GPU: launch with torch.distributed.run "
+                    "(--nproc-per-node = number of devices); each rank then calls to_device(model, devices, enable_pp=True)."
                 )
-            return model.to(f"cuda:{device[dist.get_rank() % len(device)]}")
+            if dist.get_world_size() != len(device):
+                raise ValueError(f"{len(device)} devices for {dist.get_world_size()} ranks")
+            from .pipeline import shard_model_for_pp
+
+            dev = device[dist.get_rank()]
+            shard_model_for_pp(model, dev if isinstance(dev, str) else f"cuda:{dev}")
+            return model
         raise ValueError("a device list needs enable_pp (or enable_tp)")
     return model.to(device)
 

@@ -181,3 +181,33 @@ def test_row_blocks_must_come_in_order(oracle_backend):
     duo_static_attention_row_block(t(4, 4), t(4, 2), t(4, 2), cache, 0, 0, 16, 1.0, 1e4)
     with pytest.raises(ValueError):
         duo_static_attention_row_block(t(4, 4), t(4, 2), t(4, 2), cache, 0, 8, 16, 1.0, 1e4)   # skips rows 4..7
+
+
+def test_per_row_rope_offsets_in_a_batch(oracle_backend):
+    """position_ids rows that start at different positions (a left-padded batch): every batch row is rotated at
+    ITS first position, as the reference does by handing position_ids[:, 0] to the RoPE kernel (llama.py:350-352)
+    — prefill chunk and fused decode step, equal to running each row alone."""
+    from duo_attn.patch._duo import duo_static_attention_core, first_positions
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+
+    D, Hq, Hkv, sink, recent = 128, 4, 2, 2, 4
+    heads = heads_from_counts([1], Hkv)
+    g = torch.Generator().manual_seed(3)
+    mk = lambda B, S, h: torch.randn(B, S, h, D, generator=g).to(torch.bfloat16)
+    both = DuoAttentionStaticKVCache(ShapeModel(1, Hq, Hkv, D), heads, 2, 40, sink, recent)
+    solo = [DuoAttentionStaticKVCache(ShapeModel(1, Hq, Hkv, D), heads, 1, 40, sink, recent) for _ in range(2)]
+    starts = [3, 11]
+    for S in (6, 5, 1, 1):
+        q, k, v = mk(2, S, Hq), mk(2, S, Hkv), mk(2, S, Hkv)
+        past = both.kv_seq_len
+        pos = [s + past for s in starts]
+        ids = torch.stack([torch.arange(p, p + S) for p in pos])
+        assert first_positions(ids) == pos and first_positions(ids[:1].expand(2, S)) == pos[0]
+        out = duo_static_attention_core(q.clone(), k.clone(), v.clone(), both, 0, pos, 1.0, 10000.0)
+        for b in range(2):
+            exp = duo_static_attention_core(q[b:b + 1].clone(), k[b:b + 1].clone(), v[b:b + 1].clone(), solo[b], 0,
+                                            pos[b], 1.0, 10000.0)
+            assert torch.equal(out[b:b + 1], exp), (S, b)
+    for b in range(2):
+        n = solo[b].kv_seq_len
+        assert torch.equal(both.full_key_states_list[0][b, :n], solo[b].full_key_states_list[0][0, :n])

@@ -1,0 +1,164 @@
+"""Model-level layer pipeline (BASELINE cfg4 entry point) on CPU: world_size 2 and 3, gloo.
+
+A HuggingFace Llama is sharded over ranks exactly as the reference's harness would ask for it
+(``to_device(model, devices, enable_pp=True)`` -> ``enable_llama_duo_attention_static_kv_cache_eval`` ->
+``DuoAttentionStaticKVCache(model, heads, ...)`` -> ``model(input_ids=chunk, past_key_values=kv)``, reference
+eval/efficiency/benchmark_static.py:35-105 + duo_attn/utils.py:228-283), and through the explicit driver
+``PipelinedCausalLM`` (prefill in row blocks, greedy decode with token feedback).  Both must reproduce the
+single-process patched model: logits after the prefill and every generated token.  The oracle is the device backend.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADS = [[1.0, 0.0], [0.0, 0.0], [1.0, 1.0], [0.0, 1.0], [1.0, 0.0]]
+SINK, RECENT, N_PROMPT, CHUNK, N_NEW = 4, 12, 70, 32, 5
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup_paths():
+    for p in (ROOT, os.path.join(ROOT, "duo-attention_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _tiny():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(11)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=len(HEADS), num_attention_heads=2,
+                      num_key_value_heads=2, head_dim=128, vocab_size=199, max_position_embeddings=4096,
+                      rope_theta=10000.0, attn_implementation="eager", tie_word_embeddings=False)
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+
+
+def _ids():
+    return torch.randint(0, 199, (1, N_PROMPT), generator=torch.Generator().manual_seed(12))
+
+
+def _reference_run():
+    """single process: chunked prefill, then greedy decode — the reference harness's loop"""
+    _setup_paths()
+    from duo_attn import backend
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend())
+    try:
+        model = _tiny()
+        enable_llama_duo_attention_static_kv_cache_eval(model, np.array(HEADS))
+        kv = DuoAttentionStaticKVCache(model, HEADS, 1, N_PROMPT + N_NEW + 2, SINK, RECENT)
+        ids = _ids()
+        with torch.no_grad():
+            for i in range(0, N_PROMPT, CHUNK):
+                out = model(input_ids=ids[:, i:i + CHUNK], past_key_values=kv, use_cache=True)
+            prefill_logits = out.logits.float().numpy()
+            tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+            toks, step_logits = [], []
+            for _ in range(N_NEW):
+                out = model(input_ids=tok, past_key_values=kv, use_cache=True)
+                step_logits.append(out.logits.float().numpy())
+                tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+                toks.append(int(tok))
+        return prefill_logits, toks, step_logits
+    finally:
+        backend._set_backend_for_testing(None)
+
+
+def _worker(rank, world, port, mode, q):
+    _setup_paths()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from duo_attn import backend
+        from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+        from duo_attn.pipeline import PipelinedCausalLM
+        from duo_attn.utils import to_device
+        from oracle.duo_oracle import OracleBackend
+
+        backend._set_backend_for_testing(OracleBackend())
+        model = _tiny()
+        ids = _ids()
+        if mode == "drop_in":
+            # the reference harness, line for line, on every rank
+            model = to_device(model, ["cpu"] * world, enable_pp=True)
+            enable_llama_duo_attention_static_kv_cache_eval(model, np.array(HEADS))
+            kv = DuoAttentionStaticKVCache(model, HEADS, 1, N_PROMPT + N_NEW + 2, SINK, RECENT)
+            pp = model._duo_pp
+            assert len(kv.full_key_states_list) == pp.last_layer - pp.first_layer          # this rank's pools only
+            assert kv.num_full_kv_head_list == [int(sum(h)) for h in HEADS[pp.first_layer:pp.last_layer]]
+            with torch.no_grad():
+                for i in range(0, N_PROMPT, CHUNK):
+                    last = i + CHUNK >= N_PROMPT
+                    out = model(input_ids=ids[:, i:i + CHUNK], past_key_values=kv, use_cache=True, sync_logits=last)
+                    assert last or (out.logits is None) == (rank != world - 1)
+                prefill_logits = out.logits.float().numpy()
+                tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+                toks, step_logits = [], []
+                for _ in range(N_NEW):
+                    out = model(input_ids=tok, past_key_values=kv, use_cache=True)    # S == 1: logits on every rank
+                    step_logits.append(out.logits.float().numpy())
+                    tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+                    toks.append(int(tok))
+        else:
+            enable_llama_duo_attention_static_kv_cache_eval(model, np.array(HEADS))     # enabler first, then shard
+            pl = PipelinedCausalLM(model, HEADS, "cpu")
+            kv = pl.make_kv_cache(1, N_PROMPT + N_NEW + 2, SINK, RECENT)
+            logits = pl.prefill(ids, kv, CHUNK, row_block=8 if mode == "row_blocks" else None)
+            logits = pl.pp.broadcast_from_last(logits, (1, 1, 199), torch.bfloat16)
+            prefill_logits = logits.float().numpy()
+            tok = logits[:, -1, :].argmax(-1, keepdim=True)
+            out, lg = pl.decode(tok, kv, N_NEW, return_logits=True)
+            toks = [int(t) for t in out[0]]
+            step_logits = [x.float().numpy() for x in lg]
+            assert kv.kv_seq_len == N_PROMPT + N_NEW
+        if rank == world - 1:
+            q.put((prefill_logits, toks, step_logits))
+        elif mode == "drop_in":
+            q.put(("check", toks))          # every rank decoded the same tokens
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "drop_in"), (3, "drop_in"), (2, "chunks"), (3, "row_blocks")])
+def test_pipelined_model_equals_single_process(world, mode):
+    exp_logits, exp_toks, exp_steps = _reference_run()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    n_msgs = world if mode == "drop_in" else 1
+    msgs = [q.get(timeout=300) for _ in range(n_msgs)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    main = [m for m in msgs if m[0] is not None and not isinstance(m[0], str)][0]
+    got_logits, got_toks, got_steps = main
+    for m in msgs:
+        if isinstance(m[0], str):
+            assert m[1] == exp_toks
+    assert got_toks == exp_toks
+    if mode == "row_blocks":
+        # row blocks change the GEMM shapes (bf16 summation order inside the CPU GEMMs): close, not bit-equal
+        rel = np.linalg.norm(got_logits - exp_logits) / np.linalg.norm(exp_logits)
+        assert rel < 2e-2, rel
+    else:
+        assert np.array_equal(got_logits, exp_logits)
+        for a, b in zip(got_steps, exp_steps):
+            assert np.array_equal(a, b)

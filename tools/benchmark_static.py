@@ -51,46 +51,38 @@ def bench_func(func, num_steps, num_warmup_steps):
     return start.elapsed_time(end) / num_steps, torch.cuda.max_memory_allocated() / 1024 / 1024
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="llama-3-8b-1048k", choices=list(SHAPES))
-    ap.add_argument("--max_length", type=int, default=131072)
-    ap.add_argument("--prefilling_chunk_size", type=int, default=16384)
-    ap.add_argument("--sparsity", type=float, default=0.5)
-    ap.add_argument("--sink_size", type=int, default=128)
-    ap.add_argument("--recent_size", type=int, default=256)
-    ap.add_argument("--prefill_steps", type=int, default=2)
-    ap.add_argument("--prefill_warmup", type=int, default=1)
-    ap.add_argument("--decode_steps", type=int, default=100)
-    ap.add_argument("--decode_warmup", type=int, default=20)
-    ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--graph", action="store_true",
-                    help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
-    args = ap.parse_args()
-
+def build_model(shape_name, device, seed):
     from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
 
-    from duo_attn.utils import seed_everything, sparsify_attention_heads
+    from duo_attn.utils import seed_everything
 
-    seed_everything(args.seed)
-    shape = SHAPES[args.shape]
-    is_mistral = args.shape.startswith("mistral")
+    seed_everything(seed)
+    shape = SHAPES[shape_name]
+    is_mistral = shape_name.startswith("mistral")
     cfg_kw = dict(attn_implementation="eager", tie_word_embeddings=False, **shape)
     config = MistralConfig(sliding_window=None, **cfg_kw) if is_mistral else LlamaConfig(**cfg_kw)
-    t0 = time.time()
     torch.set_default_dtype(torch.bfloat16)
-    with torch.device("cuda"):
+    with torch.device(device):
         model = (MistralForCausalLM if is_mistral else LlamaForCausalLM)(config)
     torch.set_default_dtype(torch.float32)
-    model.eval()
-    print(f"random-init {args.shape}: {sum(p.numel() for p in model.parameters()) / 1e9:.2f} B params in {time.time() - t0:.1f} s")
+    return model.eval(), config, is_mistral
+
+
+def run(args, quiet=False):
+    """single GPU: the reference's benchmark_static protocol; returns the result dict"""
+    from duo_attn.utils import sparsify_attention_heads
+
+    say = (lambda *a: None) if quiet else print
+    t0 = time.time()
+    model, config, is_mistral = build_model(args.shape, "cuda", args.seed)
+    say(f"random-init {args.shape}: {sum(p.numel() for p in model.parameters()) / 1e9:.2f} B params in {time.time() - t0:.1f} s")
 
     L, Hkv = config.num_hidden_layers, config.num_key_value_heads
     # no pattern files on the box: a synthetic importance matrix with the shipped patterns' structure
     # (sparsify_attention_heads then takes the global quantile exactly as the reference does)
     heads = np.random.RandomState(0).rand(L, Hkv)
     heads, sparsity = sparsify_attention_heads(heads, None, args.sparsity)
-    print(f"True Sparsity: {sparsity}")
+    say(f"True Sparsity: {sparsity}")
     mod = __import__("duo_attn.patch." + ("mistral" if is_mistral else "llama"), fromlist=["x"])
     enable = getattr(mod, f"enable_{'mistral' if is_mistral else 'llama'}_duo_attention_static_kv_cache_eval")
     enable(model, heads)
@@ -141,14 +133,117 @@ def main():
         "kv_cache_memory_MB": kv_cache.memory_usage / 1024 / 1024,
         "decode_mode": "hip graph replay" if args.graph else "eager",
     }
+    del model, kv_cache
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_pp(args):
+    """--pp: layer pipeline, one process per GPU (launch with torch.distributed.run).  The model is sharded with
+    duo_attn.pipeline.PipelinedCausalLM: chunked prefill streamed through the stages (row blocks with --row_block),
+    greedy decode with the token fed back from the last stage.  BASELINE cfg4's entry point:
+        python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/benchmark_static.py --pp \
+            --max_length 1048576 --prefilling_chunk_size 32000 --row_block 4096"""
+    import torch.distributed as dist
+
+    from duo_attn.pipeline import PipelinedCausalLM
+    from duo_attn.utils import sparsify_attention_heads
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = f"cuda:{local}"
+    model, config, is_mistral = build_model(args.shape, dev, args.seed)     # same seed: same weights on every rank
+    heads = np.random.RandomState(0).rand(config.num_hidden_layers, config.num_key_value_heads)
+    heads, sparsity = sparsify_attention_heads(heads, None, args.sparsity)
+    mod = __import__("duo_attn.patch." + ("mistral" if is_mistral else "llama"), fromlist=["x"])
+    getattr(mod, f"enable_{'mistral' if is_mistral else 'llama'}_duo_attention_static_kv_cache_eval")(model, heads)
+    pl = PipelinedCausalLM(model, heads, dev)
+    torch.cuda.empty_cache()
+    g = torch.Generator().manual_seed(args.seed)
+    input_ids = torch.randint(0, config.vocab_size, (1, args.max_length - 1), generator=g)
+    kv = pl.make_kv_cache(1, input_ids.size(1) + args.decode_steps + args.decode_warmup + 5, args.sink_size, args.recent_size)
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t) / steps * 1e3
+
+    rb = args.row_block if args.row_block > 0 else None
+
+    def func1():
+        pl.prefill(input_ids, kv, args.prefilling_chunk_size, row_block=rb)
+        kv.clear()
+
+    ctx_latency = timed(func1, args.prefill_steps, args.prefill_warmup)
+    logits = pl.prefill(input_ids, kv, args.prefilling_chunk_size, row_block=rb)
+    logits = pl.pp.broadcast_from_last(logits, (1, 1, config.vocab_size), torch.bfloat16)
+    tok = logits[:, -1, :].argmax(-1, keepdim=True)
+    pl.decode(tok, kv, args.decode_warmup)
+    n = args.decode_steps
+    gen_latency = timed(lambda: pl.decode(tok, kv, n), 1, 0) / n
+    stage = torch.tensor([pl.pp.first_layer, pl.pp.last_layer, kv.memory_usage // (1 << 20),
+                          int(torch.cuda.max_memory_allocated() // (1 << 20))], device=dev, dtype=torch.int64)
+    allst = [torch.zeros_like(stage) for _ in range(world)]
+    dist.all_gather(allst, stage)
+    res = {
+        "mode": f"layer pipeline, {world} ranks (RCCL p2p)", "shape": args.shape, "context_length": args.max_length,
+        "sparsity": float(sparsity), "prefilling_chunk_size": args.prefilling_chunk_size, "row_block": rb,
+        "avg_context_time_ms": ctx_latency, "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3,
+        "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
+        "handoff_bytes_per_chunk": args.prefilling_chunk_size * config.hidden_size * 2,
+        "stages": [{"rank": r, "layers": [int(s[0]), int(s[1])], "kv_cache_MB": int(s[2]), "peak_MB": int(s[3])}
+                   for r, s in enumerate(allst)],
+    }
+    if rank == 0:
+        print(json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="llama-3-8b-1048k", choices=list(SHAPES))
+    ap.add_argument("--max_length", type=int, default=131072)
+    ap.add_argument("--prefilling_chunk_size", type=int, default=16384)
+    ap.add_argument("--sparsity", type=float, default=0.5)
+    ap.add_argument("--sink_size", type=int, default=128)
+    ap.add_argument("--recent_size", type=int, default=256)
+    ap.add_argument("--prefill_steps", type=int, default=2)
+    ap.add_argument("--prefill_warmup", type=int, default=1)
+    ap.add_argument("--decode_steps", type=int, default=100)
+    ap.add_argument("--decode_warmup", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--graph", action="store_true",
+                    help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
+    ap.add_argument("--pp", action="store_true", help="layer pipeline over the ranks of torch.distributed.run")
+    ap.add_argument("--row_block", type=int, default=0, help="--pp: hand prefill chunks through the stages in row blocks")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse()
+    if args.pp:
+        return run_pp(args)
+    res = run(args)
     # same fields as the reference's benchmark_result.txt (benchmark_static.py:108-119)
-    print(f"Average generation time: {gen_latency:.4f} ms")
-    print(f"Peak generation memory usage: {gen_memory:.4f} MB")
-    print(f"Average context time: {ctx_latency:.4f} ms")
-    print(f"Peak context memory usage: {ctx_memory:.4f} MB")
+    print(f"Average generation time: {res['avg_generation_time_ms']:.4f} ms")
+    print(f"Peak generation memory usage: {res['peak_generation_memory_MB']:.4f} MB")
+    print(f"Average context time: {res['avg_context_time_ms']:.4f} ms")
+    print(f"Peak context memory usage: {res['peak_context_memory_MB']:.4f} MB")
     print(f"Context length: {args.max_length}")
-    print(f"Sparsity: {sparsity}")
-    print(f"Prefilling chunk size: {C}")
+    print(f"Sparsity: {res['sparsity']}")
+    print(f"Prefilling chunk size: {res['prefilling_chunk_size']}")
     print(f"KV cache memory usage: {res['kv_cache_memory_MB']:.4f} MB")
     print(json.dumps(res))
 
