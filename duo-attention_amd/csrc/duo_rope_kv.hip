@@ -31,6 +31,31 @@ struct RopeParams {
 
 // 64 threads per token: c = tid&7 picks dims [8c,8c+8) and [64+8c,64+8c+8),
 // hs = (tid>>3)&7 strides over the heads 8 at a time.  4 tokens per block.
+// 16-bit element <-> fp32, by element type (bf16: the static dual-cache path; fp16: the INT4-KV path's model)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ void unpack8x(const u32x4 &w, float (&f)[8]) {
+    if constexpr (F16) {
+        const f16x8_t h = __builtin_bit_cast(f16x8_t, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (float)h[e];
+    } else {
+        unpack8f(w, f);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ u32x4 pack8x(const float (&f)[8]) {
+    if constexpr (F16) {
+        f16x8_t h;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = (_Float16)f[e];     // round to nearest even
+        return __builtin_bit_cast(u32x4, h);
+    } else {
+        return pack8f(f);
+    }
+}
+
+template <bool F16>
 __global__ __launch_bounds__(256) void duo_rope_kernel(const RopeParams P) {
     const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tok >= P.n_tokens) return;
@@ -51,15 +76,15 @@ __global__ __launch_bounds__(256) void duo_rope_kernel(const RopeParams P) {
         u32x4 *plo = reinterpret_cast<u32x4 *>(row + c * 8);
         u32x4 *phi = reinterpret_cast<u32x4 *>(row + 64 + c * 8);
         float lo[8], hi[8], olo[8], ohi[8];
-        unpack8f(*plo, lo);
-        unpack8f(*phi, hi);
+        unpack8x<F16>(*plo, lo);
+        unpack8x<F16>(*phi, hi);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             olo[e] = lo[e] * cs[e] - hi[e] * sn[e];
             ohi[e] = hi[e] * cs[e] + lo[e] * sn[e];
         }
-        *plo = pack8f(olo);
-        *phi = pack8f(ohi);
+        *plo = pack8x<F16>(olo);
+        *phi = pack8x<F16>(ohi);
     }
 }
 
@@ -129,11 +154,10 @@ __global__ __launch_bounds__(256) void duo_rmsnorm_kernel(const bf16_t *x, const
 
 }  // namespace
 
-extern "C" int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride,
-                                     int32_t n_q_heads, void *k, int64_t k_token_stride,
-                                     int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
-                                     int64_t pos0, float rope_scale, float rope_theta,
-                                     int32_t head_dim, void *stream) {
+template <bool F16>
+static int rope_impl(void *q, int64_t q_token_stride, int64_t q_head_stride, int32_t n_q_heads, void *k,
+                     int64_t k_token_stride, int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                     int64_t pos0, float rope_scale, float rope_theta, int32_t head_dim, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (n_tokens <= 0) return 0;
     if ((n_q_heads > 0 && !q) || (n_kv_heads > 0 && !k) || rope_scale <= 0.f || rope_theta <= 0.f)
@@ -146,9 +170,28 @@ extern "C" int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_
     P.pos0 = pos0;
     for (int i = 0; i < 64; ++i)
         P.inv_freq[i] = (float)(pow((double)rope_theta, -2.0 * i / 128.0) / (double)rope_scale);
-    hipLaunchKernelGGL(duo_rope_kernel, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(duo_rope_kernel<F16>, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                     int32_t n_q_heads, void *k, int64_t k_token_stride,
+                                     int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                                     int64_t pos0, float rope_scale, float rope_theta,
+                                     int32_t head_dim, void *stream) {
+    return rope_impl<false>(q, q_token_stride, q_head_stride, n_q_heads, k, k_token_stride, k_head_stride, n_kv_heads,
+                            n_tokens, pos0, rope_scale, rope_theta, head_dim, stream);
+}
+
+// fp16 twin: apply_rope_inplace of the INT4-KV path's fp16 model (demo/w8a8kv4_llama.py:207-215)
+extern "C" int duo_rope_inplace_f16(void *q, int64_t q_token_stride, int64_t q_head_stride,
+                                    int32_t n_q_heads, void *k, int64_t k_token_stride,
+                                    int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                                    int64_t pos0, float rope_scale, float rope_theta,
+                                    int32_t head_dim, void *stream) {
+    return rope_impl<true>(q, q_token_stride, q_head_stride, n_q_heads, k, k_token_stride, k_head_stride, n_kv_heads,
+                           n_tokens, pos0, rope_scale, rope_theta, head_dim, stream);
 }
 
 extern "C" int duo_kv_append_bf16(const void *k_src, const void *v_src, int64_t src_token_stride,

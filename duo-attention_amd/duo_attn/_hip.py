@@ -85,6 +85,11 @@ _SIGNATURES = {
         [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64,
          c_float, c_float, c_int32, c_void_p],
     ),
+    "duo_rope_inplace_f16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64,
+         c_float, c_float, c_int32, c_void_p],
+    ),
     "duo_kv_append_bf16": (
         ctypes.c_int,
         [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32,
@@ -236,17 +241,18 @@ def make_class(n_kv_heads: int, q_head_offset: int, segA: KVSeg, segB: KVSeg) ->
 
 # ----------------------------------------------------------------------------- ops
 def rope_inplace(q: torch.Tensor, k: torch.Tensor, pos0: int, rope_scale: float, rope_theta: float):
-    """q: [S, Hq, D], k: [S, Hkv, D] views, rotated in place (flashinfer apply_rope_inplace semantics)."""
+    """q: [S, Hq, D], k: [S, Hkv, D] views, rotated in place (flashinfer apply_rope_inplace semantics); bf16, or
+    fp16 (the INT4-KV path's model)."""
     lib = load_library()
-    _require_gpu_bf16(q, "q")
-    _require_gpu_bf16(k, "k")
+    f16 = q.dtype == torch.float16
+    _require_gpu_bf16(q, "q", q.dtype if f16 else torch.bfloat16)
+    _require_gpu_bf16(k, "k", q.dtype if f16 else torch.bfloat16)
     assert q.dim() == 3 and k.dim() == 3 and q.shape[0] == k.shape[0]
+    fn = lib.duo_rope_inplace_f16 if f16 else lib.duo_rope_inplace_bf16
     _check(
-        lib.duo_rope_inplace_bf16(
-            q.data_ptr(), q.stride(0), q.stride(1), q.shape[1], k.data_ptr(), k.stride(0), k.stride(1),
-            k.shape[1], q.shape[0], int(pos0), float(rope_scale), float(rope_theta), q.shape[2], _stream_ptr(),
-        ),
-        "duo_rope_inplace_bf16",
+        fn(q.data_ptr(), q.stride(0), q.stride(1), q.shape[1], k.data_ptr(), k.stride(0), k.stride(1),
+           k.shape[1], q.shape[0], int(pos0), float(rope_scale), float(rope_theta), q.shape[2], _stream_ptr()),
+        "duo_rope_inplace_f16" if f16 else "duo_rope_inplace_bf16",
     )
 
 

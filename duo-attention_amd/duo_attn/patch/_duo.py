@@ -452,24 +452,36 @@ def _attn_modules(model):
 
 
 def get_full_attention_heads(model):
-    """reference llama.py:601-640 (single-process models; tensor_parallel wrappers are out of scope)."""
-    return [m.full_attention_heads for m in _attn_modules(model) if hasattr(m, "full_attention_heads")]
+    """reference llama.py:601-640.  Single-process model: the per-layer buffers.  A model sharded with
+    ``duo_attn.tp.shard_model_for_tp``: the reference's TensorParallel branch (:603-622) — every rank gets the whole
+    model's per-layer ``[Hkv]`` rows (original kv-head order), gathered over the TP group."""
+    local = [m.full_attention_heads for m in _attn_modules(model) if hasattr(m, "full_attention_heads")]
+    if getattr(model, "_duo_tp", None) is not None and local:
+        from ..tp import gather_full_attention_heads
+
+        return gather_full_attention_heads(model, local)
+    return local
 
 
 def set_full_attention_heads(model, full_attention_heads):
-    """reference llama.py:643-672"""
+    """reference llama.py:643-672; on a TP-sharded model the rows are whole-model ``[Hkv]`` rows and each rank
+    keeps its own heads."""
+    tp = getattr(model, "_duo_tp", None)
     for layer_idx, m in enumerate(_attn_modules(model)):
         if not hasattr(m, "full_attention_heads"):
             continue
-        m.full_attention_heads.data = full_attention_heads[layer_idx].to(
-            m.full_attention_heads.device, m.full_attention_heads.dtype
-        )
+        row = full_attention_heads[layer_idx]
+        if tp is not None and row.numel() == tp["num_kv_heads"]:
+            from ..tp import scatter_full_attention_heads
+
+            row = scatter_full_attention_heads(model, layer_idx, row)
+        m.full_attention_heads.data = row.to(m.full_attention_heads.device, m.full_attention_heads.dtype)
         m.full_attn_head_mask = None
     return model
 
 
 def map_full_attention_heads(model, func):
-    """reference llama.py:675-693"""
+    """reference llama.py:675-693 (applied to this process's buffers: all of them, or a TP rank's slice)"""
     for m in _attn_modules(model):
         if hasattr(m, "full_attention_heads"):
             func(m.full_attention_heads)

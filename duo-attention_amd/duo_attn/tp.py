@@ -139,4 +139,30 @@ def shard_model_for_tp(model, full_attention_heads, rank: Optional[int] = None, 
     cfg.num_attention_heads = Hq // tp
     cfg.num_key_value_heads = Hkv // tp
     cfg.intermediate_size = inter // tp
+    # what the TP-aware head accessors (duo_attn.patch.get/set/map_full_attention_heads) need
+    model._duo_tp = {"assign": assign, "rank": rank, "tp": tp, "group": group, "num_kv_heads": Hkv}
     return local
+
+
+def gather_full_attention_heads(model, local_heads):
+    """``local_heads``: this rank's per-layer buffers ``[Hkv / tp]`` (rank-local order, retrieval heads first).
+    Returns the whole model's per-layer ``[Hkv]`` tensors in the ORIGINAL kv-head order, identical on every rank —
+    what the reference's TP branch assembles by concatenating its shards (llama.py:601-620)."""
+    info = model._duo_tp
+    tp, group = info["tp"], info["group"]
+    out = []
+    for l, mine in enumerate(local_heads):
+        parts = [torch.empty_like(mine) for _ in range(tp)]
+        dist.all_gather(parts, mine.contiguous(), group=group)
+        full = torch.empty(info["num_kv_heads"], dtype=mine.dtype, device=mine.device)
+        for r in range(tp):
+            full[torch.tensor(info["assign"][l][r], device=mine.device)] = parts[r]
+        out.append(full)
+    return out
+
+
+def scatter_full_attention_heads(model, layer_idx, full_row):
+    """this rank's slice (rank-local order) of a whole-model ``[Hkv]`` row given in the original head order"""
+    info = model._duo_tp
+    ids = torch.tensor(info["assign"][layer_idx][info["rank"]], device=full_row.device)
+    return full_row[ids]

@@ -109,6 +109,12 @@ int duo_rope_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride
                           int64_t k_head_stride, int32_t n_kv_heads,
                           int32_t n_tokens, int64_t pos0, float rope_scale,
                           float rope_theta, int32_t head_dim, void *stream);
+/* fp16 twin: apply_rope_inplace of the INT4-KV path's fp16 model (demo/w8a8kv4_llama.py:207-215) */
+int duo_rope_inplace_f16(void *q, int64_t q_token_stride, int64_t q_head_stride,
+                         int32_t n_q_heads, void *k, int64_t k_token_stride,
+                         int64_t k_head_stride, int32_t n_kv_heads,
+                         int32_t n_tokens, int64_t pos0, float rope_scale,
+                         float rope_theta, int32_t head_dim, void *stream);
 
 /* ---- copy S new rows of n_heads kv heads into a pool at row `dst_row0` ----- */
 int duo_kv_append_bf16(const void *k_src, const void *v_src,

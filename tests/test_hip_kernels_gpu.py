@@ -72,6 +72,24 @@ def test_rope(pos0, scale, theta):
     _ulp_close(kd, rope_ref(k, pos0, scale, theta), "rope k")
 
 
+def test_rope_fp16():
+    """duo_rope_inplace_f16 (the INT4-KV path's fp16 model): same angles, fp16 in/out — within one fp16 ulp of the
+    oracle's fp32 rotation on a small fraction of elements (device vs host sincos last-bit differences)."""
+    h = _hip()
+    g = torch.Generator().manual_seed(5)
+    S, Hq, Hkv = 41, 4, 2
+    q = torch.randn(S, Hq, D, generator=g).to(torch.float16)
+    k = torch.randn(S, Hkv, D, generator=g).to(torch.float16)
+    for pos0, theta in ((0, 1e4), (70000, 500000.0)):
+        qd, kd = q.to(DEV), k.to(DEV)
+        h.rope_inplace(qd, kd, pos0, 1.0, theta)
+        for got, x in ((qd, q), (kd, k)):
+            want = rope_ref(x, pos0, 1.0, theta)
+            diff = (got.cpu().float() - want.float()).abs()
+            assert (diff <= want.float().abs() * 2.0 ** -10 + 1e-6).all()
+            assert (diff > 0).float().mean() < 0.03
+
+
 # ----------------------------------------------------------------------------- append / compress
 @pytest.mark.parametrize("head_major", [True, False])
 def test_kv_append(head_major):

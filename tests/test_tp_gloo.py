@@ -62,6 +62,22 @@ def _worker(rank, world, port, q):
         local = shard_model_for_tp(model, HEADS)
         assert local.shape == (3, 2) and (np.diff(local, axis=1) <= 0).all()     # retrieval heads first
         out = _run(model, local)
+        # TP-aware pattern accessors on the TUPLE-path patch (reference llama.py:601-693, TensorParallel branches):
+        # every rank sees the whole model's rows in the original head order; set() scatters them back
+        from duo_attn.patch import enable_duo_attention_eval, get_full_attention_heads, set_full_attention_heads
+
+        m2 = _tiny()
+        loc2 = shard_model_for_tp(m2, HEADS)
+        enable_duo_attention_eval(m2, loc2.copy(), 4, 8)
+        got = torch.stack(get_full_attention_heads(m2)).float().numpy()
+        assert np.array_equal(got, HEADS), got
+        new = torch.tensor(1.0 - HEADS, dtype=torch.float32)
+        set_full_attention_heads(m2, [r for r in new])
+        assert np.array_equal(torch.stack(get_full_attention_heads(m2)).float().numpy(), 1.0 - HEADS)
+        # each rank kept exactly its own heads of the new rows
+        for l, layer in enumerate(m2.model.layers):
+            ids = m2._duo_tp["assign"][l][rank]
+            assert layer.self_attn.full_attention_heads.tolist() == [float(new[l, h]) for h in ids]
         if rank == 0:
             q.put(out.numpy())
         dist.barrier()

@@ -211,6 +211,84 @@ def run_pp(args):
     dist.destroy_process_group()
 
 
+def run_tp(args):
+    """--tp: head-parallel tensor parallelism, one process per GPU (duo_attn.tp: retrieval heads dealt evenly over the
+    ranks, column/row-sliced projections, two RCCL all-reduces of [1, S, hidden] per layer).  Same protocol as the
+    single-GPU run; every rank executes every layer on its Hkv / tp heads."""
+    import torch.distributed as dist
+
+    from duo_attn.tp import shard_model_for_tp
+    from duo_attn.utils import sparsify_attention_heads
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = f"cuda:{local}"
+    model, config, is_mistral = build_model(args.shape, dev, args.seed)
+    L, Hkv, hidden = config.num_hidden_layers, config.num_key_value_heads, config.hidden_size
+    heads = np.random.RandomState(0).rand(L, Hkv)
+    heads, sparsity = sparsify_attention_heads(heads, None, args.sparsity)
+    mine = shard_model_for_tp(model, heads)
+    torch.cuda.empty_cache()
+    mod = __import__("duo_attn.patch." + ("mistral" if is_mistral else "llama"), fromlist=["x"])
+    getattr(mod, f"enable_{'mistral' if is_mistral else 'llama'}_duo_attention_static_kv_cache_eval")(model, mine)
+    input_ids = torch.randint(0, config.vocab_size, (1, args.max_length - 1), device=dev,
+                              generator=torch.Generator(device=dev).manual_seed(args.seed))
+    kv = mod.DuoAttentionStaticKVCache(model, mine, 1, input_ids.size(1) + 5, args.sink_size, args.recent_size)
+    C = args.prefilling_chunk_size
+
+    def prefill():
+        with torch.no_grad():
+            for i in range(0, input_ids.size(1), C):
+                out = model(input_ids=input_ids[:, i:i + C], past_key_values=kv, use_cache=True)
+        return out
+
+    def func1():
+        prefill()
+        kv.clear()
+
+    def timed(fn, steps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t) / steps * 1e3
+
+    ctx_latency = timed(func1, args.prefill_steps, args.prefill_warmup)
+    out = prefill()
+    pred = out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
+
+    def func2():
+        with torch.no_grad():
+            model(input_ids=pred, past_key_values=kv, use_cache=True)
+        kv.evict_last(1)
+
+    gen_latency = timed(func2, args.decode_steps, args.decode_warmup)
+    st = torch.tensor([int(mine.sum()), kv.memory_usage // (1 << 20)], device=dev, dtype=torch.int64)
+    allst = [torch.zeros_like(st) for _ in range(world)]
+    dist.all_gather(allst, st)
+    res = {
+        "mode": f"head-parallel TP, {world} ranks (RCCL all-reduce)", "shape": args.shape, "context_length": args.max_length,
+        "sparsity": float(sparsity), "prefilling_chunk_size": C, "avg_context_time_ms": ctx_latency,
+        "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3, "avg_generation_time_ms": gen_latency,
+        "decode_tok_s": 1e3 / gen_latency, "all_reduces_per_layer": 2, "all_reduce_bytes_decode": hidden * 2,
+        "all_reduce_bytes_prefill_chunk": C * hidden * 2,
+        "ranks": [{"rank": r, "retrieval_kv_heads": int(s[0]), "kv_cache_MB": int(s[1])} for r, s in enumerate(allst)],
+    }
+    if rank == 0:
+        print(json.dumps(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--shape", default="llama-3-8b-1048k", choices=list(SHAPES))
@@ -228,6 +306,7 @@ def parse(argv=None):
                     help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
     ap.add_argument("--pp", action="store_true", help="layer pipeline over the ranks of torch.distributed.run")
     ap.add_argument("--row_block", type=int, default=0, help="--pp: hand prefill chunks through the stages in row blocks")
+    ap.add_argument("--tp", action="store_true", help="head-parallel tensor parallelism over the ranks of torch.distributed.run")
     return ap.parse_args(argv)
 
 
@@ -235,6 +314,8 @@ def main():
     args = parse()
     if args.pp:
         return run_pp(args)
+    if args.tp:
+        return run_tp(args)
     res = run(args)
     # same fields as the reference's benchmark_result.txt (benchmark_static.py:108-119)
     print(f"Average generation time: {res['avg_generation_time_ms']:.4f} ms")
