@@ -188,9 +188,16 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             {
                 constexpr int KO = SOFF >= 32768 ? 0 : SOFF;          // 16-bit ds offset field
                 u32x4 kf[2][2];
+#ifdef DUO_ABLATE_KREAD
+                kf[0][0] = kf[0][1] = kf[1][0] = kf[1][1] = u32x4{0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#endif
+#ifdef DUO_ABLATE_KREAD      /* measurement only: K fragments are whatever the registers hold (no LDS read) */
+#define DUO_K_READ(dst, kk_, bb_) asm volatile("" : "+v"(dst))
+#else
 #define DUO_K_READ(dst, kk_, bb_)                                                                         \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(koff[kk_] + (SOFF >= 32768 ? SOFF : 0)),  \
                  "n"(KO + (bb_) * 8192) : "memory")
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_K_READ(kf[0][0], 0, 0);
                 DUO_K_READ(kf[0][1], 0, 1);
@@ -322,6 +329,10 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 const uint32_t va_ = SOFF >= 32768 ? vaddr + SOFF : vaddr;
                 constexpr int VO = SOFF >= 32768 ? 0 : SOFF;
                 u32x2 va[8], vb[8];
+#ifdef DUO_ABLATE_VREAD
+#pragma unroll
+                for (int i_ = 0; i_ < 8; ++i_) va[i_] = vb[i_] = u32x2{0x3c003c00u, 0x3c003c00u + (uint32_t)lane};
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(va, va_, VO, 0);
                 DUO_TR_STEP(vb, va_, VO, 1);
