@@ -34,6 +34,7 @@
 #include <atomic>
 #include <cstdlib>
 #include "duo_prefill_common.h"
+#include "duo_prefill_w64.h"
 
 namespace {
 
@@ -627,6 +628,26 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         if (dev < 64) attr_done[dev][tr].store(true, std::memory_order_release);
+    }
+    // 4-wave x 64-row kernel (duo_prefill_w64.h): bf16, transpose-read path, no key-range split, segment B == the
+    // query rows.  DUO_PREFILL_W64=1 selects it (A/B knob while it is being tuned).
+    static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return e && atoi(e) != 0; }();
+    if constexpr (!F16) {
+        bool w64_ok = want_w64 && tr && P.ksplit == 1;
+        for (int c = 0; c < 2; ++c)
+            if (P.cls[c].n_kv_heads > 0 && P.cls[c].b.len != n_tokens) w64_ok = false;
+        if (w64_ok) {
+            static std::atomic<bool> w64_attr[64];
+            if (dev >= 64 || !w64_attr[dev].load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute((const void *)duo_prefill_w64_kernel,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+                if (e != hipSuccess) return (int)e;
+                if (dev < 64) w64_attr[dev].store(true, std::memory_order_release);
+            }
+            hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
+            DUO_HIP_CHECK_LAUNCH();
+            return 0;
+        }
     }
     if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
     else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);

@@ -217,6 +217,7 @@ __device__ __forceinline__ void stage_dma_full(const TileSrc &s, const DmaLane &
         }                                                                             \
     } while (0)
 
+__device__ __forceinline__ u32x4 join_u(const u32x2 &a, const u32x2 &b) { return u32x4{a.x, a.y, b.x, b.y}; }
 __device__ __forceinline__ bf16x8 join_frag(const u32x2 &a, const u32x2 &b) {
     u32x4 w = {a.x, a.y, b.x, b.y};
     return *reinterpret_cast<bf16x8 *>(&w);
