@@ -548,6 +548,7 @@ static int prefill_choose_ksplit(int long_wgs, int min_tiles, int64_t workspace_
     }();
     if (long_wgs <= 0 || workspace_bytes <= 0) return 1;
     const int kmax = (int)std::min<int64_t>(8, std::min<int64_t>(min_tiles, workspace_bytes / (kPrefillPartialBytes * long_wgs)));
+    if (g_debug_flags & 256u) return 1;      // debug bit 8: no key-range split
     if (forced > 0) return std::max(1, std::min(forced, kmax));
     int best = 1;
     double best_cost = 1e30;
@@ -629,11 +630,16 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         if (e != hipSuccess) return (int)e;
         if (dev < 64) attr_done[dev][tr].store(true, std::memory_order_release);
     }
-    // 4-wave x 64-row kernel (duo_prefill_w64.h): bf16, transpose-read path, no key-range split, segment B == the
-    // query rows.  DUO_PREFILL_W64=1 selects it (A/B knob while it is being tuned).
-    static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return e && atoi(e) != 0; }();
+    // 4-wave x 64-row kernel (duo_prefill_w64.h): the default whenever it applies — bf16, no key-range split,
+    // segment B == the query rows; everything else runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
+    // flag bit 7) keeps the 8-wave kernel everywhere (same-box A/B, tests of both kernels).
+    static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return !e || atoi(e) != 0; }();
     if constexpr (!F16) {
-        bool w64_ok = want_w64 && tr && P.ksplit == 1;
+        bool w64_ok = want_w64 && tr && P.ksplit == 1 && !(g_debug_flags & 128u);
+        // it pays where cached keys dominate (+8 % on an all-retrieval launch at past 64K) and loses 2-3 % on purely
+        // causal launches (first chunk, streaming heads only — profiles/r2_prefill_w64.md): pick by the retrieval
+        // class's cached length.  Debug bit 8 (no split) doubles as "always", so tests reach every path.
+        if (!(g_debug_flags & 256u) && !(P.cls[0].n_kv_heads > 0 && P.cls[0].a.len >= n_tokens)) w64_ok = false;
         for (int c = 0; c < 2; ++c)
             if (P.cls[c].n_kv_heads > 0 && P.cls[c].b.len != n_tokens) w64_ok = false;
         if (w64_ok) {

@@ -64,43 +64,75 @@ constexpr int W64_DMA_PER_TILE = 2 * 16 / W64_NW;   // 8 global_load_lds per wav
 // one, and as plain C++ it sinks the arithmetic out of the MFMA interleave altogether.
 // (gfx950: a VALU may not read a transcendental's result in the very next slot: exp0, exp1, add0, add1 keeps one
 // independent instruction behind each v_exp.)
-#define W64_SLICE_TXT                                  \
-    "v_fma_f32 %[p0], %[s0], %[c], %[nm]\n\t"          \
-    "v_fma_f32 %[p1], %[s1], %[c], %[nm]\n\t"          \
-    "v_exp_f32 %[p0], %[p0]\n\t"                       \
-    "v_exp_f32 %[p1], %[p1]\n\t"                       \
-    "v_add_f32 %[ps], %[ps], %[p0]\n\t"                \
-    "v_add_f32 %[ps], %[ps], %[p1]\n\t"                \
-    "v_cvt_pk_bf16_f32 %[pk], %[p0], %[p1]"
-#define W64_SLICE_OUT(ps_, pkw_) [p0] "=&v"(w64_p0), [p1] "=&v"(w64_p1), [ps] "+v"(ps_), [pk] "=&v"(pkw_)
-#define W64_SLICE_IN(sx, sl, nm_)                                                                             \
+// The slice is a two-stage pipeline across consecutive statements, so that no instruction waits on the one just
+// before it (v_exp has a long latency, and one wave per SIMD has nothing else to issue meanwhile):
+//   stage A(k):   e0 = exp2(s0 c - m c), e1 = exp2(s1 c - m c)        (fma, fma, exp, exp)  -> temporaries pair k&1
+//   stage B(k-1): psum += e0' + e1';  pk = bf16x2(e0', e1')           (add, add, cvt)       <- pair (k-1)&1
+// W64_SL_AB = A(k) interleaved with B(k-1);  W64_SL_A = A only (first slice);  W64_SL_B = B only (after the last).
+// (the packed word may be an operand of the very next statement's MFMA: v_cvt_pk sits three instructions before the
+// end — a VALU-written MFMA operand needs two wait states)
+#define W64_SL_AB_TXT                                  \
+    "v_fma_f32 %[a0], %[s0], %[c], %[nm]\n\t"          \
+    "v_fma_f32 %[a1], %[s1], %[c], %[nm]\n\t"          \
+    "v_add_f32 %[ps], %[ps], %[b0]\n\t"                \
+    "v_cvt_pk_bf16_f32 %[pk], %[b0], %[b1]\n\t"        \
+    "v_exp_f32 %[a0], %[a0]\n\t"                       \
+    "v_add_f32 %[ps], %[ps], %[b1]\n\t"                \
+    "v_exp_f32 %[a1], %[a1]"
+#define W64_SL_A_TXT                                   \
+    "v_fma_f32 %[a0], %[s0], %[c], %[nm]\n\t"          \
+    "v_fma_f32 %[a1], %[s1], %[c], %[nm]\n\t"          \
+    "v_exp_f32 %[a0], %[a0]\n\t"                       \
+    "v_exp_f32 %[a1], %[a1]"
+#define W64_SL_B_TXT                                   \
+    "v_cvt_pk_bf16_f32 %[pk], %[b0], %[b1]\n\t"        \
+    "v_add_f32 %[ps], %[ps], %[b0]\n\t"                \
+    "v_add_f32 %[ps], %[ps], %[b1]"
+// operand lists: sl = the slice whose stage A runs (scores sx[..]); its stage-B partner is slice sl-1 (word pk_[sl-1])
+#define W64_A_OUT(e_, sl) [a0] "=&v"(e_[(sl) & 1][0]), [a1] "=&v"(e_[(sl) & 1][1])
+#define W64_A_IN(sx, sl, nm_)                                                                                 \
     [s0] "v"(sx[(sl) >> 3][2 * ((sl) & 7)]), [s1] "v"(sx[(sl) >> 3][2 * ((sl) & 7) + 1]), [c] "s"(c), [nm] "v"(nm_)
-// S_B MFMA (accumulate form, i >= 2) + a slice of block A's scores
-#define W64_QKB_SLICE(i, sl)                                                                                  \
-    asm volatile("v_mfma_f32_32x32x16_bf16 %[acc], a[%c[k0]:%c[k1]], a[%c[q0]:%c[q1]], %[acc]\n\t" W64_SLICE_TXT  \
-                 : [acc] "+v"(sb[(i) & 1]), W64_SLICE_OUT(psumA, pkA[sl])                                     \
-                 : W64_SLICE_IN(sa, sl, nmA), [k0] "n"(192 + 4 * (i)), [k1] "n"(195 + 4 * (i)),               \
-                   [q0] "n"(160 + 4 * ((i) >> 1)), [q1] "n"(163 + 4 * ((i) >> 1)))
-// O_x MFMA + a slice of block y's scores (sx / psum / pk / nm of block y)
-#define W64_PV_SLICE(x, i, vfrag, pfrag, sx, sl, ps_, pk_, nm_)                                               \
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[pf], a[%c[o0]:%c[o1]]\n\t" W64_SLICE_TXT \
-                 : W64_SLICE_OUT(ps_, pk_[sl])                                                                \
-                 : W64_SLICE_IN(sx, sl, nm_), [vf] "v"(vfrag), [pf] "v"(pfrag),                               \
-                   [o0] "n"(64 * (x) + 16 * ((i) & 3)), [o1] "n"(64 * (x) + 16 * ((i) & 3) + 15))
-// O_B MFMA + K(t+1) fragment read (+ a slice of block B)
-#define W64_PVB_KRD(i, vfrag, pfrag, addr, off)                                                               \
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[pf], a[%c[o0]:%c[o1]]\n\t"             \
-                 "ds_read_b128 a[%c[k0]:%c[k1]], %[ka] offset:%c[ko]"                                         \
-                 :: [vf] "v"(vfrag), [pf] "v"(pfrag), [ka] "v"(addr), [ko] "n"(off),                          \
-                    [o0] "n"(64 + 16 * ((i) & 3)), [o1] "n"(64 + 16 * ((i) & 3) + 15),                        \
-                    [k0] "n"(192 + 4 * (i)), [k1] "n"(195 + 4 * (i)) : "memory")
-#define W64_PVB_KRD_SLICE(i, vfrag, pfrag, addr, off, sl)                                                     \
-    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[pf], a[%c[o0]:%c[o1]]\n\t"             \
-                 "ds_read_b128 a[%c[k0]:%c[k1]], %[ka] offset:%c[ko]\n\t" W64_SLICE_TXT                       \
-                 : W64_SLICE_OUT(psumB, pkB[sl])                                                              \
-                 : W64_SLICE_IN(sb, sl, nmB), [vf] "v"(vfrag), [pf] "v"(pfrag), [ka] "v"(addr), [ko] "n"(off), \
-                   [o0] "n"(64 + 16 * ((i) & 3)), [o1] "n"(64 + 16 * ((i) & 3) + 15),                         \
-                   [k0] "n"(192 + 4 * (i)), [k1] "n"(195 + 4 * (i)) : "memory")
+#define W64_B_OUT(ps_, pk_, slb) [ps] "+v"(ps_), [pk] "=&v"(pk_[slb])
+#define W64_B_IN(e_, slb) [b0] "v"(e_[(slb) & 1][0]), [b1] "v"(e_[(slb) & 1][1])
+// MFMA texts
+#define W64_TXT_QKB "v_mfma_f32_32x32x16_bf16 %[acc], a[%c[k0]:%c[k1]], a[%c[q0]:%c[q1]], %[acc]\n\t"
+#define W64_TXT_PV "v_mfma_f32_32x32x16_bf16 a[%c[o0]:%c[o1]], %[vf], %[pf], a[%c[o0]:%c[o1]]\n\t"
+#define W64_TXT_KRD "ds_read_b128 a[%c[k0]:%c[k1]], %[ka] offset:%c[ko]\n\t"
+#define W64_TXT_KRD2 "ds_read_b128 a[%c[k2]:%c[k3]], %[kb] offset:%c[kp]\n\t"
+#define W64_OPS_QKB(i) [k0] "n"(192 + 4 * (i)), [k1] "n"(195 + 4 * (i)), [q0] "n"(160 + 4 * ((i) >> 1)), [q1] "n"(163 + 4 * ((i) >> 1))
+#define W64_OPS_PV(x, i, vfrag, pfrag) [vf] "v"(vfrag), [pf] "v"(pfrag), [o0] "n"(64 * (x) + 16 * ((i) & 3)), [o1] "n"(64 * (x) + 16 * ((i) & 3) + 15)
+#define W64_OPS_KRD(j, addr, off) [ka] "v"(addr), [ko] "n"(off), [k0] "n"(192 + 4 * (j)), [k1] "n"(195 + 4 * (j))
+#define W64_OPS_KRD2(j, addr, off) [kb] "v"(addr), [kp] "n"(off), [k2] "n"(192 + 4 * (j)), [k3] "n"(195 + 4 * (j))
+// S_B MFMA i (accumulate form) + stage A of A-slice sl [+ stage B of A-slice sl-1]
+#define W64_QKB_A(i, sl)                                                                                      \
+    asm volatile(W64_TXT_QKB W64_SL_A_TXT : [acc] "+v"(sb[(i) & 1]), W64_A_OUT(eA, sl)                         \
+                 : W64_A_IN(sa, sl, nmA), W64_OPS_QKB(i))
+#define W64_QKB_AB(i, sl)                                                                                     \
+    asm volatile(W64_TXT_QKB W64_SL_AB_TXT                                                                    \
+                 : [acc] "+v"(sb[(i) & 1]), W64_A_OUT(eA, sl), W64_B_OUT(psumA, pkA, (sl) - 1)                 \
+                 : W64_A_IN(sa, sl, nmA), W64_B_IN(eA, (sl) - 1), W64_OPS_QKB(i))
+// O_x MFMA i + stage A of slice sl of block y [+ stage B of slice sl-1]   (e_/ps_/pk_/nm_/sx of block y)
+#define W64_PV_A(x, i, vfrag, pfrag, sx, sl, e_, nm_)                                                         \
+    asm volatile(W64_TXT_PV W64_SL_A_TXT : W64_A_OUT(e_, sl) : W64_A_IN(sx, sl, nm_), W64_OPS_PV(x, i, vfrag, pfrag))
+#define W64_PV_AB(x, i, vfrag, pfrag, sx, sl, e_, ps_, pk_, nm_)                                              \
+    asm volatile(W64_TXT_PV W64_SL_AB_TXT : W64_A_OUT(e_, sl), W64_B_OUT(ps_, pk_, (sl) - 1)                   \
+                 : W64_A_IN(sx, sl, nm_), W64_B_IN(e_, (sl) - 1), W64_OPS_PV(x, i, vfrag, pfrag))
+#define W64_PV_B(x, i, vfrag, pfrag, slb, e_, ps_, pk_)                                                       \
+    asm volatile(W64_TXT_PV W64_SL_B_TXT : W64_B_OUT(ps_, pk_, slb) : W64_B_IN(e_, slb), W64_OPS_PV(x, i, vfrag, pfrag))
+// O_B MFMA i + TWO K(t+1) fragment reads (fragments 2i, 2i+1: all 16 requested under the first 8 MFMAs, so the
+// last one has half a phase to land before P1 waits for it) [+ B-slice stages]
+// (W64_KA(j) / W64_KOF(j): LDS address register and immediate offset of K fragment j in the NEXT tile's ring slot —
+// defined at the use site)
+#define W64_PVB_K2_AB(i, vfrag, pfrag, sl)                                                                    \
+    asm volatile(W64_TXT_PV W64_TXT_KRD W64_TXT_KRD2 W64_SL_AB_TXT                                            \
+                 : W64_A_OUT(eB, sl), W64_B_OUT(psumB, pkB, (sl) - 1)                                          \
+                 : W64_A_IN(sb, sl, nmB), W64_B_IN(eB, (sl) - 1), W64_OPS_PV(1, i, vfrag, pfrag),              \
+                   W64_OPS_KRD(2 * (i), W64_KA(2 * (i)), W64_KOF(2 * (i))),                                    \
+                   W64_OPS_KRD2(2 * (i) + 1, W64_KA(2 * (i) + 1), W64_KOF(2 * (i) + 1)) : "memory")
+#define W64_PVB_K2(i, vfrag, pfrag)                                                                           \
+    asm volatile(W64_TXT_PV W64_TXT_KRD W64_TXT_KRD2 "s_nop 0"                                                \
+                 :: W64_OPS_PV(1, i, vfrag, pfrag), W64_OPS_KRD(2 * (i), W64_KA(2 * (i)), W64_KOF(2 * (i))),   \
+                    W64_OPS_KRD2(2 * (i) + 1, W64_KA(2 * (i) + 1), W64_KOF(2 * (i) + 1)) : "memory")
 // compiler-generated code is about to read (or an MFMA to re-read) registers an asm MFMA may still be writing
 __device__ __forceinline__ void w64_mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
@@ -273,6 +305,13 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
         for (int r = 3; r < 15; r += 2) t0 = w64_max3(t0, h[r], h[r + 1]);
         return w64_max3(t0, h[15], h[15]);
     };
+    // a quarter of a score tile (8 registers) folded into a running maximum: 4 x v_max3
+    auto quarter_max = [&](float run, const f32x16 &h, int r0) -> float {
+        run = w64_max3(run, h[r0], h[r0 + 1]);
+        run = w64_max3(run, h[r0 + 2], h[r0 + 3]);
+        run = w64_max3(run, h[r0 + 4], h[r0 + 5]);
+        return w64_max3(run, h[r0 + 6], h[r0 + 7]);
+    };
     auto row_max_finish = [&](float t0, float t1) -> float {
         const float tmax = w64_max3(t0, t1, t1);
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -370,19 +409,34 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
     //      per K/V piece pair).  With one wave per SIMD every instruction is a serial issue slot next to the MFMAs.
     const int nBulk = (max(0, lenA / KVBLK - 2) / NSTAGE) * NSTAGE;
     const int64_t tileA_elems = (int64_t)KVBLK * C.a.token_stride;
+    const int64_t tileB_elems = (int64_t)KVBLK * C.b.token_stride;
     const bf16_t *run_k = C.a.k + (int64_t)kvh * C.a.head_stride + 2 * tileA_elems;    // tile t+2, t = 0
     const bf16_t *run_v = C.a.v + (int64_t)kvh * C.a.head_stride + 2 * tileA_elems;
-    uint32_t bk_ofs[4], bv_ofs[4];
+    uint32_t bk_ofs[4], bv_ofs[4];      // segment A: per-lane source byte offsets of piece pair j
+    uint32_t ck_ofs[4], cv_ofs[4];      // segment B
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         bk_ofs[j] = dmaA.kofs + (uint32_t)(j * 4 * W64_NW * C.a.token_stride * 2);
         bv_ofs[j] = dmaA.vofs + (uint32_t)(j * 4 * W64_NW * C.a.token_stride * 2);
+        ck_ofs[j] = dmaB.kofs + (uint32_t)(j * 4 * W64_NW * C.b.token_stride * 2);
+        cv_ofs[j] = dmaB.vofs + (uint32_t)(j * 4 * W64_NW * C.b.token_stride * 2);
     }
     const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(smem_lds + wave * 1024);
+    // The same for the chunk's own tiles (segment B) that EVERY row of the workgroup sees in full: tiles whose last
+    // key is not after the workgroup's first query row.  Bulk runs start on a ring-slot-0 tile and cover whole
+    // ring turns; tile t+2 of every bulk tile must itself be a full tile of segment B.
+    //   tB0: first t >= max(nA, end of the general tiles after bulk A) with t % 3 == 0
+    //   visible in full:  (t - nA) * 64 + 63 <= q0;   tile t+2 full and existing: (t + 3 - nA) * 64 <= S
+    const int tB0 = ((max(nA, nBulk) + NSTAGE - 1) / NSTAGE) * NSTAGE;
+    const int lastB_vis = nA + (q0 + 1) / KVBLK;                   // exclusive: tiles [nA, lastB_vis) are fully visible
+    const int lastB_dma = nA + S / KVBLK - 2;                      // exclusive: tile t+2 is a full tile of segment B
+    const int nBulkB = tB0 < min(lastB_vis, lastB_dma) ? ((min(lastB_vis, lastB_dma) - tB0) / NSTAGE) * NSTAGE : 0;
+    const int tB1 = tB0 + nBulkB;
 
-    auto tile_body = [&](auto slot_c, auto bulk_c, int t) {
+    auto tile_body = [&](auto slot_c, auto bulk_c, int t) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slot_c)::value;
-        constexpr bool BULK = decltype(bulk_c)::value;
+        constexpr int MODE = decltype(bulk_c)::value;     // 0 general, 1 bulk tile of segment A, 2 of segment B
+        constexpr bool BULK = MODE != 0;
         constexpr int SOFF = SLOT * STAGE_BYTES;
         constexpr int NSLOT = (SLOT + 1) % NSTAGE;            // ring slot of tile t+1
         constexpr int NSOFF = NSLOT * STAGE_BYTES;
@@ -409,7 +463,7 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
         f32x16 sa[2], sb[2];
         u32x2 vlo[16], vhi[16];     // V^T fragment i = (k-step i>>2, dim block i&3): key quads kq and kq+2
         uint32_t pkA[16], pkB[16];  // packed P words of blocks A and B (slice i -> word i)
-        float w64_p0, w64_p1;       // slice temporaries (asm early-clobber outputs)
+        float eA[2][2], eB[2][2];   // slice pipeline temporaries (pair k&1 of slice k), blocks A and B
         float psumA = 0.f, psumB = 0.f, nmA = 0.f, nmB = 0.f, hmA = 0.f, hmB = 0.f;
         bool fast_p4 = false;       // block B's slices 8..15 and its row sum are finished inside P4
         // the 16-bit ds offset field: ring slot 2 needs its base folded into the address
@@ -433,13 +487,6 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
     do {                                                                                 \
         W64_QK(sa[(i) & 1], i, 0);                                                       \
         W64_V_READ(i);                                                                   \
-        if constexpr (((i) & 3) == 1) {                                                  \
-            if constexpr (BULK)                                                          \
-                w64_dma_pair(run_k, run_v, bk_ofs[(i) >> 2], bv_ofs[(i) >> 2],           \
-                             wave_lds + DSLOT + ((i) >> 2) * W64_NW * 1024,              \
-                             wave_lds + DSLOT + K_TILE_BYTES + ((i) >> 2) * W64_NW * 1024);   \
-            else dma_piece(dn, (i) >> 2);                                                \
-        }                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                               \
     } while (0)
                 W64_P1_STEP(0); W64_P1_STEP(1); W64_P1_STEP(2); W64_P1_STEP(3);
@@ -447,58 +494,62 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
                 W64_P1_STEP(8); W64_P1_STEP(9); W64_P1_STEP(10); W64_P1_STEP(11);
                 W64_P1_STEP(12); W64_P1_STEP(13); W64_P1_STEP(14); W64_P1_STEP(15);
 #undef W64_P1_STEP
-                if constexpr (BULK) {
-                    run_k += tileA_elems;
-                    run_v += tileA_elems;
-                }
                 // ---- P2: S_B, under row max / rescale decision of block A (gaps 2-3) and A's slices 0..11 -------
                 // (S_A's last MFMA precedes two more MFMAs before any VALU reads it: complete)
                 W64_QK(sb[0], 0, 1);
                 W64_QK(sb[1], 1, 1);
                 W64_QK(sb[0], 2, 1);
                 if constexpr (!BULK) mask_tile(sa, 0, inB, key0, cnt);
-                hmA = half_max(sa[0]);
+                hmA = quarter_max(sa[0][0], sa[0], 0);
                 __builtin_amdgcn_sched_barrier(0);
                 W64_QK(sb[1], 3, 1);
-                decide(std::integral_constant<int, 0>{}, row_max_finish(hmA, half_max(sa[1])));
+                hmA = quarter_max(hmA, sa[0], 8);
+                __builtin_amdgcn_sched_barrier(0);
+                W64_QK(sb[0], 4, 1);
+                hmA = quarter_max(hmA, sa[1], 0);
+                __builtin_amdgcn_sched_barrier(0);
+                W64_QK(sb[1], 5, 1);
+                decide(std::integral_constant<int, 0>{}, row_max_finish(hmA, quarter_max(sa[1][8], sa[1], 8)));
                 nmA = (!BULK && mrow[0] == -INFINITY) ? 0.f : -mrow[0] * c;
                 __builtin_amdgcn_sched_barrier(0);
-                W64_QKB_SLICE(4, 0); W64_QKB_SLICE(5, 1); W64_QKB_SLICE(6, 2); W64_QKB_SLICE(7, 3);
-                W64_QKB_SLICE(8, 4); W64_QKB_SLICE(9, 5); W64_QKB_SLICE(10, 6); W64_QKB_SLICE(11, 7);
-                W64_QKB_SLICE(12, 8); W64_QKB_SLICE(13, 9); W64_QKB_SLICE(14, 10); W64_QKB_SLICE(15, 11);
+                W64_QKB_A(6, 0); W64_QKB_AB(7, 1); W64_QKB_AB(8, 2); W64_QKB_AB(9, 3); W64_QKB_AB(10, 4);
+                W64_QKB_AB(11, 5); W64_QKB_AB(12, 6); W64_QKB_AB(13, 7); W64_QKB_AB(14, 8); W64_QKB_AB(15, 9);
                 __builtin_amdgcn_sched_barrier(0);
-                // ---- P3: O_A, under A's slices 12..15 (their P feeds MFMAs 12..15), B's row max (gaps 4-5) and
-                //      B's slices 0..7 -------------------------------------------------------------------------
+                // ---- P3: O_A, under A's slices 10..15 (their P words feed MFMAs 8..15), B's row max (gaps 7-10)
+                //      and B's slices 0..4 ------------------------------------------------------------------------
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V^T(t) fragments
                 __builtin_amdgcn_sched_barrier(0);
-                W64_PV_SLICE(0, 0, W64_VF(0), W64_PFA(0), sa, 12, psumA, pkA, nmA);
-                W64_PV_SLICE(0, 1, W64_VF(1), W64_PFA(0), sa, 13, psumA, pkA, nmA);
-                W64_PV_SLICE(0, 2, W64_VF(2), W64_PFA(0), sa, 14, psumA, pkA, nmA);
-                W64_PV_SLICE(0, 3, W64_VF(3), W64_PFA(0), sa, 15, psumA, pkA, nmA);
-                W64_PV(0, 4, W64_VF(4), W64_PFA(1), "");
+                W64_PV_AB(0, 0, W64_VF(0), W64_PFA(0), sa, 10, eA, psumA, pkA, nmA);
+                W64_PV_AB(0, 1, W64_VF(1), W64_PFA(0), sa, 11, eA, psumA, pkA, nmA);
+                W64_PV_AB(0, 2, W64_VF(2), W64_PFA(0), sa, 12, eA, psumA, pkA, nmA);
+                W64_PV_AB(0, 3, W64_VF(3), W64_PFA(0), sa, 13, eA, psumA, pkA, nmA);
+                W64_PV_AB(0, 4, W64_VF(4), W64_PFA(1), sa, 14, eA, psumA, pkA, nmA);
+                W64_PV_AB(0, 5, W64_VF(5), W64_PFA(1), sa, 15, eA, psumA, pkA, nmA);
+                W64_PV_B(0, 6, W64_VF(6), W64_PFA(1), 15, eA, psumA, pkA);
                 if constexpr (!BULK) mask_tile(sb, 1, inB, key0, cnt);
-                hmB = half_max(sb[0]);
                 __builtin_amdgcn_sched_barrier(0);
-                W64_PV(0, 5, W64_VF(5), W64_PFA(1), "");
-                decide(std::integral_constant<int, 1>{}, row_max_finish(hmB, half_max(sb[1])));
+                W64_PV(0, 7, W64_VF(7), W64_PFA(1), "");
+                hmB = quarter_max(sb[0][0], sb[0], 0);
+                __builtin_amdgcn_sched_barrier(0);
+                W64_PV(0, 8, W64_VF(8), W64_PFA(2), "");
+                hmB = quarter_max(hmB, sb[0], 8);
+                __builtin_amdgcn_sched_barrier(0);
+                W64_PV(0, 9, W64_VF(9), W64_PFA(2), "");
+                hmB = quarter_max(hmB, sb[1], 0);
+                __builtin_amdgcn_sched_barrier(0);
+                W64_PV(0, 10, W64_VF(10), W64_PFA(2), "");
+                decide(std::integral_constant<int, 1>{}, row_max_finish(hmB, quarter_max(sb[1][8], sb[1], 8)));
                 nmB = (!BULK && mrow[1] == -INFINITY) ? 0.f : -mrow[1] * c;
                 __builtin_amdgcn_sched_barrier(0);
-                W64_PV_SLICE(0, 6, W64_VF(6), W64_PFA(1), sb, 0, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 7, W64_VF(7), W64_PFA(1), sb, 1, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 8, W64_VF(8), W64_PFA(2), sb, 2, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 9, W64_VF(9), W64_PFA(2), sb, 3, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 10, W64_VF(10), W64_PFA(2), sb, 4, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 11, W64_VF(11), W64_PFA(2), sb, 5, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 12, W64_VF(12), W64_PFA(3), sb, 6, psumB, pkB, nmB);
-                W64_PV_SLICE(0, 13, W64_VF(13), W64_PFA(3), sb, 7, psumB, pkB, nmB);
-                W64_PV(0, 14, W64_VF(14), W64_PFA(3), "");
-                W64_PV(0, 15, W64_VF(15), W64_PFA(3), "");
+                W64_PV_A(0, 11, W64_VF(11), W64_PFA(2), sb, 0, eB, nmB);
+                W64_PV_AB(0, 12, W64_VF(12), W64_PFA(3), sb, 1, eB, psumB, pkB, nmB);
+                W64_PV_AB(0, 13, W64_VF(13), W64_PFA(3), sb, 2, eB, psumB, pkB, nmB);
+                W64_PV_AB(0, 14, W64_VF(14), W64_PFA(3), sb, 3, eB, psumB, pkB, nmB);
+                W64_PV_AB(0, 15, W64_VF(15), W64_PFA(3), sb, 4, eB, psumB, pkB, nmB);
                 lsum[0] += psumA;
                 fast_p4 = true;
             } else {
                 // ---- block A sees nothing of this (diagonal) tile: plain sequence for block B -------------
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dma_piece(dn, j);
                 W64_V_READ(0); W64_V_READ(1); W64_V_READ(2); W64_V_READ(3); W64_V_READ(4); W64_V_READ(5);
                 W64_V_READ(6); W64_V_READ(7); W64_V_READ(8); W64_V_READ(9); W64_V_READ(10); W64_V_READ(11);
                 W64_V_READ(12); W64_V_READ(13); W64_V_READ(14); W64_V_READ(15);
@@ -516,74 +567,105 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // V^T(t) fragments
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else if (more2) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dma_piece(dn, j);
         }
 
-        // ---- tile t+1 must have landed (tile t+2 may stay in flight), then ONE barrier: it publishes tile t+1
-        //      and retires this tile's LDS reads (K(t) in P4(t-1), V^T(t) in P1: both complete above)
+        // ---- tile t+1 (requested in P4 of the previous tile) must have landed, then ONE barrier: it publishes
+        //      tile t+1 and retires this tile's LDS reads (K(t) in P4(t-1), V^T(t) in P1: both complete above)
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef W64_MEAS_NO_VMWAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef W64_MEAS_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
+        // LDS-DMA of tile t+2 into ring slot (t+2)%3 == (t-1)%3 (its K was read in P4(t-2), its V^T in P1(t-1) of
+        // every wave: all behind the barrier above).  Issued in the bare-MFMA gaps of P4's second half — an
+        // LDS-DMA instruction costs this wave 60-180 cycles of issue depending on what else its phase carries, and
+        // with one wave per SIMD nothing hides that; among bare MFMAs it is cheapest.
+#define W64_DMA(j)                                                                       \
+    do {                                                                                 \
+        if constexpr (MODE == 1)                                                         \
+            w64_dma_pair(run_k, run_v, bk_ofs[j], bv_ofs[j], wave_lds + DSLOT + (j) * W64_NW * 1024,   \
+                         wave_lds + DSLOT + K_TILE_BYTES + (j) * W64_NW * 1024);         \
+        else if constexpr (MODE == 2)                                                    \
+            w64_dma_pair(run_k, run_v, ck_ofs[j], cv_ofs[j], wave_lds + DSLOT + (j) * W64_NW * 1024,   \
+                         wave_lds + DSLOT + K_TILE_BYTES + (j) * W64_NW * 1024);         \
+        else dma_piece(dn, j);                                                           \
+    } while (0)
 
         // ---- P4: O_B, under the K(t+1) fragment reads (a[192:255] is free: its last use was P2) -----------------
         const bool next_active = BULK || (more1 && t + 1 < nTw);
         const uint32_t ka_ = NSOFF >= 32768 ? NSOFF : 0;
         constexpr int KO = NSOFF >= 32768 ? 0 : NSOFF;
         if (active) {
-#define W64_KA(i) (koff[(i) >> 1] + ka_)
-#define W64_KOF(i) (KO + ((i) & 1) * 8192)
+#define W64_KA(j) (koff[(j) >> 1] + ka_)
+#define W64_KOF(j) (KO + ((j) & 1) * 8192)
             if (fast_p4) {
-                // block B's slices 8..15 ride under MFMAs 0..7 (their P words feed MFMAs 8..15)
+                // block B's slices 5..15 ride under MFMAs 0..10 (P words 4..7 feed MFMA 4.., 8..11 MFMA 8.., 12..15 MFMA 12..)
                 if (next_active) {
-                    W64_PVB_KRD_SLICE(0, W64_VF(0), W64_PFB(0), W64_KA(0), W64_KOF(0), 8);
-                    W64_PVB_KRD_SLICE(1, W64_VF(1), W64_PFB(0), W64_KA(1), W64_KOF(1), 9);
-                    W64_PVB_KRD_SLICE(2, W64_VF(2), W64_PFB(0), W64_KA(2), W64_KOF(2), 10);
-                    W64_PVB_KRD_SLICE(3, W64_VF(3), W64_PFB(0), W64_KA(3), W64_KOF(3), 11);
-                    W64_PVB_KRD_SLICE(4, W64_VF(4), W64_PFB(1), W64_KA(4), W64_KOF(4), 12);
-                    W64_PVB_KRD_SLICE(5, W64_VF(5), W64_PFB(1), W64_KA(5), W64_KOF(5), 13);
-                    W64_PVB_KRD_SLICE(6, W64_VF(6), W64_PFB(1), W64_KA(6), W64_KOF(6), 14);
-                    W64_PVB_KRD_SLICE(7, W64_VF(7), W64_PFB(1), W64_KA(7), W64_KOF(7), 15);
-                    W64_PVB_KRD(8, W64_VF(8), W64_PFB(2), W64_KA(8), W64_KOF(8));
-                    W64_PVB_KRD(9, W64_VF(9), W64_PFB(2), W64_KA(9), W64_KOF(9));
-                    W64_PVB_KRD(10, W64_VF(10), W64_PFB(2), W64_KA(10), W64_KOF(10));
-                    W64_PVB_KRD(11, W64_VF(11), W64_PFB(2), W64_KA(11), W64_KOF(11));
-                    W64_PVB_KRD(12, W64_VF(12), W64_PFB(3), W64_KA(12), W64_KOF(12));
-                    W64_PVB_KRD(13, W64_VF(13), W64_PFB(3), W64_KA(13), W64_KOF(13));
-                    W64_PVB_KRD(14, W64_VF(14), W64_PFB(3), W64_KA(14), W64_KOF(14));
-                    W64_PVB_KRD(15, W64_VF(15), W64_PFB(3), W64_KA(15), W64_KOF(15));
+                    W64_PVB_K2_AB(0, W64_VF(0), W64_PFB(0), 5);
+                    W64_PVB_K2_AB(1, W64_VF(1), W64_PFB(0), 6);
+                    W64_PVB_K2_AB(2, W64_VF(2), W64_PFB(0), 7);
+                    W64_PVB_K2_AB(3, W64_VF(3), W64_PFB(0), 8);
+                    W64_PVB_K2_AB(4, W64_VF(4), W64_PFB(1), 9);
+                    W64_PVB_K2_AB(5, W64_VF(5), W64_PFB(1), 10);
+                    W64_PVB_K2_AB(6, W64_VF(6), W64_PFB(1), 11);
+                    W64_PVB_K2_AB(7, W64_VF(7), W64_PFB(1), 12);
                 } else {
-                    W64_PV_SLICE(1, 0, W64_VF(0), W64_PFB(0), sb, 8, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 1, W64_VF(1), W64_PFB(0), sb, 9, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 2, W64_VF(2), W64_PFB(0), sb, 10, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 3, W64_VF(3), W64_PFB(0), sb, 11, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 4, W64_VF(4), W64_PFB(1), sb, 12, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 5, W64_VF(5), W64_PFB(1), sb, 13, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 6, W64_VF(6), W64_PFB(1), sb, 14, psumB, pkB, nmB);
-                    W64_PV_SLICE(1, 7, W64_VF(7), W64_PFB(1), sb, 15, psumB, pkB, nmB);
-                    W64_PV(1, 8, W64_VF(8), W64_PFB(2), ""); W64_PV(1, 9, W64_VF(9), W64_PFB(2), "");
-                    W64_PV(1, 10, W64_VF(10), W64_PFB(2), ""); W64_PV(1, 11, W64_VF(11), W64_PFB(2), "");
-                    W64_PV(1, 12, W64_VF(12), W64_PFB(3), ""); W64_PV(1, 13, W64_VF(13), W64_PFB(3), "");
-                    W64_PV(1, 14, W64_VF(14), W64_PFB(3), ""); W64_PV(1, 15, W64_VF(15), W64_PFB(3), "");
+                    W64_PV_AB(1, 0, W64_VF(0), W64_PFB(0), sb, 5, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 1, W64_VF(1), W64_PFB(0), sb, 6, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 2, W64_VF(2), W64_PFB(0), sb, 7, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 3, W64_VF(3), W64_PFB(0), sb, 8, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 4, W64_VF(4), W64_PFB(1), sb, 9, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 5, W64_VF(5), W64_PFB(1), sb, 10, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 6, W64_VF(6), W64_PFB(1), sb, 11, eB, psumB, pkB, nmB);
+                    W64_PV_AB(1, 7, W64_VF(7), W64_PFB(1), sb, 12, eB, psumB, pkB, nmB);
                 }
+                W64_PV_AB(1, 8, W64_VF(8), W64_PFB(2), sb, 13, eB, psumB, pkB, nmB);
+                W64_PV_AB(1, 9, W64_VF(9), W64_PFB(2), sb, 14, eB, psumB, pkB, nmB);
+                W64_PV_AB(1, 10, W64_VF(10), W64_PFB(2), sb, 15, eB, psumB, pkB, nmB);
+                W64_PV_B(1, 11, W64_VF(11), W64_PFB(2), 15, eB, psumB, pkB);
                 lsum[1] += psumB;
-            } else if (next_active) {
-#define W64_P4K(i) W64_PVB_KRD(i, W64_VF(i), W64_PFB((i) >> 2), W64_KA(i), W64_KOF(i))
-                W64_P4K(0); W64_P4K(1); W64_P4K(2); W64_P4K(3); W64_P4K(4); W64_P4K(5); W64_P4K(6); W64_P4K(7);
-                W64_P4K(8); W64_P4K(9); W64_P4K(10); W64_P4K(11); W64_P4K(12); W64_P4K(13); W64_P4K(14); W64_P4K(15);
-#undef W64_P4K
             } else {
-#define W64_P4L(i) W64_PV(1, i, W64_VF(i), W64_PFB((i) >> 2), "")
-                W64_P4L(0); W64_P4L(1); W64_P4L(2); W64_P4L(3); W64_P4L(4); W64_P4L(5); W64_P4L(6); W64_P4L(7);
-                W64_P4L(8); W64_P4L(9); W64_P4L(10); W64_P4L(11); W64_P4L(12); W64_P4L(13); W64_P4L(14); W64_P4L(15);
-#undef W64_P4L
+                if (next_active) {
+#define W64_P4K(i) W64_PVB_K2(i, W64_VF(i), W64_PFB((i) >> 2))
+                    W64_P4K(0); W64_P4K(1); W64_P4K(2); W64_P4K(3); W64_P4K(4); W64_P4K(5); W64_P4K(6); W64_P4K(7);
+#undef W64_P4K
+                } else {
+                    W64_PV(1, 0, W64_VF(0), W64_PFB(0), ""); W64_PV(1, 1, W64_VF(1), W64_PFB(0), "");
+                    W64_PV(1, 2, W64_VF(2), W64_PFB(0), ""); W64_PV(1, 3, W64_VF(3), W64_PFB(0), "");
+                    W64_PV(1, 4, W64_VF(4), W64_PFB(1), ""); W64_PV(1, 5, W64_VF(5), W64_PFB(1), "");
+                    W64_PV(1, 6, W64_VF(6), W64_PFB(1), ""); W64_PV(1, 7, W64_VF(7), W64_PFB(1), "");
+                }
+                W64_PV(1, 8, W64_VF(8), W64_PFB(2), "");
             }
+            // the remaining MFMAs of each variant, with the DMA of tile t+2 in their (bare) gaps
+            if (!fast_p4) {
+                W64_PV(1, 9, W64_VF(9), W64_PFB(2), ""); W64_PV(1, 10, W64_VF(10), W64_PFB(2), "");
+                W64_PV(1, 11, W64_VF(11), W64_PFB(2), "");
+            }
+            W64_PV(1, 12, W64_VF(12), W64_PFB(3), "");
+            if (more2) W64_DMA(0);
+            W64_PV(1, 13, W64_VF(13), W64_PFB(3), "");
+            if (more2) W64_DMA(1);
+            W64_PV(1, 14, W64_VF(14), W64_PFB(3), "");
+            if (more2) W64_DMA(2);
+            W64_PV(1, 15, W64_VF(15), W64_PFB(3), "");
+            if (more2) W64_DMA(3);
 #undef W64_KA
 #undef W64_KOF
+        } else if (more2) {
+            W64_DMA(0); W64_DMA(1); W64_DMA(2); W64_DMA(3);
         }
+        if constexpr (MODE == 1) {
+            run_k += tileA_elems;
+            run_v += tileA_elems;
+        } else if constexpr (MODE == 2) {
+            run_k += tileB_elems;
+            run_v += tileB_elems;
+        }
+#undef W64_DMA
         __builtin_amdgcn_sched_barrier(0);
 #undef W64_V_READ
 #undef W64_PFA
@@ -591,15 +673,28 @@ void duo_prefill_w64_kernel(const PrefillParams P) {
 #undef W64_VF
     };
 
-    for (int t = 0; t < nBulk; t += NSTAGE) {
-        tile_body(std::integral_constant<int, 0>{}, std::true_type{}, t);
-        tile_body(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
-        tile_body(std::integral_constant<int, 2>{}, std::true_type{}, t + 2);
-    }
-    for (int t = nBulk; t < nT; t += NSTAGE) {
-        tile_body(std::integral_constant<int, 0>{}, std::false_type{}, t);
-        if (t + 1 < nT) tile_body(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
-        if (t + 2 < nT) tile_body(std::integral_constant<int, 2>{}, std::false_type{}, t + 2);
+    typedef std::integral_constant<int, 0> general_t;
+    typedef std::integral_constant<int, 1> bulkA_t;
+    typedef std::integral_constant<int, 2> bulkB_t;
+    // one loop over ring turns (3 tiles); the flavour of a turn is wave-uniform
+    for (int t = 0; t < nT; t += NSTAGE) {
+        if (t < nBulk) {
+            tile_body(std::integral_constant<int, 0>{}, bulkA_t{}, t);
+            tile_body(std::integral_constant<int, 1>{}, bulkA_t{}, t + 1);
+            tile_body(std::integral_constant<int, 2>{}, bulkA_t{}, t + 2);
+        } else if (t >= tB0 && t < tB1) {
+            if (t == tB0) {
+                run_k = C.b.k + (int64_t)kvh * C.b.head_stride + (int64_t)(tB0 + 2 - nA) * tileB_elems;
+                run_v = C.b.v + (int64_t)kvh * C.b.head_stride + (int64_t)(tB0 + 2 - nA) * tileB_elems;
+            }
+            tile_body(std::integral_constant<int, 0>{}, bulkB_t{}, t);
+            tile_body(std::integral_constant<int, 1>{}, bulkB_t{}, t + 1);
+            tile_body(std::integral_constant<int, 2>{}, bulkB_t{}, t + 2);
+        } else {
+            tile_body(std::integral_constant<int, 0>{}, general_t{}, t);
+            if (t + 1 < nT) tile_body(std::integral_constant<int, 1>{}, general_t{}, t + 1);
+            if (t + 2 < nT) tile_body(std::integral_constant<int, 2>{}, general_t{}, t + 2);
+        }
     }
 
     // ---- epilogue: O^T / l -> out[q][qh][d] -----------------------------------------------------------

@@ -84,9 +84,17 @@ def _check_prefill(S, past, nf, ns, G, W, g, n_sample=48, first_chunk=False):
     return q, out
 
 
-def test_cfg2_llama3_128k_last_chunk():
+@pytest.mark.parametrize("flags", [0, 128], ids=["w4x64", "w8x32"])
+def test_cfg2_llama3_128k_last_chunk(flags):
+    """(both prefill kernels at the bench workload's own launch shape)"""
+    from duo_attn import _hip
+
     g = torch.Generator(device=DEV).manual_seed(2)
-    _check_prefill(S=16384, past=131072 - 16384, nf=4, ns=4, G=4, W=384, g=g)
+    _hip.set_debug_flags(flags)
+    try:
+        _check_prefill(S=16384, past=131072 - 16384, nf=4, ns=4, G=4, W=384, g=g)
+    finally:
+        _hip.set_debug_flags(0)
 
 
 def test_cfg2_llama3_128k_first_chunk():

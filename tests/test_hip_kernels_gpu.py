@@ -332,16 +332,29 @@ PREFILL_CASES = [
 ]
 
 
+# which prefill kernel a launch lands on: 0 = automatic (4-wave x 64-row kernel unless the launcher splits the key
+# range), 128 = the 8-wave x 32-row kernel everywhere, 256 = no key-range split -> always the 4-wave kernel
+PREFILL_KERNELS = [0, 128, 256]
+
+
+@pytest.fixture(params=PREFILL_KERNELS, ids=["auto", "w8x32", "w4x64"])
+def prefill_kernel(request):
+    h = _hip()
+    h.set_debug_flags(request.param)
+    yield request.param
+    h.set_debug_flags(0)
+
+
 @pytest.mark.parametrize("case", PREFILL_CASES)
 @pytest.mark.parametrize("head_major", [True, False])
-def test_prefill_later_chunk(case, head_major):
+def test_prefill_later_chunk(case, head_major, prefill_kernel):
     S, group, nf, ns, la, ls = case
     out, ref, bud = _attention_case(S, group, nf, ns, la, ls, head_major, seed=hash(case) % 1000)
     attn_close(out, ref, f"prefill {case} hm={head_major}", bud)
 
 
 @pytest.mark.parametrize("S,group,nkv", [(2, 4, 2), (65, 4, 2), (256, 4, 1), (300, 1, 4), (1025, 4, 2)])
-def test_prefill_first_chunk(S, group, nkv):
+def test_prefill_first_chunk(S, group, nkv, prefill_kernel):
     out, ref, bud = _attention_case(S, group, nkv, 0, 0, 0, True, seed=S, first_chunk=True)
     attn_close(out, ref, f"first chunk S={S}", bud)
 
@@ -399,12 +412,13 @@ def test_prefill_key_range_splits_agree_with_single_pass():
 
 
 def test_prefill_without_transpose_read_matches():
-    """ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
+    """8-wave kernel: ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
     h = _hip()
     case = (300, 4, 1, 1, 200, 384)
-    out_tr, ref, bud = _attention_case(*case, True, seed=5)
-    h.set_debug_flags(1)
+    h.set_debug_flags(128)            # bit 7: the 8-wave kernel (the gather path only exists there)
     try:
+        out_tr, ref, bud = _attention_case(*case, True, seed=5)
+        h.set_debug_flags(128 | 1)
         out_gather, _, _ = _attention_case(*case, True, seed=5)
     finally:
         h.set_debug_flags(0)
@@ -412,7 +426,7 @@ def test_prefill_without_transpose_read_matches():
     attn_close(out_gather, ref, "prefill (gather V path)", bud)
 
 
-def test_softmax_rescale_branch_spike():
+def test_softmax_rescale_branch_spike(prefill_kernel):
     """A key late in the sequence that dominates every earlier score forces the online-softmax
     rescale path (m jumps by >> 8 in the last tiles)."""
     from duo_attn.backend import HipBackend
@@ -427,6 +441,28 @@ def test_softmax_rescale_branch_spike():
     ref, bud = flash_attn_func_ref(q[None], k[None], v[None], round_p=False, out_dtype=torch.float32,
                                    return_budget=True)
     attn_close(out, ref[0], "spike", bud[0])
+
+
+def test_rescale_inside_cached_segment_both_row_blocks(prefill_kernel):
+    """Keys deep inside the cached segment (the 4-wave kernel's bulk tiles: full 64-key tiles, no masks) that
+    dominate every earlier score of chosen query rows — rows of the first AND the second 32-row block of a wave,
+    and a second, even larger spike later — force the deferred-rescale branch (O, the row sum and the running
+    maximum rescaled; in the 4-wave kernel O lives in asm-owned accumulator registers) at a chosen tile for each."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(13)
+    S, group, lenA = 200, 4, 1100
+    q = _rand((S, group, D), g)
+    kp, vp = _rand((lenA, 1, D), g), _rand((lenA, 1, D), g)
+    kn, vn = _rand((S, 1, D), g), _rand((S, 1, D), g)
+    for row, head, key, gain in ((5, 0, 300, 3.0), (40, 1, 333, 3.0), (70, 2, 520, 3.0), (120, 3, 700, 3.0),
+                                 (5, 0, 900, 8.0), (40, 1, 64 * 3 + 1, 2.5)):
+        kp[key, 0] = (q[row, head].float() * gain).to(torch.bfloat16)
+    out = torch.empty(S, group, D, dtype=torch.bfloat16, device=DEV)
+    HipBackend().attention(q.to(DEV), out, group, (1, 0, (kp.to(DEV), vp.to(DEV)), (kn.to(DEV), vn.to(DEV))), None, D ** -0.5)
+    kk, vv = torch.cat([kp, kn], 0), torch.cat([vp, vn], 0)
+    ref, bud = flash_attn_func_ref(q[None], kk[None], vv[None], round_p=False, out_dtype=torch.float32, return_budget=True)
+    attn_close(out, ref[0], "rescale in cached tiles", bud[0])
 
 
 # ----------------------------------------------------------------------------- whole hot path
