@@ -335,12 +335,18 @@ def measure_traffic(args):
         cur = sqlite3.connect(dbs[0]).cursor()
         rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
                            "where counter_name = 'FETCH_SIZE' group by kernel_name").fetchall()
-        res, n = {}, {}
+        # the prefill attention of a launch runs on duo_prefill_w64_kernel (4 waves x 64 rows) or duo_prefill_kernel
+        # (8 waves x 32 rows: first chunk, split launches): one figure = launch-weighted mean over both
+        res, n, acc = {}, {}, {}
         for name, mean, cnt in rows:
-            for key in ("duo_prefill_kernel", "duo_decode_split_kernel"):
-                if key in name:
-                    res[key] = float(mean) * 1024.0 * 2.0
-                    n[key] = cnt
+            key = "duo_prefill" if ("duo_prefill_w64_kernel" in name or "duo_prefill_kernel" in name) else (
+                "duo_decode_split_kernel" if "duo_decode_split_kernel" in name else None)
+            if key:
+                tot, c0 = acc.get(key, (0.0, 0))
+                acc[key] = (tot + float(mean) * cnt, c0 + cnt)
+        for key, (tot, c0) in acc.items():
+            res[key] = tot / c0 * 1024.0 * 2.0
+            n[key] = c0
         if not res:
             return {}, "unavailable: no FETCH_SIZE rows for the attention kernels in the rocpd database"
         return res, (f"rocprofv3 --pmc FETCH_SIZE --kernel-trace child of this run ({time.strftime('%Y-%m-%d %H:%M:%S')}), "
@@ -541,9 +547,10 @@ def main():
     if not args.no_kernel_roofline:
         pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
-        roof = {"kernel": "duo_prefill_kernel", "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
+        roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows; first chunk / split launches: duo_prefill_kernel, 8 x 32)",
+                "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK,
-                "traffic": traffic.get("duo_prefill_kernel"), "traffic_source": traffic_source,
+                "traffic": traffic.get("duo_prefill"), "traffic_source": traffic_source,
                 "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"],
                 "algorithmic_flops_per_launch": pre["flops"] / pre["launches"]}
         roof_dec = {"kernel": "duo_decode_split_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,

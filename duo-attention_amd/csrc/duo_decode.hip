@@ -672,14 +672,16 @@ static int decode_target_wgs() {
     static int v = [] {
         const char *e = getenv("DUO_DECODE_TARGET_WGS");
         const int x = e ? atoi(e) : 0;
-        return x > 0 ? x : 512;
+        return x > 0 ? x : 256;
     }();
     return v;
 }
 
-// Split policy: one resident round.  The kernel runs 2 workgroups per CU (register-limited), so the
-// grid aims at 2 x 256 workgroups in total; each kv head's 64-token units are dealt evenly to its
-// splits (balanced partition in the kernel).  Never more splits than units or than the workspace holds.
+// Split policy: one resident round of ONE workgroup per CU (256 in total); each kv head's 64-token units are dealt
+// evenly to its splits (balanced partition in the kernel).  Never more splits than units or than the workspace
+// holds.  Measured at 131072 context, 32 layers (profiles/r2_decode_wgs.md): 256 workgroups 1.46-1.49 ms per step of
+// scans, 512 (two per CU, the round-1 choice) 1.54 ms, 384 / 640 (not a multiple of the CU count) 1.63-1.66 ms —
+// fewer, longer workgroups amortise the per-workgroup prologue / epilogue and halve the partials to merge.
 static void choose_splits(int n_kv_heads, int L, int max_splits, int budget_wgs, int &splits) {
     if (n_kv_heads <= 0 || L <= 0) {
         splits = 0;

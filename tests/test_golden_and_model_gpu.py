@@ -10,7 +10,7 @@ import torch
 
 from helpers import ShapeModel, attn_close, heads_from_counts
 from oracle.duo_oracle import StaticCacheRef, static_forward_ref
-from test_oracle_golden import bf16, load, split_hidden
+from test_oracle_golden import bf16, load, split_hidden, ulp_close
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -36,11 +36,17 @@ def test_hip_hot_path_reproduces_reference_golden(name):
         for l in range(len(counts)):
             q, k, v = split_hidden(bf16(g[f"h_{si}_{l}"]), Hq, Hkv, D)
             out = duo_static_attention_core(q.to(DEV), k.to(DEV), v.to(DEV), cache, l, pos, factor, theta)
-            _, bud = static_forward_ref(q, k, v, ref, l, pos, factor, theta, round_p=False,
-                                        out_dtype=torch.float32, return_budget=True)
+            exact, bud = static_forward_ref(q, k, v, ref, l, pos, factor, theta, round_p=False,
+                                            out_dtype=torch.float32, return_budget=True)
             golden = bf16(g[f"o_{si}_{l}"]).view(1, S, Hq, D).float()
-            # golden is itself bf16-rounded: one more ulp of slack than against the fp32 oracle
-            attn_close(out, golden, f"{name} step {si} layer {l}", (bud if S > 1 else 0 * bud) + golden.abs())
+            # (1) against the exact-P fp32 oracle on the same inputs: the usual bar
+            attn_close(out, exact, f"{name} step {si} layer {l}", bud if S > 1 else None)
+            # (2) against the reference's own bf16 output: both sides carry one output rounding -> allow ONE more
+            #     bf16 ulp of the golden value than (1), nothing else
+            err = (out.float().cpu() - golden).abs()
+            tol = (2.0 ** -8) * golden.abs() * 2 + 1e-3 * golden.abs() + (2.0 ** -8) * (bud if S > 1 else 0 * bud) \
+                + 1e-3 * golden.pow(2).mean().sqrt()
+            assert (err <= tol).all(), f"{name} step {si} layer {l}: {int((err > tol).sum())} elements beyond the golden bar"
         if si >= n_prefill:
             cache.evict_last(1)
             ref.evict_last(1)
@@ -51,8 +57,11 @@ def test_hip_hot_path_reproduces_reference_golden(name):
         assert cache.kv_seq_len_list[l] == n and cache.streaming_kv_seq_len_list[l] == m
         assert torch.equal(cache.full_value_states_list[l][:, :n].cpu(), bf16(g[f"fullv_{l}"]))
         assert torch.equal(cache.streaming_value_states_list[l][:, :m].cpu(), bf16(g[f"strv_{l}"]))
-        kd = (cache.full_key_states_list[l][:, :n].cpu().float() - bf16(g[f"fullk_{l}"]).float()).abs()
-        assert kd.numel() == 0 or kd.max() <= 2.0 ** -7 * 8     # RoPE'd keys: one bf16 ulp at |k| < 8
+        # RoPE'd keys: per element within ONE bf16 ulp of the reference's value, on a small fraction of elements
+        # (fp64 angle in the generator's stub vs fp32 angle here, device vs host sincos last bit) — the same bar the
+        # CPU twin holds the oracle to (test_oracle_golden.ulp_close), not an absolute bound
+        ulp_close(cache.full_key_states_list[l][:, :n].cpu(), bf16(g[f"fullk_{l}"]), f"full K {l}", max_frac=0.05)
+        ulp_close(cache.streaming_key_states_list[l][:, :m].cpu(), bf16(g[f"strk_{l}"]), f"stream K {l}", max_frac=0.05)
 
 
 def tiny(family, seed=0):

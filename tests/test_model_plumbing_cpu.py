@@ -197,3 +197,39 @@ def test_without_a_backend_the_patched_model_refuses_cpu():
     enable_duo_attention_eval(model, np.ones((2, 2)), 4, 8)
     with pytest.raises(_hip.DuoHipError, match="no CPU fallback"):
         model(input_ids=torch.zeros(1, 4, dtype=torch.long), use_cache=True)
+
+
+def test_config0_llama2_7b_shape_4k_prompt(exact_backend):
+    """BASELINE configs[0] at its STATED size: Llama-2-7B-32K shape (hidden 4096, 32 q = kv heads of 128 dims, linear
+    rope scaling factor 8), a 4096-token prompt through enable_duo_attention_eval / the static path on the CPU
+    (oracle as backend).  One decoder layer of that shape (the 32 layers are identical in shape; a 7B model is 27 GB
+    in fp32), pattern with 8 of 32 retrieval heads (sparsity 0.75).
+      * static path, window covering the prompt, chunks of 2048 + 3 decode tokens == unpatched HF eager logits;
+      * the same pattern with the shipped sink 128 + recent 256: cache geometry of the 4K prompt."""
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+
+    torch.manual_seed(5)
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=1024, num_hidden_layers=1, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=211, max_position_embeddings=32768, rope_theta=10000.0,
+                      rope_scaling={"rope_type": "linear", "factor": 8.0}, attn_implementation="eager",
+                      tie_word_embeddings=False)
+    ref = LlamaForCausalLM(cfg).float().eval()
+    N = 4096
+    ids = torch.randint(0, 211, (1, N + 3), generator=torch.Generator().manual_seed(6))
+    heads = np.zeros((1, 32))
+    heads[0, [1, 4, 5, 9, 16, 22, 27, 31]] = 1.0
+    model = copy.deepcopy(ref)
+    enable_llama_duo_attention_static_kv_cache_eval(model, heads.copy())
+    kv = DuoAttentionStaticKVCache(model, heads, 1, N + 8, 2048, 2560)        # window >= context: == full attention
+    outs, _ = run_chunks(model, ids, [2048, 2048, 1, 1, 1], past=kv)
+    want = hf_last_logits(ref, ids)
+    assert kv.kv_seq_len == N + 3 and kv.num_full_kv_head_list == [8]
+    rel = ((outs[-1] - want).norm() / want.norm()).item()
+    assert rel < 2e-3, rel          # fp32 model; linear rope factor 8 applied identically on both sides
+    # shipped window: the streaming pool saturates at sink + recent rows, the retrieval pool holds the prompt
+    kv2 = DuoAttentionStaticKVCache(model, heads, 1, N + 8, 128, 256)
+    outs2, _ = run_chunks(model, ids[:, :N], [2048, 2048], past=kv2)
+    assert kv2.kv_seq_len == N and kv2.streaming_kv_seq_len == 384
+    assert kv2.full_key_states_list[0].shape == (1, N + 8, 8, 128) and kv2.streaming_key_states_list[0].shape == (1, 384, 24, 128)
+    assert kv2.memory_usage == 2 * ((N + 8) * 8 + 384 * 24) * 128 * 4              # K and V, fp32 model here
+    assert torch.isfinite(outs2[-1]).all() and not torch.allclose(outs2[-1], outs[1], atol=1e-3)   # eviction changes the result
