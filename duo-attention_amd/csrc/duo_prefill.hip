@@ -704,3 +704,9 @@ extern "C" int duo_attn_prefill_ws_f16(const void *q, int64_t q_token_stride, in
     return prefill_impl<true>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
                               group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream);
 }
+
+#ifdef W64_TIMING      /* measurement builds only (tools/debug): per-phase cycle sums of the last w64 launch */
+extern "C" int duo_debug_w64_timing(uint32_t *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w64_timing), 8 * sizeof(uint32_t));
+}
+#endif

@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generates duo-attention_amd/csrc/duo_prefill_w64_bulk.inc: the instruction schedule of ONE bulk tile of the
+4-wave x 64-row prefill kernel (duo_prefill_w64.h), as a sequence of asm statements — one per MFMA "gap".
+
+Why a generator: with one wave per SIMD every instruction next to the 64 MFMAs of a tile is a serial issue slot,
+and a gap hides about five of them (MI355X_MICROARCH, 'one wave per SIMD').  A tile carries ~340 such
+instructions (2 x 16 exponentiation slices of 7, 2 row maxima of 21, 48 LDS fragment reads, 4 LDS-DMA pairs),
+i.e. 5.3 per gap ONLY IF they are spread evenly over all 64 gaps.  Block B's softmax therefore lags block A's by
+half a tile (the skewed order below), and the placement is a table in this file instead of hand-expanded macros.
+
+Tile t, 64 gaps (gap g = the instructions issued behind MFMA g):
+    ph1  g  0..15   S_A(t)  = K(t) . Q_A^T        | block B(t-1) slices (second half), LDS-DMA of tile t+2
+    ph2  g 16..31   O_B    += V^T(t-1) . P_B(t-1) | row max A(t), block A(t) slices, first V^T(t) reads
+    ph3  g 32..47   S_B(t)  = K(t) . Q_B^T        | V^T(t) read burst, block A(t) slices
+         -- lgkmcnt(0), vmcnt(8), ONE s_barrier --
+    ph4  g 48..63   O_A    += V^T(t) . P_A(t)     | K(t+1) fragment reads, row max B(t), block B(t) slices (first half)
+
+Variants: STEADY (above), FIRST (first tile of a bulk run: no block B(t-1) work, no ph2 MFMAs) and DRAIN (after
+the last tile of a run: the pending block-B slices and the 16 ph2 MFMAs only).
+
+Usage: python tools/gen_w64_bulk.py            (rewrites the .inc next to duo_prefill_w64.h)
+"""
+import os
+import sys
+
+
+class Op:
+    def __init__(self, text, operands, n=1, clobbers=()):
+        self.text = text            # "{key}" placeholders; several lines allowed
+        self.operands = operands    # (key, cls, cexpr, access)   cls: v s n sout; access: r w rw
+        self.n = n
+        self.clobbers = tuple(clobbers)
+
+
+AB = "AB"
+ab = "ab"
+
+
+def mfma_qk(x, i):
+    acc = f"s{ab[x]}[{i & 1}]"
+    k0 = 192 + 4 * i
+    q0 = 128 + 32 * x + 4 * (i >> 1)
+    tail = "0" if i < 2 else "{acc}"
+    return Op(f"v_mfma_f32_32x32x16_bf16 {{acc}}, a[{k0}:{k0 + 3}], a[{q0}:{q0 + 3}], {tail}",
+              [("acc", "v", acc, "w" if i < 2 else "rw")])
+
+
+def mfma_pv(x, i):
+    o0 = 64 * x + 16 * (i & 3)
+    return Op(f"v_mfma_f32_32x32x16_bf16 a[{o0}:{o0 + 15}], {{vf}}, {{pf}}, a[{o0}:{o0 + 15}]",
+              [("vf", "v", f"W64_VF({i})", "r"), ("pf", "v", f"W64_PF{AB[x]}({i >> 2})", "r")])
+
+
+def S(x, k, h):
+    return f"s{ab[x]}[{k >> 3}][{2 * (k & 7) + h}]"
+
+
+def E(x, k, h):
+    return f"e{AB[x]}[{k & 1}][{h}]"
+
+
+def fma(x, k, h):
+    return Op("v_fma_f32 {e}, {s}, {c}, {nm}",
+              [("e", "v", E(x, k, h), "w"), ("s", "v", S(x, k, h), "r"), ("c", "s", "c", "r"),
+               ("nm", "v", f"nmv[{x}]", "r")])
+
+
+def exp(x, k, h):
+    return Op("v_exp_f32 {e}, {e}", [("e", "v", E(x, k, h), "rw")])
+
+
+def add(x, k, h):
+    return Op("v_add_f32 {l}, {l}, {e}", [("l", "v", f"lsum[{x}]", "rw"), ("e", "v", E(x, k, h), "r")])
+
+
+def cvt(x, k):
+    return Op("v_cvt_pk_bf16_f32 {pk}, {e0}, {e1}",
+              [("pk", "v", f"pk{AB[x]}[{k}]", "w"), ("e0", "v", E(x, k, 0), "r"), ("e1", "v", E(x, k, 1), "r")])
+
+
+def slice_list(x):
+    """Two-stage pipeline over the 16 slices of a block: stage A(k) = fma, fma, exp, exp into temporaries pair k&1,
+    stage B(k-1) = add, cvt, add from pair (k-1)&1, interleaved so that no instruction reads the one just before it
+    (gfx950: a VALU may not read a transcendental's result in the very next slot)."""
+    L = []
+    for k in range(16):
+        L += [fma(x, k, 0), fma(x, k, 1)]
+        if k:
+            L += [add(x, k - 1, 0), cvt(x, k - 1)]
+        L += [exp(x, k, 0)]
+        if k:
+            L += [add(x, k - 1, 1)]
+        L += [exp(x, k, 1)]
+    L += [add(x, 15, 0), cvt(x, 15), add(x, 15, 1)]
+    return L
+
+
+def e8(x, b, r0):
+    return [(f"e{j}", "v", f"s{ab[x]}[{b}][{r0 + j}]", "r") for j in range(8)]
+
+
+def max_init(x, b, r0):
+    return Op("v_max3_f32 {h0}, {e0}, {e1}, {e2}\n"
+              "v_max3_f32 {h1}, {e3}, {e4}, {e5}\n"
+              "v_max3_f32 {h0}, {h0}, {e6}, {e7}",
+              [("h0", "v", f"h0{AB[x]}", "w"), ("h1", "v", f"h1{AB[x]}", "w")] + e8(x, b, r0), n=3)
+
+
+def max4(x, b, r0, combine=False):
+    t = ("v_max3_f32 {h1}, {h1}, {e0}, {e1}\n"
+         "v_max3_f32 {h0}, {h0}, {e2}, {e3}\n"
+         "v_max3_f32 {h1}, {h1}, {e4}, {e5}\n"
+         "v_max3_f32 {h0}, {h0}, {e6}, {e7}")
+    if combine:
+        t += "\nv_max3_f32 {h0}, {h0}, {h1}, {h1}"
+    return Op(t, [("h0", "v", f"h0{AB[x]}", "rw"), ("h1", "v", f"h1{AB[x]}", "rw")] + e8(x, b, r0),
+              n=5 if combine else 4)
+
+
+def max_fin(x):
+    # partner lane (the other 32 keys of the row), then: which lanes' tile max passed the rescale threshold
+    return Op("v_mov_b32 {h1}, {h0}\n"
+              "s_nop 1\n"
+              "v_permlane32_swap_b32 {h0}, {h1}\n"
+              "v_max3_f32 {h0}, {h0}, {h1}, {h1}\n"
+              "v_cmp_gt_f32 {mk}, {h0}, {thr}",
+              [("h0", "v", f"h0{AB[x]}", "rw"), ("h1", "v", f"h1{AB[x]}", "w"),
+               ("mk", "sout", f"mk{AB[x]}", "w"), ("thr", "v", f"thr[{x}]", "r")], n=5)
+
+
+def vread(i, hi):
+    off = (i >> 2) * 4096 + (i & 3) * 256 + (2048 if hi else 0)
+    return Op("ds_read_b64_tr_b16 {v}, {va} offset:{off}",
+              [("v", "v", f"v{'hi' if hi else 'lo'}[{i}]", "w"), ("va", "v", "va_", "r"),
+               ("off", "n", f"VO + {off}", "r")], clobbers=("memory",))
+
+
+def kread(i):
+    return Op(f"ds_read_b128 a[{192 + 4 * i}:{195 + 4 * i}], {{ka}} offset:{{ko}}",
+              [("ka", "v", f"W64_KA({i})", "r"), ("ko", "n", f"W64_KOF({i})", "r")], clobbers=("memory",))
+
+
+def dma_pair(j):
+    return Op("s_mov_b32 m0, {lk}\n"
+              "s_nop 0\n"
+              "global_load_lds_dwordx4 {kofs}, {kb}\n"
+              "s_mov_b32 m0, {lv}\n"
+              "s_nop 0\n"
+              "global_load_lds_dwordx4 {vofs}, {vb}",
+              [("lk", "s", f"W64_DMA_LDS_K({j})", "r"), ("kofs", "v", f"W64_DMA_KOFS({j})", "r"),
+               ("kb", "s", "run_k", "r"), ("lv", "s", f"W64_DMA_LDS_V({j})", "r"),
+               ("vofs", "v", f"W64_DMA_VOFS({j})", "r"), ("vb", "s", "run_v", "r")],
+              n=6, clobbers=("memory",))   # M0: reserved, the compiler only ever sets it right before a use
+
+
+def raw(text, clobbers=("memory",)):
+    return Op(text, [], n=0, clobbers=clobbers)
+
+
+# ---- the placement table ------------------------------------------------------------------------------------------
+# chain timeline r (block A: gap 17 + r, block B: gap 49 + r, wrapping into the next tile's gaps 0..16):
+#   r 0..4   row max (INIT, MAX4, MAX4, MAX4C, FIN)
+#   r 5..14  slices, r 15..18 idle (block A: the V^T read burst; block B: the LDS-DMA pairs), r 19..31 slices
+SLICE_R = list(range(5, 15)) + list(range(19, 32))
+
+
+def chain_ops(x):
+    """r -> list of ops for block x"""
+    by_r = {0: [max_init(x, 0, 0)], 1: [max4(x, 0, 8)], 2: [max4(x, 1, 0)], 3: [max4(x, 1, 8, combine=True)],
+            4: [max_fin(x)]}
+    L = slice_list(x)
+    sizes = [5] * len(SLICE_R)
+    extra = sum(sizes) - len(L)
+    for j in range(extra):
+        sizes[-1 - j] -= 1
+    assert sum(sizes) == len(L)
+    pos = 0
+    for r, n in zip(SLICE_R, sizes):
+        by_r[r] = L[pos:pos + n]
+        pos += n
+    return by_r
+
+
+DROP = set(filter(None, os.environ.get("W64_GEN_DROP", "").split(",")))   # measurement only: kread vread dma slice max
+
+
+def build_gaps(variant):
+    gaps = build_gaps_full(variant)
+    if not DROP:
+        return gaps
+    def keep(op):
+        t = op.text
+        if "kread" in DROP and t.startswith("ds_read_b128"): return False
+        if "vread" in DROP and t.startswith("ds_read_b64_tr"): return False
+        if "dma" in DROP and "global_load_lds" in t: return False
+        if "slice" in DROP and t.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32"): return False
+        if "max" in DROP and t.startswith("v_max3") : return False
+        return True
+    return [[op for op in g if keep(op)] for g in gaps]
+
+
+def build_gaps_full(variant):
+    A = chain_ops(0)
+    B = chain_ops(1)
+    gaps = []
+    for g in range(64):
+        ops = []
+        ph, i = g >> 4, g & 15
+        # the MFMA of this gap
+        if variant != "DRAIN":
+            if ph == 0:
+                ops.append(mfma_qk(0, i))
+            elif ph == 1:
+                if variant == "STEADY":
+                    ops.append(mfma_pv(1, i))
+            elif ph == 2:
+                ops.append(mfma_qk(1, i))
+            else:
+                ops.append(mfma_pv(0, i))
+        elif ph == 1:
+            ops.append(mfma_pv(1, i))
+        # LDS reads first (they land sooner), then the softmax work, the LDS-DMA pair last
+        if variant != "DRAIN":
+            if 22 <= g <= 31:          # V^T(t) fragments 0..4: their registers were last read by ph2 MFMA 16+f
+                j = g - 22
+                ops.append(vread(j >> 1, j & 1))
+            if 32 <= g <= 35:          # fragments 6..15: five reads per gap (block A's chain idles here)
+                for j in range(5):
+                    q = 12 + (g - 32) * 5 + j
+                    ops.append(vread(q >> 1, q & 1))
+            if g in (36, 37):          # fragment 5
+                ops.append(vread(5, g - 36))
+            if ph == 3:                # K(t+1) fragment i (a[192:255] was last read by ph3)
+                ops.append(kread(i))
+            ops += A.get(g - 17, [])
+            if g >= 49:
+                ops += B.get(g - 49, [])
+        if variant in ("STEADY", "DRAIN") and g + 15 in B and g <= 16:
+            ops += B[g + 15]           # block B of the previous tile
+        if variant != "DRAIN" and g < 4:
+            ops.append(dma_pair(g))
+        gaps.append(ops)
+    return gaps
+
+
+def emit_stmt(ops, out, prefix=None):
+    if not ops and not prefix:
+        return
+    names = {}
+    lines = []
+    clob = []
+    if prefix:
+        lines.append(prefix)
+        clob.append("memory")
+    for op in ops:
+        m = {}
+        for key, cls, cexpr, acc in op.operands:
+            d = names.get(cexpr)
+            if d is None:
+                d = names[cexpr] = {"name": f"x{len(names)}", "cls": cls, "written": False, "read_first": False}
+            if acc in ("r", "rw") and not d["written"]:
+                d["read_first"] = True
+            if acc in ("w", "rw"):
+                d["written"] = True
+            m[key] = ("%c[" if cls == "n" else "%[") + d["name"] + "]"
+        for ln in op.text.split("\n"):
+            lines.append(ln.format(**m))
+        for c in op.clobbers:
+            if c not in clob:
+                clob.append(c)
+    outs, ins = [], []
+    for cexpr, d in names.items():
+        nm = d["name"]
+        if d["cls"] == "n":
+            ins.append(f'[{nm}] "n"({cexpr})')
+        elif d["cls"] == "s":
+            ins.append(f'[{nm}] "s"({cexpr})')
+        elif d["cls"] == "sout":
+            outs.append(f'[{nm}] "=s"({cexpr})')
+        elif not d["written"]:
+            ins.append(f'[{nm}] "v"({cexpr})')
+        elif d["read_first"]:
+            outs.append(f'[{nm}] "+v"({cexpr})')
+        else:
+            outs.append(f'[{nm}] "=&v"({cexpr})')
+    assert len(outs) + len(ins) <= 30, (len(outs), len(ins))
+    out.append("asm volatile(")
+    for k, ln in enumerate(lines):
+        out.append(f'    "{ln}' + ('\\n\\t"' if k + 1 < len(lines) else '"'))
+    out.append("    : " + ", ".join(outs))
+    out.append("    : " + ", ".join(ins))
+    if clob:
+        out.append("    : " + ", ".join(f'"{c}"' for c in clob))
+    out[-1] += ");"
+
+
+def emit_variant(variant, out):
+    gaps = build_gaps(variant)
+    count = sum(op.n for g in gaps for op in g if not op.text.startswith("v_mfma"))
+    out.append(f"#ifdef W64_GEN_{variant}   /* {count} instructions beside the MFMAs */")
+    for g, ops in enumerate(gaps):
+        if variant == "DRAIN" and g >= 32:
+            break
+        prefix = None
+        if variant != "DRAIN":
+            if g == 0:
+                out.append("W64_T(0);")
+                prefix = "s_waitcnt lgkmcnt(8)"      # K(t) fragments 0..7 (read in gaps 48..55 of the previous tile)
+            if g == 8:
+                prefix = "s_waitcnt lgkmcnt(0)"      # fragments 8..15 (no other LDS read since)
+            if g == 16:
+                out.append("W64_T(1);")
+            if g == 32:
+                out.append("W64_T(2);")
+            if g == 48:
+                out.append("W64_T(3);")
+                # V^T(t) landed (last read issued in gap 37); tile t+1 landed (the 8 pieces of tile t+2 may fly);
+                # the barrier publishes tile t+1 and retires every wave's reads of tile t
+                emit_stmt([raw("s_waitcnt lgkmcnt(0)\ns_waitcnt vmcnt(8)\ns_barrier")], out)
+                out.append("W64_T(4);")
+        nfill = sum(op.n for op in ops if not op.text.startswith("v_mfma"))
+        out.append(f"// gap {g}: {nfill}")
+        emit_stmt(ops, out, prefix)
+        if variant != "DRAIN":
+            if g == 21:
+                out.append("if (mkA != 0) rescale(std::integral_constant<int, 0>{}, h0A);")
+                out.append("__builtin_amdgcn_sched_barrier(0);")
+            if g == 53:
+                out.append("if (mkB != 0) rescale(std::integral_constant<int, 1>{}, h0B);")
+                out.append("__builtin_amdgcn_sched_barrier(0);")
+            if g == 63:
+                out.append("W64_T(5);")
+    out.append(f"#endif  // W64_GEN_{variant}")
+    out.append("")
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    dst = os.path.join(here, "..", "duo-attention_amd", "csrc", "duo_prefill_w64_bulk.inc")
+    out = ["// GENERATED by tools/gen_w64_bulk.py — do not edit; the schedule (which instruction rides in which MFMA gap)",
+           "// is the table in that script.  Included three times by duo_prefill_w64.h, inside the bulk-tile lambdas.",
+           ""]
+    for v in ("STEADY", "FIRST", "DRAIN"):
+        emit_variant(v, out)
+    with open(dst, "w") as f:
+        f.write("\n".join(out))
+    if "-v" in sys.argv:
+        for v in ("STEADY",):
+            for g, ops in enumerate(build_gaps(v)):
+                print(g, sum(op.n for op in ops if not op.text.startswith("v_mfma")))
+
+
+if __name__ == "__main__":
+    main()
