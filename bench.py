@@ -547,7 +547,7 @@ def main():
     if not args.no_kernel_roofline:
         pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
-        roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows; first chunk / split launches: duo_prefill_kernel, 8 x 32)",
+        roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows, every launch of this workload; key-range-split launches of short chunks run duo_prefill_kernel, 8 x 32)",
                 "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK,
                 "traffic": traffic.get("duo_prefill"), "traffic_source": traffic_source,

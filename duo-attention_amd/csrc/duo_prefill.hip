@@ -636,10 +636,9 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return !e || atoi(e) != 0; }();
     if constexpr (!F16) {
         bool w64_ok = want_w64 && tr && P.ksplit == 1 && !(g_debug_flags & 128u);
-        // it pays where cached keys dominate (+8 % on an all-retrieval launch at past 64K) and loses 2-3 % on purely
-        // causal launches (first chunk, streaming heads only — profiles/r2_prefill_w64.md): pick by the retrieval
-        // class's cached length.  Debug bit 8 (no split) doubles as "always", so tests reach every path.
-        if (!(g_debug_flags & 256u) && !(P.cls[0].n_kv_heads > 0 && P.cls[0].a.len >= n_tokens)) w64_ok = false;
+        // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
+        // included: +9 ... +14 %, profiles/r2_prefill_w64.md; debug bit 8 = never split the key range, so tests reach it
+        // on short launches too)
         for (int c = 0; c < 2; ++c)
             if (P.cls[c].n_kv_heads > 0 && P.cls[c].b.len != n_tokens) w64_ok = false;
         if (w64_ok) {
