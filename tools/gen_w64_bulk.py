@@ -153,6 +153,31 @@ def dma_pair(j):
               n=6, clobbers=("memory",))   # M0: reserved, the compiler only ever sets it right before a use
 
 
+def dma_single(j, which):
+    """one K (which = 0) or V (1) piece of the LDS-DMA of tile t+2"""
+    kv = "KV"[which]
+    return Op("s_mov_b32 m0, {l}\n"
+              "s_nop 0\n"
+              "global_load_lds_dwordx4 {ofs}, {b}",
+              [("l", "s", f"W64_DMA_LDS_{kv}({j})", "r"), ("ofs", "v", f"W64_DMA_{kv}OFS({j})", "r"),
+               ("b", "s", "run_v" if which else "run_k", "r")], n=3, clobbers=("memory",))
+
+
+def dma_m0(j, which):
+    return Op("s_mov_b32 m0, {l}", [("l", "s", f"W64_DMA_LDS_{'KV'[which]}({j})", "r")], n=1)
+
+
+def dma_load(j, which):
+    kv = "KV"[which]
+    return Op("global_load_lds_dwordx4 {ofs}, {b}",
+              [("ofs", "v", f"W64_DMA_{kv}OFS({j})", "r"), ("b", "s", "run_v" if which else "run_k", "r")],
+              n=1, clobbers=("memory",))
+
+
+DMA_LAYOUT = os.environ.get("W64_GEN_DMA", "split")     # pairs: gaps 0..3;  split: K pieces gaps 0..3, V pieces gaps 14..17
+LIKELY = os.environ.get("W64_GEN_LIKELY", "0") == "1"   # measured: moving the rescale block out of line made the tile 3.8x slower
+
+
 def raw(text, clobbers=("memory",)):
     return Op(text, [], n=0, clobbers=clobbers)
 
@@ -161,7 +186,12 @@ def raw(text, clobbers=("memory",)):
 # chain timeline r (block A: gap 17 + r, block B: gap 49 + r, wrapping into the next tile's gaps 0..16):
 #   r 0..4   row max (INIT, MAX4, MAX4, MAX4C, FIN)
 #   r 5..14  slices, r 15..18 idle (block A: the V^T read burst; block B: the LDS-DMA pairs), r 19..31 slices
-SLICE_R = list(range(5, 15)) + list(range(19, 32))
+# slice instructions per r (112 per block).  Block A pauses at r 15..18 (= gaps 32..35, the V^T read burst); block B
+# runs lighter in ph4 (its gaps also carry the K(t+1) reads and sit behind the barrier) and in the gaps that carry an
+# LDS-DMA piece
+SIZES_A = {**{r: 5 for r in range(5, 15)}, **{r: 5 for r in range(19, 29)}, 29: 4, 30: 4, 31: 4}
+SIZES_B = ({**{r: 4 for r in range(5, 15)}, **{r: 3 for r in range(15, 19)}, **{r: 5 for r in range(19, 29)},
+            29: 3, 30: 3, 31: 4} if os.environ.get("W64_GEN_BSIZES", "light") == "light" else SIZES_A)
 
 
 def chain_ops(x):
@@ -169,15 +199,12 @@ def chain_ops(x):
     by_r = {0: [max_init(x, 0, 0)], 1: [max4(x, 0, 8)], 2: [max4(x, 1, 0)], 3: [max4(x, 1, 8, combine=True)],
             4: [max_fin(x)]}
     L = slice_list(x)
-    sizes = [5] * len(SLICE_R)
-    extra = sum(sizes) - len(L)
-    for j in range(extra):
-        sizes[-1 - j] -= 1
-    assert sum(sizes) == len(L)
+    sizes = SIZES_B if x else SIZES_A
+    assert sum(sizes.values()) == len(L), (sum(sizes.values()), len(L))
     pos = 0
-    for r, n in zip(SLICE_R, sizes):
-        by_r[r] = L[pos:pos + n]
-        pos += n
+    for r in sorted(sizes):
+        by_r[r] = L[pos:pos + sizes[r]]
+        pos += sizes[r]
     return by_r
 
 
@@ -219,7 +246,18 @@ def build_gaps_full(variant):
                 ops.append(mfma_pv(0, i))
         elif ph == 1:
             ops.append(mfma_pv(1, i))
-        # LDS reads first (they land sooner), then the softmax work, the LDS-DMA pair last
+        # an LDS-DMA piece of tile t+2: M0 is set right behind the MFMA and the load goes last, so the gap's other
+        # instructions are the wait state the M0 write needs (LDS reads do not use M0 on this chip)
+        piece = None
+        if variant != "DRAIN" and DMA_LAYOUT == "split":
+            if g < 4:
+                piece = (g, 0)
+            if 14 <= g <= 17:
+                piece = (g - 14, 1)
+        if piece:
+            ops.append(dma_m0(*piece))
+        nbefore = len(ops)
+        # LDS reads first (they land sooner), then the softmax work
         if variant != "DRAIN":
             if 22 <= g <= 31:          # V^T(t) fragments 0..4: their registers were last read by ph2 MFMA 16+f
                 j = g - 22
@@ -237,7 +275,11 @@ def build_gaps_full(variant):
                 ops += B.get(g - 49, [])
         if variant in ("STEADY", "DRAIN") and g + 15 in B and g <= 16:
             ops += B[g + 15]           # block B of the previous tile
-        if variant != "DRAIN" and g < 4:
+        if piece:
+            if len(ops) == nbefore:
+                ops.append(raw("s_nop 0", clobbers=()))
+            ops.append(dma_load(*piece))
+        if variant != "DRAIN" and DMA_LAYOUT == "pairs" and g < 4:
             ops.append(dma_pair(g))
         gaps.append(ops)
     return gaps
@@ -323,10 +365,10 @@ def emit_variant(variant, out):
         emit_stmt(ops, out, prefix)
         if variant != "DRAIN":
             if g == 21:
-                out.append("if (mkA != 0) rescale(std::integral_constant<int, 0>{}, h0A);")
+                out.append(("if (__builtin_expect(mkA != 0, 0))" if LIKELY else "if (mkA != 0)") + " rescale(std::integral_constant<int, 0>{}, h0A);")
                 out.append("__builtin_amdgcn_sched_barrier(0);")
             if g == 53:
-                out.append("if (mkB != 0) rescale(std::integral_constant<int, 1>{}, h0B);")
+                out.append(("if (__builtin_expect(mkB != 0, 0))" if LIKELY else "if (mkB != 0)") + " rescale(std::integral_constant<int, 1>{}, h0B);")
                 out.append("__builtin_amdgcn_sched_barrier(0);")
             if g == 63:
                 out.append("W64_T(5);")
