@@ -2,18 +2,20 @@
 """Generates duo-attention_amd/csrc/duo_prefill_w64_bulk.inc: the instruction schedule of ONE bulk tile of the
 4-wave x 64-row prefill kernel (duo_prefill_w64.h), as a sequence of asm statements — one per MFMA "gap".
 
-Why a generator: with one wave per SIMD every instruction next to the 64 MFMAs of a tile is a serial issue slot,
-and a gap hides about five of them (MI355X_MICROARCH, 'one wave per SIMD').  A tile carries ~340 such
-instructions (2 x 16 exponentiation slices of 7, 2 row maxima of 21, 48 LDS fragment reads, 4 LDS-DMA pairs),
-i.e. 5.3 per gap ONLY IF they are spread evenly over all 64 gaps.  Block B's softmax therefore lags block A's by
-half a tile (the skewed order below), and the placement is a table in this file instead of hand-expanded macros.
+Why a generator: with one wave per SIMD every instruction next to the 64 MFMAs of a tile is a serial issue slot that
+delays the next MFMA by 2.5-5 cycles (an LDS-DMA load by ~38, two loads in one gap by much more), see
+profiles/r2_prefill_w64.md.  A tile carries 330 such instructions (2 x 112 exponentiation-slice instructions, 2 x 21
+row-max instructions, 48 LDS fragment reads, 8 LDS-DMA loads + 8 M0 writes): 5.2 per gap ONLY IF they are spread
+evenly over all 64 gaps.  Block B's softmax therefore lags block A's by half a tile (the skewed order below), and the
+placement is a table in this file instead of hand-expanded macros; the W64_GEN_* environment switches rebuild the
+alternatives that were measured against it (tools/debug/build_variant.sh + w64_timing_variants.sh).
 
 Tile t, 64 gaps (gap g = the instructions issued behind MFMA g):
-    ph1  g  0..15   S_A(t)  = K(t) . Q_A^T        | block B(t-1) slices (second half), LDS-DMA of tile t+2
-    ph2  g 16..31   O_B    += V^T(t-1) . P_B(t-1) | row max A(t), block A(t) slices, first V^T(t) reads
-    ph3  g 32..47   S_B(t)  = K(t) . Q_B^T        | V^T(t) read burst, block A(t) slices
+    ph1  g  0..15   S_A(t)  = K(t) . Q_A^T        | block B(t-1) slices (rest), LDS-DMA of tile t+2: K pieces g 0..3, V pieces g 14..17
+    ph2  g 16..31   O_B    += V^T(t-1) . P_B(t-1) | row max A(t) g 17..21, block A(t) slices, V^T(t) reads (one per gap g 22..31)
+    ph3  g 32..47   S_B(t)  = K(t) . Q_B^T        | V^T(t) read burst (five per gap g 32..35; spreading them measured 0.6 % slower), block A(t) slices
          -- lgkmcnt(0), vmcnt(8), ONE s_barrier --
-    ph4  g 48..63   O_A    += V^T(t) . P_A(t)     | K(t+1) fragment reads, row max B(t), block B(t) slices (first half)
+    ph4  g 48..63   O_A    += V^T(t) . P_A(t)     | K(t+1) fragment reads (one per gap), row max B(t) g 49..53, block B(t) slices
 
 Variants: STEADY (above), FIRST (first tile of a bulk run: no block B(t-1) work, no ph2 MFMAs) and DRAIN (after
 the last tile of a run: the pending block-B slices and the 16 ph2 MFMAs only).
@@ -189,7 +191,12 @@ def raw(text, clobbers=("memory",)):
 # slice instructions per r (112 per block).  Block A pauses at r 15..18 (= gaps 32..35, the V^T read burst); block B
 # runs lighter in ph4 (its gaps also carry the K(t+1) reads and sit behind the barrier) and in the gaps that carry an
 # LDS-DMA piece
-SIZES_A = {**{r: 5 for r in range(5, 15)}, **{r: 5 for r in range(19, 29)}, 29: 4, 30: 4, 31: 4}
+VLAYOUT = os.environ.get("W64_GEN_VLAYOUT", "burst")   # burst: gaps 32..35 carry five V^T reads each; spread: 1-2 per gap
+if VLAYOUT == "burst":
+    SIZES_A = {**{r: 5 for r in range(5, 15)}, **{r: 5 for r in range(19, 29)}, 29: 4, 30: 4, 31: 4}
+else:
+    SIZES_A = {**{r: 4 for r in range(5, 15)}, **{r: 3 for r in range(15, 23)}, **{r: 5 for r in range(23, 29)},
+               29: 6, 30: 6, 31: 6}
 SIZES_B = ({**{r: 4 for r in range(5, 15)}, **{r: 3 for r in range(15, 19)}, **{r: 5 for r in range(19, 29)},
             29: 3, 30: 3, 31: 4} if os.environ.get("W64_GEN_BSIZES", "light") == "light" else SIZES_A)
 
@@ -259,15 +266,23 @@ def build_gaps_full(variant):
         nbefore = len(ops)
         # LDS reads first (they land sooner), then the softmax work
         if variant != "DRAIN":
-            if 22 <= g <= 31:          # V^T(t) fragments 0..4: their registers were last read by ph2 MFMA 16+f
-                j = g - 22
-                ops.append(vread(j >> 1, j & 1))
-            if 32 <= g <= 35:          # fragments 6..15: five reads per gap (block A's chain idles here)
-                for j in range(5):
-                    q = 12 + (g - 32) * 5 + j
-                    ops.append(vread(q >> 1, q & 1))
-            if g in (36, 37):          # fragment 5
-                ops.append(vread(5, g - 36))
+            if VLAYOUT == "burst":
+                if 22 <= g <= 31:          # V^T(t) fragments 0..4: their registers were last read by ph2 MFMA 16+f
+                    j = g - 22
+                    ops.append(vread(j >> 1, j & 1))
+                if 32 <= g <= 35:          # fragments 6..15: five reads per gap (block A's chain idles here)
+                    for j in range(5):
+                        q = 12 + (g - 32) * 5 + j
+                        ops.append(vread(q >> 1, q & 1))
+                if g in (36, 37):          # fragment 5
+                    ops.append(vread(5, g - 36))
+            else:
+                # read k (fragment k>>1, half k&1): one per gap from gap 18 (fragment f's registers are free after ph2
+                # MFMA 16+f), two per gap in gaps 32..39; the last one goes out in gap 41, six gaps before the wait
+                order = list(range(18, 32)) + [g2 for g2 in range(32, 40) for _ in (0, 1)] + [40, 41]
+                for k, g2 in enumerate(order):
+                    if g2 == g:
+                        ops.append(vread(k >> 1, k & 1))
             if ph == 3:                # K(t+1) fragment i (a[192:255] was last read by ph3)
                 ops.append(kread(i))
             ops += A.get(g - 17, [])
