@@ -1,7 +1,7 @@
 """Layer pipeline (duo_attn/pipeline.py) on CPU: world_size 2 and 3, gloo backend.
 
 Covers the N>1 path of bench.py by construction: the even layer split, the item streaming with
-posted-ahead receives / asynchronous sends, and the sharded hot path (each rank owns the dual KV
+paired batch_isend_irecv hand-offs / asynchronous sends, and the sharded hot path (each rank owns the dual KV
 pools of its layers) against a single-process run.  The oracle is the device backend here.
 """
 import os
