@@ -465,6 +465,51 @@ def test_rescale_inside_cached_segment_both_row_blocks(prefill_kernel):
     attn_close(out, ref[0], "rescale in cached tiles", bud[0])
 
 
+@pytest.mark.parametrize("lenA", [0, 640, 1100])
+def test_rescale_at_every_position_of_a_bulk_run(lenA, prefill_kernel):
+    """The 4-wave kernel's bulk tiles run a skewed schedule (block B of tile t-1 finishes inside tile t; first tile
+    of a run, steady tiles, drain — duo_prefill_w64_bulk.inc), for runs in the cached segment AND among the chunk's own
+    fully visible tiles.  One moderate spike per chosen query row — strong enough to pass the deferred-rescale
+    threshold (score ~9.5 against a running max of ~2.5 + 5.5), weak enough that the other keys keep ~15 % of the row's
+    weight — with the spike keys walking over every tile the row sees in full: first / middle / last tile of each run,
+    the general tiles between runs, rows of both 32-row blocks of every wave."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(100 + lenA)
+    S, group = 1024, 2
+    q = _rand((S, group, D), g)
+    kp, vp = _rand((lenA, 1, D), g), _rand((lenA, 1, D), g)
+    kn, vn = _rand((S, 1, D), g), _rand((S, 1, D), g)
+    nA = (lenA + 63) // 64
+    used = set()
+    n_spikes = 0
+    for i, row in enumerate(range(256, S, 3)):          # q tiles 1..3, every third row: both blocks of all four waves
+        head = i % group
+        tiles_seen = nA + row // 64                       # tiles this row sees in full (cached + chunk-own)
+        tile = (i * 5) % tiles_seen
+        key = tile * 64 + (row * 7) % 64
+        if key in used or (tile == nA - 1 and lenA % 64 and key >= lenA):
+            continue
+        used.add(key)
+        gain = 0.85 if i % 2 else 1.2
+        vec = (q[row, head].float() * gain).to(torch.bfloat16)
+        if key < lenA:
+            kp[key, 0] = vec
+        else:
+            kk_ = key - nA * 64 if lenA % 64 == 0 else None
+            if kk_ is None or kk_ < 0 or kk_ > row:
+                continue
+            kn[kk_, 0] = vec
+        n_spikes += 1
+    assert n_spikes > 100
+    out = torch.empty(S, group, D, dtype=torch.bfloat16, device=DEV)
+    segA = (kp.to(DEV), vp.to(DEV)) if lenA else None
+    HipBackend().attention(q.to(DEV), out, group, (1, 0, segA, (kn.to(DEV), vn.to(DEV))), None, D ** -0.5)
+    kk, vv = torch.cat([kp, kn], 0), torch.cat([vp, vn], 0)
+    ref, bud = flash_attn_func_ref(q[None], kk[None], vv[None], round_p=False, out_dtype=torch.float32, return_budget=True)
+    attn_close(out, ref[0], f"rescale along bulk runs lenA={lenA}", bud[0])
+
+
 # ----------------------------------------------------------------------------- whole hot path
 @pytest.mark.parametrize(
     "counts,Hq,Hkv,chunks,sink,recent",
