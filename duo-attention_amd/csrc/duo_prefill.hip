@@ -550,6 +550,7 @@ static int prefill_choose_ksplit(int long_wgs, int min_tiles, int64_t workspace_
     const int kmax = (int)std::min<int64_t>(8, std::min<int64_t>(min_tiles, workspace_bytes / (kPrefillPartialBytes * long_wgs)));
     if (g_debug_flags & 256u) return 1;      // debug bit 8: no key-range split
     if (forced > 0) return std::max(1, std::min(forced, kmax));
+    if ((g_debug_flags >> 12) & 15u) return std::max(1, std::min((int)((g_debug_flags >> 12) & 15u), kmax));   // bits 12-15: tests force a count
     int best = 1;
     double best_cost = 1e30;
     for (int k = 1; k <= kmax; ++k) {
@@ -630,17 +631,15 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         if (e != hipSuccess) return (int)e;
         if (dev < 64) attr_done[dev][tr].store(true, std::memory_order_release);
     }
-    // 4-wave x 64-row kernel (duo_prefill_w64.h): the default whenever it applies — bf16, no key-range split,
-    // segment B == the query rows; everything else runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
+    // 4-wave x 64-row kernel (duo_prefill_w64.h): the default whenever it applies — bf16 with the
+    // transposed-V LDS layout; everything else (fp16, the gather debug path) runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
     // flag bit 7) keeps the 8-wave kernel everywhere (same-box A/B, tests of both kernels).
     static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return !e || atoi(e) != 0; }();
     if constexpr (!F16) {
-        bool w64_ok = want_w64 && tr && P.ksplit == 1 && !(g_debug_flags & 128u);
+        bool w64_ok = want_w64 && tr && !(g_debug_flags & 128u);
         // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
         // included: +9 ... +14 %, profiles/r2_prefill_w64.md; debug bit 8 = never split the key range, so tests reach it
         // on short launches too)
-        for (int c = 0; c < 2; ++c)
-            if (P.cls[c].n_kv_heads > 0 && P.cls[c].b.len != n_tokens) w64_ok = false;
         if (w64_ok) {
             static std::atomic<bool> w64_attr[64];
             if (dev >= 64 || !w64_attr[dev].load(std::memory_order_acquire)) {
@@ -651,6 +650,10 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
             }
             hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
             DUO_HIP_CHECK_LAUNCH();
+            if (P.ksplit > 1) {
+                hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs), dim3(256), 0, st, P);
+                DUO_HIP_CHECK_LAUNCH();
+            }
             return 0;
         }
     }

@@ -359,8 +359,9 @@ def test_prefill_first_chunk(S, group, nkv, prefill_kernel):
     attn_close(out, ref, f"first chunk S={S}", bud)
 
 
-@pytest.mark.parametrize("S,lenA,lenB,group", [(300, 100, 500, 4), (256, 0, 1024, 4), (77, 384, 78, 1), (512, 1000, 513, 2)])
-def test_prefill_query_block_shorter_than_segment_b(S, lenA, lenB, group):
+@pytest.mark.parametrize("S,lenA,lenB,group", [(300, 100, 500, 4), (256, 0, 1024, 4), (77, 384, 78, 1), (512, 1000, 513, 2),
+                                               (512, 1000, 2048, 2), (640, 0, 1700, 1)])
+def test_prefill_query_block_shorter_than_segment_b(S, lenA, lenB, group, prefill_kernel):
     """segment B longer than the query block: the S queries are its last S rows (bottom-right alignment,
     flash_attn_func with seqlen_q < seqlen_k) — a chunk processed in row blocks."""
     from duo_attn.backend import HipBackend
@@ -377,7 +378,7 @@ def test_prefill_query_block_shorter_than_segment_b(S, lenA, lenB, group):
     attn_close(out, ref[0], f"row block S={S} lenB={lenB}", bud[0])
 
 
-def test_prefill_key_range_splits_agree_with_single_pass():
+def test_prefill_key_range_splits_agree_with_single_pass(prefill_kernel):
     """duo_attn_prefill_ws_bf16 (workspace: the retrieval class may be split over key ranges, partials merged
     by a second launch) against duo_attn_prefill_bf16 (one workgroup walks all of a q tile's keys): same
     attention, fp32 summation order aside.  Shape chosen so that the launcher does split (8 long workgroups)."""
@@ -409,6 +410,34 @@ def test_prefill_key_range_splits_agree_with_single_pass():
     attn_close(out_single, ref[0], "single", bud[0])
     rms = b.pow(2).mean().sqrt()
     assert (a - b).pow(2).mean().sqrt() <= 5e-3 * rms
+
+
+@pytest.mark.parametrize("eight_wave", [False, True], ids=["w4x64", "w8x32"])
+@pytest.mark.parametrize("ksplit", [2, 3, 5, 8])
+@pytest.mark.parametrize("S,lenA", [(700, 3000), (256, 0), (1024, 200)])
+def test_prefill_forced_key_range_splits(S, lenA, ksplit, eight_wave):
+    """Every workgroup of the retrieval class walks 1/k of its tile sequence (debug bits 12-15 force k): ranges that
+    start inside the cached segment, on its partial last tile, inside the chunk's own tiles (rows that see no key of
+    their range leave m = -inf, l = 0), bulk runs that begin at a split boundary — merged partials against the oracle."""
+    h = _hip()
+    g = torch.Generator().manual_seed(S + lenA + ksplit)
+    group = 2
+    q = _rand((S, group, D), g)
+    ka, va = _rand((lenA, 1, D), g), _rand((lenA, 1, D), g)
+    kb, vb = _rand((S, 1, D), g), _rand((S, 1, D), g)
+    out = torch.full((S, group, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qd, kad, vad, kbd, vbd = (t.to(DEV) for t in (q, ka, va, kb, vb))     # the segments hold raw pointers: keep these alive
+    cls = h.make_class(1, 0, h.make_seg(kad, vad), h.make_seg(kbd, vbd))
+    h.set_debug_flags((ksplit << 12) | (128 if eight_wave else 0))
+    try:
+        h.attn_prefill(qd, out, group, cls, None, D ** -0.5)
+        torch.cuda.synchronize()
+    finally:
+        h.set_debug_flags(0)
+    ref, bud = flash_attn_func_ref(q[None], torch.cat([ka, kb])[None], torch.cat([va, vb])[None], round_p=False,
+                                   out_dtype=torch.float32, return_budget=True)
+    # each range rounds P relative to ITS running maximum: the P-rounding budget is drawn once per range that matters
+    attn_close(out, ref[0], f"forced {ksplit} splits S={S} lenA={lenA}", bud[0])
 
 
 def test_prefill_without_transpose_read_matches():
