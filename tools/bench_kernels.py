@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=131072)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--uniform-nf", type=int, default=-1, help="decode: every layer has this many retrieval kv heads")
     a = ap.parse_args()
     from duo_attn import _hip
     from duo_attn.backend import get_backend
@@ -108,7 +109,7 @@ def main():
     else:
         import bench
 
-        counts = bench.LLAMA3_8B_FULL_KV_HEADS
+        counts = bench.LLAMA3_8B_FULL_KV_HEADS if a.uniform_nf < 0 else [a.uniform_nf] * 8
         N = a.ctx
         q = torch.randn(1, HQ, D, generator=g, device=dev).to(torch.bfloat16)
         kn, vn = pools(HKV, 1, dev, g)
@@ -129,7 +130,7 @@ def main():
 
         avg, mn, med = time_it(step, a.reps)
         nbytes = sum(bench.decode_bytes(counts, N))
-        print(json.dumps({"case": f"decode split kernel x32 layers ctx={N}", "avg_ms": avg, "min_ms": mn,
+        print(json.dumps({"case": f"decode split kernel x{len(counts)} layers ctx={N}" + (f" nf={a.uniform_nf}" if a.uniform_nf >= 0 else ""), "avg_ms": avg, "min_ms": mn,
                           "GBps_avg": nbytes / avg / 1e6, "GBps_best": nbytes / mn / 1e6,
                           "frac_of_8TBps": nbytes / avg / 1e6 / 8000}))
         _hip.set_debug_flags(0)
