@@ -631,24 +631,26 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         if (e != hipSuccess) return (int)e;
         if (dev < 64) attr_done[dev][tr].store(true, std::memory_order_release);
     }
-    // 4-wave x 64-row kernel (duo_prefill_w64.h): the default whenever it applies — bf16 with the
-    // transposed-V LDS layout; everything else (fp16, the gather debug path) runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
+    // 4-wave x 64-row kernel (duo_prefill_w64.h): the default for bf16 and fp16 with the
+    // transposed-V LDS layout; the gather debug path runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
     // flag bit 7) keeps the 8-wave kernel everywhere (same-box A/B, tests of both kernels).
     static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return !e || atoi(e) != 0; }();
-    if constexpr (!F16) {
+    {
         bool w64_ok = want_w64 && tr && !(g_debug_flags & 128u);
         // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
         // included: +9 ... +14 %, profiles/r2_prefill_w64.md; debug bit 8 = never split the key range, so tests reach it
         // on short launches too)
         if (w64_ok) {
-            static std::atomic<bool> w64_attr[64];
-            if (dev >= 64 || !w64_attr[dev].load(std::memory_order_acquire)) {
-                hipError_t e = hipFuncSetAttribute((const void *)duo_prefill_w64_kernel,
+            static std::atomic<bool> w64_attr[64][2];
+            const void *wfn = F16 ? (const void *)duo_prefill_w64_f16_kernel : (const void *)duo_prefill_w64_kernel;
+            if (dev >= 64 || !w64_attr[dev][F16].load(std::memory_order_acquire)) {
+                hipError_t e = hipFuncSetAttribute(wfn,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
                 if (e != hipSuccess) return (int)e;
-                if (dev < 64) w64_attr[dev].store(true, std::memory_order_release);
+                if (dev < 64) w64_attr[dev][F16].store(true, std::memory_order_release);
             }
-            hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
+            if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
+            else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
             DUO_HIP_CHECK_LAUNCH();
             if (P.ksplit > 1) {
                 hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs), dim3(256), 0, st, P);

@@ -240,8 +240,10 @@ def test_int4_cache_put_compress_decode_flow():
 
 @gpu
 @pytest.mark.parametrize("S,group,nf,ns,la,ls", [(2, 4, 1, 1, 3, 2), (100, 4, 1, 3, 1000, 384), (257, 4, 2, 0, 300, 0),
-                                                  (300, 4, 0, 2, 0, 384), (513, 1, 2, 2, 77, 10), (700, 8, 1, 0, 129, 0)])
-def test_fp16_prefill_kernel(S, group, nf, ns, la, ls):
+                                                  (300, 4, 0, 2, 0, 384), (513, 1, 2, 2, 77, 10), (700, 8, 1, 0, 129, 0),
+                                                  (1024, 2, 1, 1, 1100, 384)])
+@pytest.mark.parametrize("flags", [0, 128], ids=["w4x64", "w8x32"])
+def test_fp16_prefill_kernel(S, group, nf, ns, la, ls, flags):
     """duo_attn_prefill_f16 (the MFMA prefill kernel instantiated for fp16) against the oracle, both head
     classes, pool + chunk as two segments."""
     from duo_attn.backend import HipBackend
@@ -267,8 +269,14 @@ def test_fp16_prefill_kernel(S, group, nf, ns, la, ls):
         stream = (ns, nf * group, (sk.to(DEV), sv.to(DEV)) if ls else None, (knd[:, nf:], vnd[:, nf:]))
         o, b = flash_attn_func_ref(q[None, :, nf * group:], torch.cat([sk, kn[:, nf:]])[None], torch.cat([sv, vn[:, nf:]])[None], **kw)
         ref[:, nf * group:], bud[:, nf * group:] = o[0], b[0]
-    HipBackend().attention(q.to(DEV), out, group, full, stream, 128 ** -0.5)
-    attn_close(out, ref, f"fp16 prefill S={S}", bud)
+    from duo_attn import _hip
+    _hip.set_debug_flags(flags)       # bit 7: the 8-wave kernel; default: the fp16 twin of the 4-wave x 64-row kernel
+    try:
+        HipBackend().attention(q.to(DEV), out, group, full, stream, 128 ** -0.5)
+        torch.cuda.synchronize()
+    finally:
+        _hip.set_debug_flags(0)
+    attn_close(out, ref, f"fp16 prefill S={S} flags={flags}", bud)
 
 
 @gpu

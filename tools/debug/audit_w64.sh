@@ -8,15 +8,18 @@ cd $d
 python3 - <<'PY'
 import re, collections, sys
 s = open('duo_prefill-hip-amdgcn-amd-amdhsa-gfx950.s').read()
-a = s.index('duo_prefill_w64_kernelENS_13PrefillParamsE:')
-k = s[a:]; k = k[:k.index('.Lfunc_end')]
-tail = s[a:]; tail = tail[tail.index('.Lfunc_end'):][:3000]
-stats = dict(re.findall(r'; (NumVgprs|NumAgprs|ScratchSize): (\d+)', tail))
-inasm, bad = False, []
-for l in k.splitlines():
-    if 'ASMSTART' in l: inasm = True; continue
-    if 'ASMEND' in l: inasm = False; continue
-    if not inasm and ('accvgpr' in l or re.search(r'\ba\[?\d+', l.split(';')[0])): bad.append(l.strip())
-print(stats, 'compiler instructions touching AGPRs:', len(bad))
-sys.exit(1 if bad or stats.get('ScratchSize') != '0' else 0)
+rc = 0
+for name in ('duo_prefill_w64_kernelENS_13PrefillParamsE:', 'duo_prefill_w64_f16_kernelENS_13PrefillParamsE:'):
+    a = s.index(name)
+    k = s[a:]; k = k[:k.index('.Lfunc_end')]
+    tail = s[a:]; tail = tail[tail.index('.Lfunc_end'):][:3000]
+    stats = dict(re.findall(r'; (NumVgprs|NumAgprs|ScratchSize): (\d+)', tail))
+    inasm, bad = False, []
+    for l in k.splitlines():
+        if 'ASMSTART' in l: inasm = True; continue
+        if 'ASMEND' in l: inasm = False; continue
+        if not inasm and ('accvgpr' in l or re.search(r'\ba\[?\d+', l.split(';')[0])): bad.append(l.strip())
+    print(name.split('ENS')[0], stats, 'compiler instructions touching AGPRs:', len(bad))
+    if bad or stats.get('ScratchSize') != '0': rc = 1
+sys.exit(rc)
 PY

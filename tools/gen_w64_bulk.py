@@ -43,13 +43,13 @@ def mfma_qk(x, i):
     k0 = 192 + 4 * i
     q0 = 128 + 32 * x + 4 * (i >> 1)
     tail = "0" if i < 2 else "{acc}"
-    return Op(f"v_mfma_f32_32x32x16_bf16 {{acc}}, a[{k0}:{k0 + 3}], a[{q0}:{q0 + 3}], {tail}",
+    return Op(f"@MFMA@ {{acc}}, a[{k0}:{k0 + 3}], a[{q0}:{q0 + 3}], {tail}",
               [("acc", "v", acc, "w" if i < 2 else "rw")])
 
 
 def mfma_pv(x, i):
     o0 = 64 * x + 16 * (i & 3)
-    return Op(f"v_mfma_f32_32x32x16_bf16 a[{o0}:{o0 + 15}], {{vf}}, {{pf}}, a[{o0}:{o0 + 15}]",
+    return Op(f"@MFMA@ a[{o0}:{o0 + 15}], {{vf}}, {{pf}}, a[{o0}:{o0 + 15}]",
               [("vf", "v", f"W64_VF({i})", "r"), ("pf", "v", f"W64_PF{AB[x]}({i >> 2})", "r")])
 
 
@@ -76,7 +76,7 @@ def add(x, k, h):
 
 
 def cvt(x, k):
-    return Op("v_cvt_pk_bf16_f32 {pk}, {e0}, {e1}",
+    return Op("@CVT@ {pk}, {e0}, {e1}",
               [("pk", "v", f"pk{AB[x]}[{k}]", "w"), ("e0", "v", E(x, k, 0), "r"), ("e1", "v", E(x, k, 1), "r")])
 
 
@@ -227,7 +227,7 @@ def build_gaps(variant):
         if "kread" in DROP and t.startswith("ds_read_b128"): return False
         if "vread" in DROP and t.startswith("ds_read_b64_tr"): return False
         if "dma" in DROP and "global_load_lds" in t: return False
-        if "slice" in DROP and t.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "v_cvt_pk_bf16_f32"): return False
+        if "slice" in DROP and t.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "@CVT@"): return False
         if "max" in DROP and t.startswith("v_max3") : return False
         return True
     return [[op for op in g if keep(op)] for g in gaps]
@@ -343,6 +343,7 @@ def emit_stmt(ops, out, prefix=None):
     assert len(outs) + len(ins) <= 30, (len(outs), len(ins))
     out.append("asm volatile(")
     for k, ln in enumerate(lines):
+        ln = ln.replace("@MFMA@", '" W64_MFMA "').replace("@CVT@", '" W64_CVT "')     # element-type mnemonics: macros of the including kernel
         out.append(f'    "{ln}' + ('\\n\\t"' if k + 1 < len(lines) else '"'))
     out.append("    : " + ", ".join(outs))
     out.append("    : " + ", ".join(ins))
@@ -353,7 +354,7 @@ def emit_stmt(ops, out, prefix=None):
 
 def emit_variant(variant, out):
     gaps = build_gaps(variant)
-    count = sum(op.n for g in gaps for op in g if not op.text.startswith("v_mfma"))
+    count = sum(op.n for g in gaps for op in g if not op.text.startswith("@MFMA@"))
     out.append(f"#ifdef W64_GEN_{variant}   /* {count} instructions beside the MFMAs */")
     for g, ops in enumerate(gaps):
         if variant == "DRAIN" and g >= 32:
@@ -375,7 +376,7 @@ def emit_variant(variant, out):
                 # the barrier publishes tile t+1 and retires every wave's reads of tile t
                 emit_stmt([raw("s_waitcnt lgkmcnt(0)\ns_waitcnt vmcnt(8)\ns_barrier")], out)
                 out.append("W64_T(4);")
-        nfill = sum(op.n for op in ops if not op.text.startswith("v_mfma"))
+        nfill = sum(op.n for op in ops if not op.text.startswith("@MFMA@"))
         out.append(f"// gap {g}: {nfill}")
         emit_stmt(ops, out, prefix)
         if variant != "DRAIN":
@@ -404,7 +405,7 @@ def main():
     if "-v" in sys.argv:
         for v in ("STEADY",):
             for g, ops in enumerate(build_gaps(v)):
-                print(g, sum(op.n for op in ops if not op.text.startswith("v_mfma")))
+                print(g, sum(op.n for op in ops if not op.text.startswith("@MFMA@")))
 
 
 if __name__ == "__main__":
