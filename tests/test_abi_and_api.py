@@ -177,3 +177,17 @@ def test_to_device_contract():
         to_device(m, [0, 1])
     with pytest.raises(NotImplementedError, match="shard_model_for_tp"):
         to_device(m, [0, 1], enable_tp=True)
+
+
+def test_generated_prefill_schedule_is_in_sync(tmp_path):
+    """duo_prefill_w64_bulk.inc is generated (tools/gen_w64_bulk.py): the committed file must be what the committed
+    generator writes with its default switches."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "bulk.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("W64_GEN_")}
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_w64_bulk.py"), "-o", str(out)], check=True, env=env)
+    committed = open(os.path.join(root, "duo-attention_amd", "csrc", "duo_prefill_w64_bulk.inc")).read()
+    assert out.read_text() == committed

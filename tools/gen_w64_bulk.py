@@ -395,6 +395,8 @@ def emit_variant(variant, out):
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     dst = os.path.join(here, "..", "duo-attention_amd", "csrc", "duo_prefill_w64_bulk.inc")
+    if "-o" in sys.argv:
+        dst = sys.argv[sys.argv.index("-o") + 1]
     out = ["// GENERATED by tools/gen_w64_bulk.py — do not edit; the schedule (which instruction rides in which MFMA gap)",
            "// is the table in that script.  Included three times by duo_prefill_w64.h, inside the bulk-tile lambdas.",
            ""]
