@@ -595,6 +595,16 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     // (grid.y == 1 is guaranteed by the launcher, so the workgroups of a kv head are exactly its `splits`)
     if constexpr (FUSED) {
         if (!P.one_launch) return;
+        if (P.one_launch == 2) {
+            // two launches, but a streaming head scanned by ONE workgroup updates its pool right here (every read of
+            // that head's pool by this launch is this workgroup's own scan, behind the barrier above): the epilogue
+            // launch is then the merge alone
+            if (splits == 1 && ci == 1 && CP.n_heads > 0) {
+                duo_stream_compress_block(CP, 2 * kvh);
+                duo_stream_compress_block(CP, 2 * kvh + 1);
+            }
+            return;
+        }
         bool do_compress = false;
         if (splits == 1) {
             // this workgroup saw every cached row of the head; its waves left the scan through the barrier above
@@ -892,10 +902,17 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
         D.P.tickets = (int32_t *)tickets;
         return decode_launch_split<true>(D, C, st);
     }
-    rc = decode_launch_split<true>(D, CompressParams{}, st);
+    // two launches: fold the streaming-pool update into the scan when every streaming head is one workgroup (grid.y == 1)
+    static const bool fold_ok = [] { const char *e = getenv("DUO_DECODE_FOLD_COMPRESS"); return !e || atoi(e) != 0; }();
+    const bool fold = fold_ok && ns > 0 && group == D.gt && D.P.splits[1] == 1 && !(duo_get_debug_flags() & 2u);
+    if (fold) {
+        D.P.one_launch = 2;
+        n_compress = 0;
+    }
+    rc = decode_launch_split<true>(D, fold ? C : CompressParams{}, st);
     if (rc) return rc;
 
-    // ---- launch 2: merge + streaming-pool update -------------------------------------------------
+    // ---- launch 2: merge (+ streaming-pool update when it was not folded) ----------------------------
     if (D.n_merge + n_compress > 0) {
         hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge + n_compress), dim3(256), 0, st, D.M, 4 * D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
