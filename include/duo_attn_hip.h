@@ -218,7 +218,7 @@ int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t
                          int32_t d_pos, int32_t str_cap, void *stream);
 
 /* ---- the same step in ONE launch ------------------------------------------------------------------
- * duo_decode_layer_bf16 / _dev_bf16 issue two launches (scan, then merge + streaming update).  Here both
+ * duo_decode_layer_bf16 / _dev_bf16 issue two launches (scan — which also updates the pool of every streaming head it scans with one workgroup — then the merge).  Here both
  * are folded into the scan kernel: every workgroup publishes its split-KV partial (agent-scope release) and
  * takes a ticket of its kv head; the last min(splits, 4 * group) arrivals of a head wait until all of its
  * partials are published (bounded spin, agent-scope acquire) and merge one (q head, 32-dim quarter) each;
