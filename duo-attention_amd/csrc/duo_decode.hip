@@ -297,8 +297,20 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
 
 // grid.x = (kv head, split) pairs of the full class then of the streaming class
 // grid.y = group / GT
+#ifdef DUO_DECODE_TIMING   /* measurement builds only (tools/debug/decode_timing.py): s_memtime of wave 0 per workgroup */
+__device__ unsigned long long duo_decode_timing[2048][8];
+#define DUO_DT(k)                                                                                  \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048)                              \
+            duo_decode_timing[blockIdx.x][k] = __builtin_amdgcn_s_memtime();                       \
+    } while (0)
+#else
+#define DUO_DT(k) do { } while (0)
+#endif
+
 template <int GT, bool NT, bool PREFETCH, bool FUSED>
 __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P, const CompressParams CP) {
+    DUO_DT(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar loop control
     const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
@@ -344,6 +356,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     src.tsa = C.a.token_stride;
     src.tsb = C.b.token_stride;
     src.lenA = C.a.len;
+    DUO_DT(4);
 
     // RoPE factors of this lane's 8 dims (FUSED): dims 8*sub+e pair with dims (8*sub+e) ^ 64, i.e.
     // with the slice of lane sub ^ 8; both slices of a pair use frequency index (8*sub+e) & 63
@@ -352,6 +365,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
 #pragma unroll
         for (int e = 0; e < 8; ++e) sincos_rev(pos * P.inv_freq[((sub & 7) << 3) + e], sn[e], cs[e]);
     }
+    DUO_DT(5);
     // x: own slice, y: partner slice -> rotated own slice (first half: x*c - y*s, second half: x*c + y*s)
     auto rope8 = [&](const u32x4 &own, const u32x4 &partner, float (&o)[8]) {
         float x[8], y[8];
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     }
 
     float m[GT], l[GT], acc[GT][8];
+    DUO_DT(1);
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
         m[g] = kNegSentinel;
@@ -451,6 +466,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
         }
     }
 
+    DUO_DT(2);
     if constexpr (FUSED) {
         // ---- the new token: last split of the kv head, wave 0, token group 0 (one 16-lane DPP row) ----
         if (split == splits - 1 && wave == 0 && tg == 0) {
@@ -591,6 +607,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
     }
 
+    DUO_DT(3);
     // ---- single-launch step: the merge of the partials and the streaming-pool update happen here ---------
     // (grid.y == 1 is guaranteed by the launcher, so the workgroups of a kv head are exactly its `splits`)
     if constexpr (FUSED) {
@@ -976,3 +993,9 @@ extern "C" int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_laye
     DUO_HIP_CHECK_LAUNCH();
     return 0;
 }
+
+#ifdef DUO_DECODE_TIMING
+extern "C" int duo_debug_decode_timing(unsigned long long *host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(duo_decode_timing), sizeof(unsigned long long) * 2048 * 8);
+}
+#endif

@@ -1,12 +1,17 @@
 #!/bin/bash
-# Builds a measurement variant of the HIP library: tools/debug/build_variant.sh <tag> [-DSWITCH ...]
-#   -> duo-attention_amd/lib/ab/lib_<tag>.so   (only duo_prefill.hip is rebuilt with the switches; other objects reused)
+# Builds a measurement variant of the HIP library: [SRC=duo_decode] tools/debug/build_variant.sh <tag> [-DSWITCH ...]
+#   -> duo-attention_amd/lib/ab/lib_<tag>.so   (only $SRC.hip — default duo_prefill — is rebuilt with the switches)
 set -e
 tag=$1; shift
+SRC=${SRC:-duo_prefill}
 root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/duo-attention_amd/csrc
 make -s -C $src
 mkdir -p $root/duo-attention_amd/lib/ab /tmp/ab_$tag
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $src/duo_prefill.hip -o /tmp/ab_$tag/duo_prefill.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/duo-attention_amd/lib/ab/lib_$tag.so /tmp/ab_$tag/duo_prefill.o $src/duo_decode.o $src/duo_rope_kv.o $src/duo_int4.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $src/$SRC.hip -o /tmp/ab_$tag/$SRC.o
+objs=""
+for f in duo_decode duo_prefill duo_rope_kv duo_int4; do
+  if [ $f = $SRC ]; then objs="$objs /tmp/ab_$tag/$f.o"; else objs="$objs $src/$f.o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/duo-attention_amd/lib/ab/lib_$tag.so $objs
 echo built lib_$tag.so
