@@ -68,11 +68,11 @@ def test_dependencies_and_hazards_of_the_steady_state():
             if c[1] == "a":
                 assert g >= 17 + half, (g, c)
             else:
-                assert g >= 49 + half or g <= 16, (g, c)
+                assert g >= 49 + half or g <= 26, (g, c)
         # exponentiation uses the max decided in the FIN statement of its block (same tile, or the previous one for B)
         if head == "v_fma_f32":
             x = "A" if _reads(op, r"sa\[.*") else "B"
-            assert g > fin[x] or (x == "B" and g <= 16), (g, x)
+            assert g > fin[x] or (x == "B" and g <= 26), (g, x)
         # V^T fragment f is free once ph2 MFMA 16+f has read it, and must land before the barrier in front of ph4
         for c in _writes(op, r"v(lo|hi)\[\d+\]"):
             f = int(re.search(r"\[(\d+)\]", c).group(1))
@@ -87,10 +87,19 @@ def test_dependencies_and_hazards_of_the_steady_state():
             for c in _writes(op, rf"pk{x}\[\d+\]"):
                 j = int(re.search(r"\[(\d+)\]", c).group(1))
                 need = first_mfma + 4 * (j >> 2)
-                gg = g if x == "A" or g > 16 else g + 64      # block B's late words are written in the next tile's ph1
+                gg = g if x == "A" or g > 26 else g + 64      # block B's late words are written in the next tile's ph1 / ph2
                 if x == "B":
                     need += 64
                 assert gg <= need - 2, (x, j, g)
+    # the rule of the table: a statement never reads or writes a register the statement before it wrote (the compiler
+    # assumes a 16-bit destination select in every asm statement and pads an s_nop otherwise) — row sums alternate
+    # between two accumulators, the row max between two pairs of chains, slice consumers sit two gaps behind
+    def regs(stmt, accs):
+        return {c for op in stmt for _, cls, c, acc in op.operands if cls == "v" and acc in accs and not c.startswith("W64_")}
+    for g in range(64):
+        nxt = gaps[(g + 1) % 64]
+        shared = regs(gaps[g], ("w", "rw")) & regs(nxt, ("r", "w", "rw"))
+        assert not shared, (g, shared)
     # no instruction reads a transcendental's result in the very next slot of the same statement
     for g, stmt in enumerate(gaps):
         for a, b in zip(stmt, stmt[1:]):
@@ -110,4 +119,4 @@ def test_gap_loads_are_balanced():
     gen = _gen()
     loads = [sum(op.n for op in stmt if not op.text.startswith("@MFMA@")) for stmt in gen.build_gaps("STEADY")]
     assert sum(loads) == 330
-    assert max(loads) <= 6 and min(loads) >= 3
+    assert max(loads) <= 8 and sorted(loads)[4] >= 4      # the two FIN gaps carry 7-8, the gap before block A's FIN 1

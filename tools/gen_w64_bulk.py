@@ -57,8 +57,11 @@ def S(x, k, h):
     return f"s{ab[x]}[{k >> 3}][{2 * (k & 7) + h}]"
 
 
+NT = 4   # slices in flight per block (asserted by the scheduler): temporaries e?[k % NT][h]
+
+
 def E(x, k, h):
-    return f"e{AB[x]}[{k & 1}][{h}]"
+    return f"e{AB[x]}[{k % NT}][{h}]"
 
 
 def fma(x, k, h):
@@ -71,8 +74,10 @@ def exp(x, k, h):
     return Op("v_exp_f32 {e}, {e}", [("e", "v", E(x, k, h), "rw")])
 
 
-def add(x, k, h):
-    return Op("v_add_f32 {l}, {l}, {e}", [("l", "v", f"lsum[{x}]", "rw"), ("e", "v", E(x, k, h), "r")])
+def add(x, k, h, parity):
+    # two row-sum accumulators per block, alternating by gap: no statement reads what the previous one wrote
+    acc = f"lsum[{x}]" if parity == 0 else f"lodd[{x}]"
+    return Op("v_add_f32 {l}, {l}, {e}", [("l", "v", acc, "rw"), ("e", "v", E(x, k, h), "r")])
 
 
 def cvt(x, k):
@@ -80,54 +85,37 @@ def cvt(x, k):
               [("pk", "v", f"pk{AB[x]}[{k}]", "w"), ("e0", "v", E(x, k, 0), "r"), ("e1", "v", E(x, k, 1), "r")])
 
 
-def slice_list(x):
-    """Two-stage pipeline over the 16 slices of a block: stage A(k) = fma, fma, exp, exp into temporaries pair k&1,
-    stage B(k-1) = add, cvt, add from pair (k-1)&1, interleaved so that no instruction reads the one just before it
-    (gfx950: a VALU may not read a transcendental's result in the very next slot)."""
-    L = []
-    for k in range(16):
-        L += [fma(x, k, 0), fma(x, k, 1)]
-        if k:
-            L += [add(x, k - 1, 0), cvt(x, k - 1)]
-        L += [exp(x, k, 0)]
-        if k:
-            L += [add(x, k - 1, 1)]
-        L += [exp(x, k, 1)]
-    L += [add(x, 15, 0), cvt(x, 15), add(x, 15, 1)]
-    return L
-
-
 def e8(x, b, r0):
     return [(f"e{j}", "v", f"s{ab[x]}[{b}][{r0 + j}]", "r") for j in range(8)]
 
 
-def max_init(x, b, r0):
+def max_init(x, b, r0, c0, c1):
     return Op("v_max3_f32 {h0}, {e0}, {e1}, {e2}\n"
               "v_max3_f32 {h1}, {e3}, {e4}, {e5}\n"
               "v_max3_f32 {h0}, {h0}, {e6}, {e7}",
-              [("h0", "v", f"h0{AB[x]}", "w"), ("h1", "v", f"h1{AB[x]}", "w")] + e8(x, b, r0), n=3)
+              [("h0", "v", f"h{c0}{AB[x]}", "w"), ("h1", "v", f"h{c1}{AB[x]}", "w")] + e8(x, b, r0), n=3)
 
 
-def max4(x, b, r0, combine=False):
-    t = ("v_max3_f32 {h1}, {h1}, {e0}, {e1}\n"
-         "v_max3_f32 {h0}, {h0}, {e2}, {e3}\n"
-         "v_max3_f32 {h1}, {h1}, {e4}, {e5}\n"
-         "v_max3_f32 {h0}, {h0}, {e6}, {e7}")
-    if combine:
-        t += "\nv_max3_f32 {h0}, {h0}, {h1}, {h1}"
-    return Op(t, [("h0", "v", f"h0{AB[x]}", "rw"), ("h1", "v", f"h1{AB[x]}", "rw")] + e8(x, b, r0),
-              n=5 if combine else 4)
+def max4(x, b, r0, c0, c1):
+    return Op("v_max3_f32 {h1}, {h1}, {e0}, {e1}\n"
+              "v_max3_f32 {h0}, {h0}, {e2}, {e3}\n"
+              "v_max3_f32 {h1}, {h1}, {e4}, {e5}\n"
+              "v_max3_f32 {h0}, {h0}, {e6}, {e7}",
+              [("h0", "v", f"h{c0}{AB[x]}", "rw"), ("h1", "v", f"h{c1}{AB[x]}", "rw")] + e8(x, b, r0), n=4)
 
 
 def max_fin(x):
-    # partner lane (the other 32 keys of the row), then: which lanes' tile max passed the rescale threshold
-    return Op("v_mov_b32 {h1}, {h0}\n"
+    # the four chains, then the partner lane (the other 32 keys of the row), then: which lanes' tile max passed the
+    # rescale threshold
+    return Op("v_max3_f32 {h0}, {h0}, {h1}, {h2}\n"
+              "v_max3_f32 {h0}, {h0}, {h3}, {h3}\n"
+              "v_mov_b32 {h1}, {h0}\n"
               "s_nop 1\n"
               "v_permlane32_swap_b32 {h0}, {h1}\n"
               "v_max3_f32 {h0}, {h0}, {h1}, {h1}\n"
               "v_cmp_gt_f32 {mk}, {h0}, {thr}",
-              [("h0", "v", f"h0{AB[x]}", "rw"), ("h1", "v", f"h1{AB[x]}", "w"),
-               ("mk", "sout", f"mk{AB[x]}", "w"), ("thr", "v", f"thr[{x}]", "r")], n=5)
+              [("h0", "v", f"h0{AB[x]}", "rw"), ("h1", "v", f"h1{AB[x]}", "rw"), ("h2", "v", f"h2{AB[x]}", "r"),
+               ("h3", "v", f"h3{AB[x]}", "r"), ("mk", "sout", f"mk{AB[x]}", "w"), ("thr", "v", f"thr[{x}]", "r")], n=7)
 
 
 def vread(i, hi):
@@ -185,33 +173,75 @@ def raw(text, clobbers=("memory",)):
 
 
 # ---- the placement table ------------------------------------------------------------------------------------------
-# chain timeline r (block A: gap 17 + r, block B: gap 49 + r, wrapping into the next tile's gaps 0..16):
-#   r 0..4   row max (INIT, MAX4, MAX4, MAX4C, FIN)
-#   r 5..14  slices, r 15..18 idle (block A: the V^T read burst; block B: the LDS-DMA pairs), r 19..31 slices
-# slice instructions per r (112 per block).  Block A pauses at r 15..18 (= gaps 32..35, the V^T read burst); block B
-# runs lighter in ph4 (its gaps also carry the K(t+1) reads and sit behind the barrier) and in the gaps that carry an
-# LDS-DMA piece
+# The compiler's hazard recogniser assumes that an asm statement may have written its outputs with a 16-bit destination
+# select, and puts an s_nop in front of the NEXT asm statement if that one touches any of them.  With a running sum, a
+# max chain or an exp feeding the next statement that was one wasted issue slot in almost every gap (57 per tile).
+# So the rule of the table: a statement never reads or writes a register the statement before it wrote.
+#   * row max: four chains, two per statement, alternating (r 0..3), combined two gaps after the last update (r 5)
+#   * row sums: two accumulators per block, by gap parity
+#   * slices: fma / exp / add+cvt+add scheduled per instruction, every consumer at least two gaps behind its producer
+#     (an exp may share the gap of its fma: same statement), NT temporaries pairs in flight
+# chain timeline r (block A: gap 17 + r, block B: gap 49 + r, wrapping into the next tile):
 VLAYOUT = os.environ.get("W64_GEN_VLAYOUT", "burst")   # burst: gaps 32..35 carry five V^T reads each; spread: 1-2 per gap
+# slice instructions a gap may take (block A pauses at r 15..18 = gaps 32..35, the V^T read burst; block B runs lighter
+# next to the K(t+1) reads of ph4, the LDS-DMA pieces and block A's row max)
 if VLAYOUT == "burst":
-    SIZES_A = {**{r: 5 for r in range(5, 15)}, **{r: 5 for r in range(19, 29)}, 29: 4, 30: 4, 31: 4}
+    CAP_A = {**{r: 5 for r in range(6, 15)}, **{r: 5 for r in range(19, 32)}, **{r: 3 for r in range(32, 42)}}
 else:
-    SIZES_A = {**{r: 4 for r in range(5, 15)}, **{r: 3 for r in range(15, 23)}, **{r: 5 for r in range(23, 29)},
-               29: 6, 30: 6, 31: 6}
-SIZES_B = ({**{r: 4 for r in range(5, 15)}, **{r: 3 for r in range(15, 19)}, **{r: 5 for r in range(19, 29)},
-            29: 3, 30: 3, 31: 4} if os.environ.get("W64_GEN_BSIZES", "light") == "light" else SIZES_A)
+    CAP_A = {**{r: 4 for r in range(6, 15)}, **{r: 3 for r in range(15, 23)}, **{r: 5 for r in range(23, 32)},
+             **{r: 3 for r in range(32, 42)}}
+CAP_B = ({**{r: 4 for r in range(6, 15)}, **{r: 3 for r in range(15, 19)}, **{r: 5 for r in range(19, 29)},
+          **{r: 3 for r in range(29, 33)}, **{r: 2 for r in range(33, 36)}, 36: 5, **{r: 2 for r in range(37, 42)}}
+         if os.environ.get("W64_GEN_BSIZES", "light") == "light" else CAP_A)
+FIN_R = 5
+
+
+def schedule_slices(x, cap, gap0):
+    """r -> ops of block x's 16 slices (112 instructions), list-scheduled oldest slice first"""
+    deps = {"F0": [], "F1": [], "X0": ["F0"], "X1": ["F1"], "A0": ["X0"], "C": ["X0", "X1"], "A1": ["X1"]}
+    rank = {"A0": 0, "C": 0, "A1": 0, "X0": 1, "X1": 1, "F0": 2, "F1": 2}
+    pending = [(k, o) for k in range(16) for o in ("F0", "F1", "X0", "X1", "A0", "C", "A1")]
+    place, by_r = {}, {}
+    for r in sorted(cap):
+        picked = []
+        while len(picked) < cap[r]:
+            def ready(k, o):
+                for d in deps[o]:
+                    g = place.get((k, d))
+                    if g is None or (g > r - 2 and not (o[0] == "X" and g == r)):
+                        return False
+                return True
+            oldest = min(k for k, _ in pending) if pending else 0
+            cands = [(k, o) for (k, o) in pending if ready(k, o) and not (o[0] == "F" and k - oldest >= NT)]
+            if not cands:
+                break
+            k, o = min(cands, key=lambda ko: (rank[ko[1]], ko[0]))
+            place[(k, o)] = r
+            pending.remove((k, o))
+            picked.append((k, o))
+        # text order inside the statement: fma, then add / cvt, the exps last (an exp of this gap's fma sits behind it)
+        picked.sort(key=lambda ko: {"F": 0, "A": 1, "C": 1, "X": 2}[ko[1][0]])
+        parity = (gap0 + r) & 1
+        mk = {"F0": lambda k: fma(x, k, 0), "F1": lambda k: fma(x, k, 1), "X0": lambda k: exp(x, k, 0),
+              "X1": lambda k: exp(x, k, 1), "A0": lambda k: add(x, k, 0, parity), "A1": lambda k: add(x, k, 1, parity),
+              "C": lambda k: cvt(x, k)}
+        by_r[r] = [mk[o](k) for k, o in picked]
+    assert not pending, pending
+    # the temporaries of slice k are free before slice k + NT starts; P words land two gaps before their MFMA
+    for k in range(16 - NT):
+        assert max(place[(k, o)] for o in ("A0", "C", "A1")) < place[(k + NT, "F0")], k
+    need0 = 48 if x == 0 else 80
+    for k in range(16):
+        assert gap0 + place[(k, "C")] <= need0 + 4 * (k >> 2) - 2, (x, k)
+    return by_r
 
 
 def chain_ops(x):
     """r -> list of ops for block x"""
-    by_r = {0: [max_init(x, 0, 0)], 1: [max4(x, 0, 8)], 2: [max4(x, 1, 0)], 3: [max4(x, 1, 8, combine=True)],
-            4: [max_fin(x)]}
-    L = slice_list(x)
-    sizes = SIZES_B if x else SIZES_A
-    assert sum(sizes.values()) == len(L), (sum(sizes.values()), len(L))
-    pos = 0
-    for r in sorted(sizes):
-        by_r[r] = L[pos:pos + sizes[r]]
-        pos += sizes[r]
+    by_r = {0: [max_init(x, 0, 0, 0, 1)], 1: [max_init(x, 0, 8, 2, 3)], 2: [max4(x, 1, 0, 0, 1)], 3: [max4(x, 1, 8, 2, 3)],
+            FIN_R: [max_fin(x)]}
+    for r, ops in schedule_slices(x, CAP_B if x else CAP_A, 49 if x else 17).items():
+        by_r.setdefault(r, []).extend(ops)
     return by_r
 
 
@@ -267,8 +297,8 @@ def build_gaps_full(variant):
         # LDS reads first (they land sooner), then the softmax work
         if variant != "DRAIN":
             if VLAYOUT == "burst":
-                if 22 <= g <= 31:          # V^T(t) fragments 0..4: their registers were last read by ph2 MFMA 16+f
-                    j = g - 22
+                if 21 <= g <= 31 and g != 22:     # V^T(t) fragments 0..4 (free once ph2 MFMA 16+f has read them); not in block A's FIN gap
+                    j = g - 21 if g < 22 else g - 22
                     ops.append(vread(j >> 1, j & 1))
                 if 32 <= g <= 35:          # fragments 6..15: five reads per gap (block A's chain idles here)
                     for j in range(5):
@@ -288,8 +318,8 @@ def build_gaps_full(variant):
             ops += A.get(g - 17, [])
             if g >= 49:
                 ops += B.get(g - 49, [])
-        if variant in ("STEADY", "DRAIN") and g + 15 in B and g <= 16:
-            ops += B[g + 15]           # block B of the previous tile
+        if variant in ("STEADY", "DRAIN") and g + 15 in B and g <= 26:
+            ops += B[g + 15]           # block B of the previous tile (r = g + 15)
         if piece:
             if len(ops) == nbefore:
                 ops.append(raw("s_nop 0", clobbers=()))
@@ -380,10 +410,10 @@ def emit_variant(variant, out):
         out.append(f"// gap {g}: {nfill}")
         emit_stmt(ops, out, prefix)
         if variant != "DRAIN":
-            if g == 21:
+            if g == 17 + FIN_R:
                 out.append(("if (__builtin_expect(mkA != 0, 0))" if LIKELY else "if (mkA != 0)") + " rescale(std::integral_constant<int, 0>{}, h0A);")
                 out.append("__builtin_amdgcn_sched_barrier(0);")
-            if g == 53:
+            if g == 49 + FIN_R:
                 out.append(("if (__builtin_expect(mkB != 0, 0))" if LIKELY else "if (mkB != 0)") + " rescale(std::integral_constant<int, 1>{}, h0B);")
                 out.append("__builtin_amdgcn_sched_barrier(0);")
             if g == 63:
