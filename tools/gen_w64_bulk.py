@@ -12,10 +12,10 @@ alternatives that were measured against it (tools/debug/build_variant.sh + w64_t
 
 Tile t, 64 gaps (gap g = the instructions issued behind MFMA g):
     ph1  g  0..15   S_A(t)  = K(t) . Q_A^T        | block B(t-1) slices (rest), LDS-DMA of tile t+2: K pieces g 0..3, V pieces g 14..17
-    ph2  g 16..31   O_B    += V^T(t-1) . P_B(t-1) | row max A(t) g 17..21, block A(t) slices, V^T(t) reads (one per gap g 22..31)
+    ph2  g 16..31   O_B    += V^T(t-1) . P_B(t-1) | row max A(t) g 17..20 + g 22, block A(t) slices from g 23, V^T(t) reads (one per gap)
     ph3  g 32..47   S_B(t)  = K(t) . Q_B^T        | V^T(t) read burst (five per gap g 32..35; spreading them measured 0.6 % slower), block A(t) slices
          -- lgkmcnt(0), vmcnt(8), ONE s_barrier --
-    ph4  g 48..63   O_A    += V^T(t) . P_A(t)     | K(t+1) fragment reads (one per gap), row max B(t) g 49..53, block B(t) slices
+    ph4  g 48..63   O_A    += V^T(t) . P_A(t)     | K(t+1) fragment reads (one per gap), row max B(t) g 49..52 + g 54, block B(t) slices from g 55
 
 Variants: STEADY (above), FIRST (first tile of a bulk run: no block B(t-1) work, no ph2 MFMAs) and DRAIN (after
 the last tile of a run: the pending block-B slices and the 16 ph2 MFMAs only).
