@@ -176,7 +176,9 @@ def raw(text, clobbers=("memory",)):
 # The compiler's hazard recogniser assumes that an asm statement may have written its outputs with a 16-bit destination
 # select, and puts an s_nop in front of the NEXT asm statement if that one touches any of them.  With a running sum, a
 # max chain or an exp feeding the next statement that was one wasted issue slot in almost every gap (57 per tile).
-# So the rule of the table: a statement never reads or writes a register the statement before it wrote.
+# So the rule of the table: a statement never reads or writes a register the statement before it wrote.  (An asm
+# statement counts as zero wait states in that look-back, so a register written TWO statements back still draws the pad
+# unless a compiler-generated instruction sits in between: 57 -> 31 pads per tile, not 0.)
 #   * row max: four chains, two per statement, alternating (r 0..3), combined two gaps after the last update (r 5)
 #   * row sums: two accumulators per block, by gap parity
 #   * slices: fma / exp / add+cvt+add scheduled per instruction, every consumer at least two gaps behind its producer
