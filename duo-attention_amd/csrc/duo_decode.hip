@@ -295,22 +295,31 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
 }
 
 
-// grid.x = (kv head, split) pairs of the full class then of the streaming class
-// grid.y = group / GT
 #ifdef DUO_DECODE_TIMING   /* measurement builds only (tools/debug/decode_timing.py): s_memtime of wave 0 per workgroup */
-__device__ unsigned long long duo_decode_timing[2048][8];
+__device__ unsigned long long duo_decode_timing[2048][12];
 #define DUO_DT(k)                                                                                  \
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048)                              \
             duo_decode_timing[blockIdx.x][k] = __builtin_amdgcn_s_memtime();                       \
     } while (0)
+/* constant-rate clock (100 MHz): the only one that compares across XCDs */
+#define DUO_DRT(k)                                                                                 \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 2048)                              \
+            duo_decode_timing[blockIdx.x][k] = __builtin_amdgcn_s_memrealtime();                   \
+    } while (0)
 #else
 #define DUO_DT(k) do { } while (0)
+#define DUO_DRT(k) do { } while (0)
 #endif
+
+// grid.x = (kv head, split) pairs of the full class then of the streaming class
+// grid.y = group / GT
 
 template <int GT, bool NT, bool PREFETCH, bool FUSED>
 __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParams P, const CompressParams CP) {
     DUO_DT(0);
+    DUO_DRT(8);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar loop control
     const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
@@ -507,175 +516,303 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
         }
     }
 
-    // ---- combine the 4 token groups of the wave (lanes l, l^16, l^32, l^48 hold
-    //      the same dim slice), then the 4 waves through LDS -------------------
+#include "duo_decode_tail.inc"
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// duo_decode_scan_kernel — the same split-KV scan behind a SHORT prologue (round 3; duo_decode_split_kernel above is
+// kept as the general fallback and as the same-box A/B, debug bit 9).
+//
+// What the anatomy of the launch showed (profiles/r2_decode_wgs.md): all 256 workgroups run their prologue at the
+// same time, so HBM idles for its whole length, and the prologue was a chain of DEPENDENT memory round trips of
+// ~1 us each — kernel arguments (scalar loads, the class descriptor picked through a computed address) -> q rows ->
+// first K/V rows.  Here
+//   * everything the retrieval class needs to form its q and K/V addresses is the first 14 dwords of the argument
+//     list (plain scalars, one s_load batch, no class select through a computed address); streaming-class workgroups,
+//     a handful per launch and short, read their descriptor from the by-value parameter block as before.  (Preloading
+//     those 14 dwords into SGPRs at wave launch — -mllvm -amdgpu-kernarg-preload-count=14 — was built and measured:
+//     1.582 / 1.590 vs 1.589 / 1.589 ms per token, no difference, so the build does not use it.)
+//   * the loads go out back to back in the order they are consumed — RoPE frequencies, q rows, then the FIRST K/V
+//     group (clamped per-lane addresses, so it is unconditional and the counted waits stay exact), then the new
+//     token's rows — and the RoPE factors / q rotation are computed underneath them: one memory round trip instead
+//     of three before the first FMA;
+//   * the new token's k/v rows sit in registers through the scan, so the epilogue of the last split has no load.
+// pack0 = splits of the retrieval class (bits 0-11) | q heads per kv head (12-17) | first q head of the class (18-31);
+// pack1 = q head stride in elements (0-15) | rows of the retrieval class's segment B (16-31).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t cvt_pk_bf16_rne(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    hw_bf16x2_t r = __builtin_convertvector(v, hw_bf16x2_t);   // v_cvt_pk_bf16_f32: round to nearest even
+    return *reinterpret_cast<uint32_t *>(&r);
+}
+
+template <int GT, bool NT, bool FUSED>
+__global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__restrict__ q, const bf16_t *k0,
+                                                              const bf16_t *v0, const int32_t *dev_state, int32_t len0,
+                                                              uint32_t pack0, int32_t nblk_full, uint32_t hs0,
+                                                              uint32_t ts0, uint32_t pack1, const DecodeParams P,
+                                                              const CompressParams CP) {
+    DUO_DT(0);
+    DUO_DRT(8);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar loop control
+    const int sub = lane & 15;   // which 8-dim slice of the 128-dim row
+    const int tg = lane >> 4;    // which of the 4 rows a wave-load covers
+
+    // ---- class description: retrieval class from the preloaded SGPRs, streaming class from the kernarg segment -----
+    int b = blockIdx.x;
+    const int ci = b < nblk_full ? 0 : 1;
+    const int group = (int)((pack0 >> 12) & 63u);
+    const bf16_t *ak = k0, *av = v0;
+    int64_t a_ts = ts0, a_hs = hs0;
+    int a_len = len0, b_len = (int)(pack1 >> 16), splits = (int)(pack0 & 4095u), qoff = (int)(pack0 >> 18);
+    int app_row = 0, st_full = 0, st_str = 0;
+    float pos = 0.f;
+    bool have_state = false;
+    if constexpr (FUSED) {
+        if (dev_state) {   // captured step: lengths / position live in device memory (uniform scalar loads)
+            st_full = dev_state[0];
+            st_str = dev_state[1];
+            pos = (float)dev_state[2];
+            app_row = st_full;
+            have_state = true;
+        }
+    }
+    if (ci) {
+        asm volatile("" ::: "memory");   // a real branch: retrieval workgroups must not wait for these scalar loads
+        b -= nblk_full;
+        ak = P.cls[1].a.k;
+        av = P.cls[1].a.v;
+        a_ts = P.cls[1].a.token_stride;
+        a_hs = P.cls[1].a.head_stride;
+        a_len = P.cls[1].a.len;
+        b_len = P.cls[1].b.len;
+        splits = P.splits[1];
+        qoff = P.cls[1].q_head_offset;
+    }
+    if constexpr (FUSED) {
+        if (have_state) a_len = ci ? st_str : st_full;
+    }
+    const int kvh = b / splits;
+    const int split = b - kvh * splits;
+    const int qh0 = qoff + kvh * group + blockIdx.y * GT;
+
+    // balanced static partition (as duo_decode_split_kernel): the head's 64-token units dealt evenly to the splits
+    const int L = FUSED ? a_len : a_len + b_len;
+    const int units = (L + 63) >> 6;
+    const int uq = units / splits, ur = units - uq * splits;
+    const int u0 = split * uq + min(split, ur);
+    const int un = uq + (split < ur ? 1 : 0);
+    const int c0 = u0 << 6;
+    const int c1 = min((u0 + un) << 6, L);
+    const int per_wave = (((c1 - c0 + 3) >> 2) + 15) & ~15;  // quarter of the chunk, multiple of 16
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + wave * per_wave);
+    const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
+
+    const char *kA = reinterpret_cast<const char *>(ak + (int64_t)kvh * a_hs);
+    const char *vA = reinterpret_cast<const char *>(av + (int64_t)kvh * a_hs);
+    uint32_t roff[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) roff[u] = ((uint32_t)(4 * u + tg) * (uint32_t)a_ts + (uint32_t)sub * 8u) * 2u;
+
+    // ================= loads, in the order they are consumed =======================================================
+    // (a) RoPE frequencies of this lane's 8 dims (FUSED): dims 8*sub+e pair with dims (8*sub+e) ^ 64; both slices of a
+    //     pair use frequency index (8*sub+e) & 63.  Vector loads from the kernarg segment (per-lane index).
+    f32x4 fr0 = {0.f, 0.f, 0.f, 0.f}, fr1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSED) {
+        const float *fp = &P.inv_freq[(sub & 7) << 3];
+        fr0 = *reinterpret_cast<const f32x4 *>(fp);
+        fr1 = *reinterpret_cast<const f32x4 *>(fp + 4);
+    }
+    // (b) q rows (own slice, and the rotation partner's when q arrives un-rotated)
+    const uint32_t qhs = pack1 & 0xffffu;
+    u32x4 qw[GT], qp[GT];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-        float mm = m[g];
-        mm = fmaxf(mm, __shfl_xor(mm, 16));
-        mm = fmaxf(mm, __shfl_xor(mm, 32));
-        const float sc = fast_exp2(m[g] - mm);
-        float ll = l[g] * sc;
-        ll += __shfl_xor(ll, 16);
-        ll += __shfl_xor(ll, 32);
-        m[g] = mm;
-        l[g] = ll;
+        const bf16_t *qrow = q + (int64_t)(qh0 + g) * qhs;
+        qw[g] = *reinterpret_cast<const u32x4 *>(qrow + sub * 8);
+        if constexpr (FUSED) qp[g] = *reinterpret_cast<const u32x4 *>(qrow + (sub ^ 8) * 8);
+    }
+    // (c) the first K/V group of this wave: per-lane row index clamped into segment A (which always has a readable
+    //     row 0: an empty segment A is given the base of segment B by the launcher), so the eight loads are
+    //     unconditional.  When the wave has a full first group (nfast > 0) no lane is clamped and the registers hold
+    //     exactly what load_fast(t_first) would have fetched.
+    // The wave's full groups are visited in ROTATED order (attention does not care, the order is a fixed function of the
+    // block id, so results stay reproducible): all 256 workgroups otherwise walk their equally long, equally aligned
+    // chunks in lockstep — at every instant the whole chip reads the same offset of 256 chunks (debug bit 11: no rotation).
+    const int fast_end = min(w1, a_len);
+    const int nfast = fast_end > w0 ? (fast_end - w0) / kTokPerIter : 0;
+    const int rot = (nfast > 1 && !(P.dbg & 2048u)) ? (int)((blockIdx.x * 13u + (uint32_t)wave * 8u) % (uint32_t)nfast) : 0;
+    const int t_first = __builtin_amdgcn_readfirstlane(w0 + rot * kTokPerIter);
+    u32x4 k0r[4], v0r[4], k1r[4], v1r[4];
+    {
+        const int last = max(a_len - 1, 0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = acc[g][e] * sc;
-            a += __shfl_xor(a, 16);
-            a += __shfl_xor(a, 32);
-            acc[g][e] = a;
+        for (int u = 0; u < 4; ++u) {
+            const int tok = min(t_first + 4 * u + tg, last);
+            const int64_t off = ((int64_t)tok * a_ts + sub * 8) * 2;
+            k0r[u] = ld16<NT>(reinterpret_cast<const bf16_t *>(kA + off));
+            v0r[u] = ld16<NT>(reinterpret_cast<const bf16_t *>(vA + off));
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    DUO_DT(4);
 
-    __shared__ float s_ml[4][GT][2];
-    __shared__ float s_acc[4][GT][DUO_HEAD_DIM];
-    if (tg == 0) {
-#pragma unroll
-        for (int g = 0; g < GT; ++g) {
-            if (sub == 0) {
-                s_ml[wave][g][0] = m[g];
-                s_ml[wave][g][1] = l[g];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s_acc[wave][g][sub * 8 + e] = acc[g][e];
-        }
-    }
-    __syncthreads();
-
-    const bool publish = FUSED && P.one_launch && splits > 1;
-    if (!publish) {
-        for (int idx = threadIdx.x; idx < GT * DUO_HEAD_DIM; idx += 256) {
-            const int g = idx >> 7;
-            const int d = idx & 127;
-            float M = s_ml[0][g][0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
-            float Lsum = 0.f, o = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float sc = fast_exp2(s_ml[w][g][0] - M);
-                Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
-                o = fmaf(s_acc[w][g][d], sc, o);
-            }
-            const int qh = qh0 + g;
-            if (splits == 1) {
-                // single split: this workgroup saw every key of the head
-                P.out[(int64_t)qh * P.out_head_stride + d] = (bf16_t)f32_to_bf16_bits(o / Lsum);
-            } else {
-                const int64_t slot = (int64_t)qh * P.max_splits + split;
-                P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
-                if (d == 0) {
-                    P.ws_ml[slot * 2 + 0] = M;
-                    P.ws_ml[slot * 2 + 1] = Lsum;
-                }
-            }
-        }
-    } else {
-        // Single-launch step: the partial is PUBLISHED to other workgroups of this launch — write-through
-        // (sc1) 16-byte stores, so no release fence (an L2 write-back per workgroup) is needed; same values
-        // as the loop above, four dims per thread.
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.ws_ml, 0, P.ws_bytes, 0x00020000);
-        const uint32_t acc_base = (uint32_t)((const char *)P.ws_acc - (const char *)P.ws_ml);
-        for (int idx = threadIdx.x; idx < GT * (DUO_HEAD_DIM / 4); idx += 256) {
-            const int g = idx >> 5;
-            const int d = (idx & 31) * 4;
-            float M = s_ml[0][g][0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][g][0]);
-            float Lsum = 0.f;
-            f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float sc = fast_exp2(s_ml[w][g][0] - M);
-                Lsum = fmaf(s_ml[w][g][1], sc, Lsum);
-                o.x = fmaf(s_acc[w][g][d + 0], sc, o.x);
-                o.y = fmaf(s_acc[w][g][d + 1], sc, o.y);
-                o.z = fmaf(s_acc[w][g][d + 2], sc, o.z);
-                o.w = fmaf(s_acc[w][g][d + 3], sc, o.w);
-            }
-            const uint32_t slot = (uint32_t)(qh0 + g) * P.max_splits + split;
-            u32x4 ow = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(ow, rsrc, acc_base + (slot * DUO_HEAD_DIM + d) * 4, 0, 16);
-            if (d == 0) {
-                const unsigned long long ml = ((unsigned long long)__float_as_uint(Lsum) << 32) | __float_as_uint(M);
-                __hip_atomic_store(reinterpret_cast<unsigned long long *>(P.ws_ml + (size_t)slot * 2), ml,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its own stores
-    }
-
-    DUO_DT(3);
-    // ---- single-launch step: the merge of the partials and the streaming-pool update happen here ---------
-    // (grid.y == 1 is guaranteed by the launcher, so the workgroups of a kv head are exactly its `splits`)
+    // ================= everything below runs underneath those loads ================================================
+    const DuoSegDev Bseg = duo_select(P.cls[0].b, P.cls[1].b, ci != 0);
     if constexpr (FUSED) {
-        if (!P.one_launch) return;
-        if (P.one_launch == 2) {
-            // two launches, but a streaming head scanned by ONE workgroup updates its pool right here (every read of
-            // that head's pool by this launch is this workgroup's own scan, behind the barrier above): the epilogue
-            // launch is then the merge alone
-            if (splits == 1 && ci == 1 && CP.n_heads > 0) {
-                duo_stream_compress_block(CP, 2 * kvh);
-                duo_stream_compress_block(CP, 2 * kvh + 1);
-            }
-            return;
-        }
-        bool do_compress = false;
-        if (splits == 1) {
-            // this workgroup saw every cached row of the head; its waves left the scan through the barrier above
-            do_compress = ci == 1;
-        } else {
-            // The partial went out write-through and drained above; after the barrier one lane takes the head's
-            // ticket (MI355X inter-workgroup hand-off, form R1).  The LAST min(splits, 4 GT) arrivals of the head
-            // stay as mergers: merger j takes the (q head, 32-dim quarter) tasks j, j + NM, ...; every merger
-            // first waits until all `splits` partials are published (bounded spin).
-            __shared__ int s_ticket;
-            int32_t *cnt = P.tickets + 2 * ((ci ? P.cls[0].n_kv_heads : 0) + kvh);
-            __syncthreads();
-            if (threadIdx.x == 0)
-                s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int n = s_ticket;
-            const int n_tasks = 4 * GT;
-            const int NM = min(splits, n_tasks);
-            if (n < splits - NM) return;
-            const int j = n - (splits - NM);
-            if (threadIdx.x == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < splits) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSpinLimit) {   // never seen; better a flagged wrong answer than a hung GPU
-                        __hip_atomic_store(P.tickets + kTicketWords - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
-                    }
-                }
-                // no acquire fence: the partials were stored sc1 and are read back with sc1 loads
-            }
-            __syncthreads();
-            for (int task = j; task < n_tasks; task += NM) {
-                duo_decode_merge_task<true>(P.ws_ml, P.ws_acc, P.ws_bytes, P.out, P.out_head_stride, P.max_splits,
-                                            qh0 + (task >> 2), task & 3, splits);
-                __syncthreads();
-            }
-            do_compress = ci == 1 && j == 0;   // (a streaming class scanned in splits: an all-streaming layer)
-            // the last merger to finish re-arms the head's tickets for the next launch
-            if (threadIdx.x == 0) {
-                const int d = __hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (d == NM - 1) {
-                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        if (do_compress && CP.n_heads > 0) {
-            // sink+recent update of this streaming head's K and V rows (every read of the pool by this launch
-            // is behind us: this workgroup's own scan, or — split scan — all arrivals of the head)
-            duo_stream_compress_block(CP, 2 * kvh);
-            duo_stream_compress_block(CP, 2 * kvh + 1);
+        if (!have_state) {
+            app_row = P.app_row;
+            pos = P.pos;
         }
     }
+    // (d) the new token's rows (FUSED): k slice, its rotation partner, v slice — every wave loads them (L2 hits), only
+    //     the last split's wave 0 uses them after the scan
+    u32x4 nkw = {0u, 0u, 0u, 0u}, nkp = {0u, 0u, 0u, 0u}, nvw = {0u, 0u, 0u, 0u};
+    if constexpr (FUSED) {
+        const bf16_t *krow = Bseg.k + (int64_t)kvh * Bseg.head_stride;
+        const bf16_t *vrow = Bseg.v + (int64_t)kvh * Bseg.head_stride;
+        nkw = *reinterpret_cast<const u32x4 *>(krow + sub * 8);
+        nkp = *reinterpret_cast<const u32x4 *>(krow + (sub ^ 8) * 8);
+        nvw = *reinterpret_cast<const u32x4 *>(vrow + sub * 8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float cs[8], sn[8];
+    if constexpr (FUSED) {
+        const float fr[8] = {fr0.x, fr0.y, fr0.z, fr0.w, fr1.x, fr1.y, fr1.z, fr1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sincos_rev(pos * fr[e], sn[e], cs[e]);
+    }
+    DUO_DT(5);
+    // x: own slice, y: partner slice -> rotated own slice (first half: x*c - y*s, second half: x*c + y*s), rounded to
+    // bf16 exactly like the standalone RoPE kernel does before the attention reads it; `packed` = the bf16 bits
+    auto rope8 = [&](const u32x4 &own, const u32x4 &partner, float (&o)[8], u32x4 &packed) {
+        float x[8], y[8];
+        unpack8(own, x);
+        unpack8(partner, y);
+        const float sgn = sub < 8 ? -1.f : 1.f;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            w[e >> 1] = cvt_pk_bf16_rne(x[e] * cs[e] + sgn * y[e] * sn[e], x[e + 1] * cs[e + 1] + sgn * y[e + 1] * sn[e + 1]);
+            o[e] = bf16_lo(w[e >> 1]);
+            o[e + 1] = bf16_hi(w[e >> 1]);
+        }
+        packed.x = w[0]; packed.y = w[1]; packed.z = w[2]; packed.w = w[3];
+    };
+
+    float qf[GT][8];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        if constexpr (FUSED) {
+            u32x4 unused;
+            rope8(qw[g], qp[g], qf[g], unused);
+        } else {
+            unpack8(qw[g], qf[g]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[g][e] *= P.scale_log2e;
+    }
+
+    float m[GT], l[GT], acc[GT][8];
+    DUO_DT(1);
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        m[g] = kNegSentinel;
+        l[g] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+    }
+
+    // ---- main loop: as duo_decode_split_kernel (uniform SGPR base + constant per-lane offsets, a fixed number of
+    //      loads in flight at every use); its first group is already on the way -------------------------------------
+    auto load_fast = [&](int t, u32x4 (&kb)[4], u32x4 (&vb)[4]) __attribute__((always_inline)) {
+        gchar_t *kt = uniform_gptr(kA + (int64_t)t * a_ts * 2), *vt = uniform_gptr(vA + (int64_t)t * a_ts * 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(roff[u]));
+            kb[u] = ld16g<NT>(kt + roff[u]);
+            vb[u] = ld16g<NT>(vt + roff[u]);
+        }
+    };
+    int t_rest = w0;
+    if (nfast > 0) {
+        // nfast groups starting at t_first, wrapping from the last one back to w0; the load behind the last group
+        // re-reads it (never consumed), as before
+        const int t_last = w0 + (nfast - 1) * kTokPerIter;
+        int t = t_first;
+        for (int i = 0;; i += 2) {
+            int t1 = t + kTokPerIter;
+            t1 = t1 > t_last ? w0 : t1;
+            t1 = i + 1 < nfast ? t1 : t;
+            load_fast(t1, k1r, v1r);
+            __builtin_amdgcn_sched_barrier(0);
+            if (P.dbg & 64u) l[0] += __uint_as_float((k0r[0].x ^ k0r[1].y ^ k0r[2].z ^ k0r[3].w ^ v0r[0].x ^ v0r[1].y ^ v0r[2].z ^ v0r[3].w) & 1u);
+            else consume_rows<GT, true>(k0r, v0r, t, tg, w1, qf, m, l, acc);
+            if (i + 1 >= nfast) break;
+            int t2 = t1 + kTokPerIter;
+            t2 = t2 > t_last ? w0 : t2;
+            t2 = i + 2 < nfast ? t2 : t1;
+            load_fast(t2, k0r, v0r);
+            __builtin_amdgcn_sched_barrier(0);
+            if (P.dbg & 64u) l[0] += __uint_as_float((k1r[0].x ^ k1r[1].y ^ k1r[2].z ^ k1r[3].w ^ v1r[0].x ^ v1r[1].y ^ v1r[2].z ^ v1r[3].w) & 1u);
+            else consume_rows<GT, true>(k1r, v1r, t1, tg, w1, qf, m, l, acc);
+            if (i + 2 >= nfast) break;
+            t = t2;
+        }
+        t_rest = w0 + nfast * kTokPerIter;
+    }
+    {
+        // what is left: a partial group of segment A, segment B rows (non-fused form) — general clamped loader
+        RowSrc src;
+        src.ka = reinterpret_cast<const bf16_t *>(kA) + sub * 8;
+        src.va = reinterpret_cast<const bf16_t *>(vA) + sub * 8;
+        src.kb = Bseg.k + (int64_t)kvh * Bseg.head_stride + sub * 8;
+        src.vb = Bseg.v + (int64_t)kvh * Bseg.head_stride + sub * 8;
+        src.tsa = a_ts;
+        src.tsb = Bseg.token_stride;
+        src.lenA = a_len;
+        u32x4 kt[4], vt[4];
+        for (int t = t_rest; t < w1; t += kTokPerIter) {
+            load_rows<NT>(src, t, tg, w1, kt, vt);
+            consume_rows<GT>(kt, vt, t, tg, w1, qf, m, l, acc);
+        }
+    }
+
+    DUO_DT(2);
+    if constexpr (FUSED) {
+        // ---- the new token: last split of the kv head, wave 0, token group 0 (one 16-lane DPP row) ----
+        if (split == splits - 1 && wave == 0 && tg == 0) {
+            float kf[8], vf[8];
+            u32x4 kr;   // rotated slice, bf16
+            rope8(nkw, nkp, kf, kr);
+            unpack8(nvw, vf);
+#pragma unroll
+            for (int g = 0; g < GT; ++g) {
+                float d = qf[g][0] * kf[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e) d = fmaf(qf[g][e], kf[e], d);
+                const float sc_ = row16_allreduce_sum(d);
+                const float mn = fmaxf(m[g], sc_);
+                const float alpha = fast_exp2(m[g] - mn);
+                const float p_ = fast_exp2(sc_ - mn);
+                l[g] = fmaf(l[g], alpha, p_);
+                m[g] = mn;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(p_, vf[e], acc[g][e] * alpha);
+            }
+            // retrieval heads: the rotated key and the value join the pool (row app_row is outside every scan range
+            // of this launch)
+            if (ci == 0 && blockIdx.y == 0) {
+                const int64_t po = (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
+                *reinterpret_cast<u32x4 *>(P.app_k + po) = kr;
+                *reinterpret_cast<u32x4 *>(P.app_v + po) = nvw;
+            }
+        }
+    }
+#include "duo_decode_tail.inc"
 }
 
 // Epilogue launch of a decode step: blocks [0, n_merge) merge the split-KV partials of one q-head quarter
@@ -754,6 +891,7 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     D.nblk = 0;
     D.n_merge = 0;
     if (n_q_heads <= 0) return 0;
+    if ((q_head_stride & 7) || (out_head_stride & 3)) return DUO_EINVAL;   // 16-byte q loads, 8-byte out stores
     for (int c = 0; c < 2; ++c) {
         const DuoClassDev &C = P.cls[c];
         if (C.n_kv_heads <= 0) { P.cls[c].n_kv_heads = 0; continue; }
@@ -801,6 +939,21 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     return 0;
 }
 
+// The short-prologue scan kernel takes the retrieval class's addressing in 14 preloaded dwords; it applies when those
+// fields fit their packed widths (always, for the pools and activations this library's callers hand over).
+static bool decode_scan_eligible(const DecodeParams &P) {
+    const DuoClassDev &F = P.cls[0];
+    auto u32ok = [](int64_t x) { return x >= 0 && x <= 0xffffffffll; };
+    if (P.group <= 0 || P.group > 63 || P.q_head_stride < 0 || P.q_head_stride > 0xffff) return false;
+    if (F.n_kv_heads > 0) {
+        if (P.splits[0] <= 0 || P.splits[0] > 4095 || F.q_head_offset < 0 || F.q_head_offset > 16383) return false;
+        if (!u32ok(F.a.token_stride) || !u32ok(F.a.head_stride) || F.b.len < 0 || F.b.len > 0xffff) return false;
+    }
+    const DuoClassDev &S = P.cls[1];
+    if (S.n_kv_heads > 0 && (S.a.token_stride < 0 || S.a.head_stride < 0)) return false;
+    return true;
+}
+
 template <bool FUSED>
 static int decode_launch_split(const DecodePlan &D, const CompressParams &CP, hipStream_t st) {
     if (D.nblk <= 0) return 0;
@@ -809,6 +962,29 @@ static int decode_launch_split(const DecodePlan &D, const CompressParams &CP, hi
     const uint32_t fl = duo_get_debug_flags();
     const bool nt = !(fl & 4u);        // debug bit 2: plain (temporal) K/V loads
     const bool pf = !(fl & 8u);        // debug bit 3: no register prefetch of the next 16 tokens
+    // debug bit 9: stay on duo_decode_split_kernel (the long-prologue form: same-box A/B of the two scans)
+    if (pf && !(fl & 512u) && decode_scan_eligible(P)) {
+        const DuoClassDev &F = P.cls[0];
+        const bool hasF = F.n_kv_heads > 0;
+        const uint32_t pack0 = hasF ? ((uint32_t)P.splits[0] | ((uint32_t)P.group << 12) | ((uint32_t)F.q_head_offset << 18))
+                                    : (1u | ((uint32_t)P.group << 12));
+        const uint32_t pack1 = (uint32_t)P.q_head_stride | (hasF ? (uint32_t)F.b.len << 16 : 0u);
+        const uint32_t hs0 = hasF ? (uint32_t)F.a.head_stride : 0u, ts0 = hasF ? (uint32_t)F.a.token_stride : 0u;
+        const int32_t len0 = hasF ? F.a.len : 0;
+#define DUO_LAUNCH_SCAN(GT_)                                                                                          \
+    do {                                                                                                              \
+        if (nt) hipLaunchKernelGGL((duo_decode_scan_kernel<GT_, true, FUSED>), grid, block, 0, st, P.q, F.a.k, F.a.v,     \
+                                   P.dev_state, len0, pack0, P.nblk_full, hs0, ts0, pack1, P, CP);                       \
+        else hipLaunchKernelGGL((duo_decode_scan_kernel<GT_, false, FUSED>), grid, block, 0, st, P.q, F.a.k, F.a.v,       \
+                                P.dev_state, len0, pack0, P.nblk_full, hs0, ts0, pack1, P, CP);                          \
+    } while (0)
+        if (D.gt == 4) DUO_LAUNCH_SCAN(4);
+        else if (D.gt == 2) DUO_LAUNCH_SCAN(2);
+        else DUO_LAUNCH_SCAN(1);
+#undef DUO_LAUNCH_SCAN
+        DUO_HIP_CHECK_LAUNCH();
+        return 0;
+    }
 #define DUO_LAUNCH_DECODE(GT_)                                                                                      \
     do {                                                                                                            \
         if (nt && pf) hipLaunchKernelGGL((duo_decode_split_kernel<GT_, true, true, FUSED>), grid, block, 0, st, P, CP);   \
@@ -996,6 +1172,6 @@ extern "C" int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_laye
 
 #ifdef DUO_DECODE_TIMING
 extern "C" int duo_debug_decode_timing(unsigned long long *host_out) {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(duo_decode_timing), sizeof(unsigned long long) * 2048 * 8);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(duo_decode_timing), sizeof(unsigned long long) * 2048 * 12);
 }
 #endif

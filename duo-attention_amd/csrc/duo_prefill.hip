@@ -616,6 +616,7 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     if ((out_token_stride | out_head_stride) & 3) return DUO_EINVAL;
     if (nblk == 0) return 0;
     P.nblk_full = long_wgs * P.ksplit;
+    P.xmap_rows = P.xmap_q = 0;
 
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
@@ -648,6 +649,18 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
                 if (e != hipSuccess) return (int)e;
                 if (dev < 64) w64_attr[dev][F16].store(true, std::memory_order_release);
+            }
+            // XCD-aware order of the retrieval class (unsplit launches; DUO_PREFILL_XMAP=0 / debug bit 10: plain order)
+            static const bool want_xmap = [] { const char *e = getenv("DUO_PREFILL_XMAP"); return !e || atoi(e) != 0; }();
+            if (want_xmap && !(g_debug_flags & 1024u) && P.ksplit == 1 && long_wgs > 0) {
+                const int row_items = P.cls[0].n_kv_heads * group;
+                int rows = 1;
+                while ((rows * row_items) % 8 != 0) rows *= 2;       // 1, 2, 4 or 8 rows: the first multiple of 8 workgroups
+                const int periods = (P.n_qtiles + rows - 1) / rows;
+                P.xmap_rows = rows;
+                P.xmap_q = rows * row_items / 8;
+                nblk += periods * rows * row_items - P.nblk_full;     // the padded last period
+                P.nblk_full = periods * rows * row_items;
             }
             if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
             else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);

@@ -34,6 +34,9 @@ struct PrefillParams {
     int32_t ksplit;
     float *ws_o;     // [block][256 rows][128] fp32
     float *ws_ml;    // [block][256 rows][2]   (row max in score units, row sum)
+    // XCD-aware block order of the retrieval class (4-wave kernel, unsplit launches; see duo_prefill_w64_kernel.inc):
+    // q-tile rows per period and workgroups per XCD per period; xmap_q == 0: plain q-tile-major order
+    int32_t xmap_rows, xmap_q;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;

@@ -161,6 +161,9 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 _lib = None
+# DUO_DEBUG_FLAGS=<bits>: debug flags OR-ed into every set_debug_flags call (same-box A/B of kernel variants through
+# unmodified harnesses; see duo_set_debug_flags in include/duo_attn_hip.h)
+_ENV_DEBUG_FLAGS = int(os.environ.get("DUO_DEBUG_FLAGS", "0") or "0", 0)
 
 
 def load_library(path: Optional[str] = None):
@@ -184,6 +187,8 @@ def load_library(path: Optional[str] = None):
         raise DuoHipError(f"ABI mismatch: library {lib.duo_abi_version()} vs binding {ABI_VERSION}")
     if path is None:
         _lib = lib
+    if _ENV_DEBUG_FLAGS:
+        lib.duo_set_debug_flags(_ENV_DEBUG_FLAGS)
     return lib
 
 
@@ -568,4 +573,4 @@ def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optio
 
 
 def set_debug_flags(flags: int):
-    load_library().duo_set_debug_flags(int(flags))
+    load_library().duo_set_debug_flags(int(flags) | _ENV_DEBUG_FLAGS)

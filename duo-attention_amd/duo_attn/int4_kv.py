@@ -46,7 +46,16 @@ class DuoAttentionStaticINT4KVCache:
         self.device = next(model.parameters()).device
         self.dtype = next(model.parameters()).dtype
         cfg = model.config
-        self.num_layers = cfg.num_hidden_layers
+        # a model sharded over pipeline stages (duo_attn.pipeline.shard_model_for_pp): this rank owns the pools of the
+        # layers it kept, indexed by LOCAL layer number like the patched forwards do; `full_attention_heads` may be the
+        # whole model's pattern or already the stage's rows (same rule as DuoAttentionStaticKVCache)
+        pp = getattr(model, "_duo_pp", None)
+        if pp is not None:
+            full_attention_heads = pp.local_rows(full_attention_heads)
+        full_attention_heads = list(full_attention_heads)
+        self.num_layers = len(full_attention_heads) if pp is not None else cfg.num_hidden_layers
+        if len(full_attention_heads) != self.num_layers:
+            raise ValueError(f"{len(full_attention_heads)} head-pattern rows for {self.num_layers} layers")
         self.num_heads = cfg.num_attention_heads
         self.num_kv_heads = cfg.num_key_value_heads
         self.num_kv_groups = self.num_heads // self.num_kv_heads

@@ -62,6 +62,12 @@ class LayerPipeline:
             self.bounds = even_layer_split(num_layers, self.world_size)
         self.first_layer, self.last_layer = self.bounds[self.rank]
 
+    def peer(self, stage: int) -> int:
+        """Stage index (= rank inside ``group``) -> the GLOBAL rank torch.distributed's point-to-point calls take as
+        ``src`` / ``dst`` / ``P2POp`` peer.  Identity for the default group; a pipeline that lives on a sub-group
+        (stages on ranks 4..7, one pipeline per tensor-parallel slice) needs the translation."""
+        return dist.get_global_rank(self.group, stage) if self.group is not None else stage
+
     @property
     def is_first(self):
         return self.rank == 0
@@ -90,7 +96,9 @@ class LayerPipeline:
         token); on the first stage it is called as ``token_feedback(i, token)`` with the tensor received
         for item i-1 -> i (its return value is ignored).  One extra 8-byte hop per item."""
         n = len(shapes)
-        prev_rank, next_rank = self.rank - 1, self.rank + 1
+        prev_rank = self.peer(self.rank - 1) if self.rank > 0 else -1
+        next_rank = self.peer(self.rank + 1) if self.rank + 1 < self.world_size else -1
+        first_rank, last_rank = self.peer(0), self.peer(self.world_size - 1)
         recv_bufs = [None, None]
         recv_work = [None, None]
         send_work = [None, None]
@@ -111,7 +119,7 @@ class LayerPipeline:
             x = None
             if feedback and self.is_first and i > 0:
                 tok = torch.empty(shapes[i][0], 1, device=device, dtype=torch.int64)
-                dist.recv(tok, src=self.world_size - 1, group=self.group)
+                dist.recv(tok, src=last_rank, group=self.group)
                 token_feedback(i, tok)
             if not self.is_first:
                 recv_work[slot].wait()
@@ -120,7 +128,7 @@ class LayerPipeline:
             if self.is_last:
                 outs.append(y)
                 if feedback and i + 1 < n:
-                    dist.send(token_feedback(i, y), dst=0, group=self.group)
+                    dist.send(token_feedback(i, y), dst=first_rank, group=self.group)
                 post_recv(i + 1)
                 continue
             outs.append(None)
@@ -142,9 +150,15 @@ class LayerPipeline:
                     dist.P2POp(dist.isend, keep_alive[slot], next_rank, group=self.group),
                     dist.P2POp(dist.irecv, recv_bufs[nslot], prev_rank, group=self.group),
                 ])
-                pair = _WorkGroup(works)
-                send_work[slot] = pair
-                recv_work[nslot] = pair
+                if len(works) == 2:
+                    # the backend hands back one request per operation (gloo; RCCL returns ONE for the coalesced group):
+                    # wait for the receive before computing and for the send only before its buffer is reused, so a slow
+                    # downstream stage does not hold up this stage's next item
+                    send_work[slot], recv_work[nslot] = works[0], works[1]
+                else:
+                    pair = _WorkGroup(works)
+                    send_work[slot] = pair
+                    recv_work[nslot] = pair
         for w in send_work:
             if w is not None:
                 w.wait()
@@ -158,9 +172,13 @@ class PPState:
     """Pipeline placement of a sharded HF model (``model._duo_pp`` and ``model.model._duo_pp``): which layers this
     rank kept, where they live, and the in-flight hand-off of the per-call mode."""
 
-    def __init__(self, pipe: LayerPipeline, device, num_layers_total: int):
+    def __init__(self, pipe: LayerPipeline, device, num_layers_total: int, handoff=None):
         self.pipe = pipe
         self.device = torch.device(device)
+        # where hand-off buffers live: the compute device (RCCL moves device memory), or "cpu" for a gloo group —
+        # the one-GPU rehearsal of the multi-rank path (every rank computes on cuda:0, the hidden state crosses
+        # through host memory; tests/test_sharded_models_gpu.py, DUO_BENCH_DEBUG_SHARED_GPU)
+        self.handoff = torch.device(handoff) if handoff is not None else self.device
         self.first_layer, self.last_layer = pipe.first_layer, pipe.last_layer
         self.num_layers_total = num_layers_total
         self._send = None          # (work, tensor) of the last asynchronous send of the per-call mode
@@ -185,28 +203,27 @@ class PPState:
 
     # ---- per-call hand-off: ``model(input_ids=chunk, past_key_values=kv)`` on every rank ---------------------
     def recv_hidden(self, shape, dtype):
-        buf = torch.empty(shape, device=self.device, dtype=dtype)
-        dist.recv(buf, src=self.pipe.rank - 1, group=self.pipe.group)
-        return buf
+        buf = torch.empty(shape, device=self.handoff, dtype=dtype)
+        dist.recv(buf, src=self.pipe.peer(self.pipe.rank - 1), group=self.pipe.group)
+        return buf.to(self.device)
 
     def send_hidden(self, x):
         """asynchronous: the call returns while the hidden state leaves, so this rank starts its next chunk
         while the next stage works on this one (chunks pipeline across successive model calls)"""
         if self._send is not None:
             self._send[0].wait()
-        x = x.contiguous()
-        self._send = (dist.isend(x, dst=self.pipe.rank + 1, group=self.pipe.group), x)
+        x = x.contiguous().to(self.handoff)
+        self._send = (dist.isend(x, dst=self.pipe.peer(self.pipe.rank + 1), group=self.pipe.group), x)
 
     def broadcast_from_last(self, t, shape, dtype):
         if t is None:
-            t = torch.empty(shape, device=self.device, dtype=dtype)
-        src = self.pipe.world_size - 1
-        src = dist.get_global_rank(self.pipe.group, src) if self.pipe.group is not None else src
-        dist.broadcast(t, src=src, group=self.pipe.group)
-        return t
+            t = torch.empty(shape, device=self.handoff, dtype=dtype)
+        t = t.to(self.handoff)
+        dist.broadcast(t, src=self.pipe.peer(self.pipe.world_size - 1), group=self.pipe.group)
+        return t.to(self.device)
 
 
-def shard_model_for_pp(model, device, group=None, layer_costs=None) -> PPState:
+def shard_model_for_pp(model, device, group=None, layer_costs=None, handoff=None) -> PPState:
     """In place: keep this rank's contiguous block of decoder layers (+ ``embed_tokens`` on the first stage,
     ``norm`` / ``lm_head`` on the last), move them to ``device``, drop the rest.  Even split like the reference
     (``utils.py:251-271``) unless ``layer_costs`` is given.  Works before or after the DuoAttention enabler:
@@ -216,7 +233,7 @@ def shard_model_for_pp(model, device, group=None, layer_costs=None) -> PPState:
     inner = model.model
     n_layers = len(inner.layers)
     pipe = LayerPipeline(n_layers, group=group, layer_costs=layer_costs)
-    pp = PPState(pipe, device, n_layers)
+    pp = PPState(pipe, device, n_layers, handoff=handoff)
     kept = [inner.layers[i].to(pp.device) for i in range(pp.first_layer, pp.last_layer)]
     inner.layers = torch.nn.ModuleList(kept)
     if pp.is_first:
@@ -264,10 +281,10 @@ class PipelinedCausalLM:
     Logits exist on the last stage (``None`` elsewhere); ``decode`` returns the tokens on every rank.
     """
 
-    def __init__(self, model, full_attention_heads, device, group=None, even_split_layers=False):
+    def __init__(self, model, full_attention_heads, device, group=None, even_split_layers=False, handoff=None):
         heads = [[float(x) for x in torch.as_tensor(h).flatten().tolist()] for h in full_attention_heads]
         costs = None if even_split_layers else [1.0 + sum(1 for x in h if x > 0.5) / max(1, len(h)) for h in heads]
-        self.pp = shard_model_for_pp(model, device, group=group, layer_costs=costs)
+        self.pp = shard_model_for_pp(model, device, group=group, layer_costs=costs, handoff=handoff)
         self.pipe = self.pp.pipe
         self.model = model
         self.device = self.pp.device
@@ -288,6 +305,8 @@ class PipelinedCausalLM:
         inner = self.model.model
         if self.pipe.is_first:
             x = inner.embed_tokens(ids.to(self.device))
+        else:
+            x = x.to(self.device)          # (no-op unless the hand-off goes through host memory)
         kw = {} if row_block is None else {"row_block": row_block}
         for li, layer in enumerate(inner.layers):
             x = layer(x, position_ids=None, kv_cache=kv, layer_idx=li, use_cache=True, pos0=pos0, **kw)[0]
@@ -319,9 +338,9 @@ class PipelinedCausalLM:
             y = self._stage(x, input_ids[:, a:b], kv, base + a - (rb[0] if rb else 0), rb)
             if self.pipe.is_last and i == len(items) - 1:
                 last["logits"] = self._logits(y)
-            return y
+            return y if self.pipe.is_last else y.to(self.pp.handoff)
 
-        self.pipe.run(shapes, stage, self.device, self.dtype)
+        self.pipe.run(shapes, stage, self.pp.handoff, self.dtype)
         return last.get("logits")
 
     # ------------------------------------------------------------------ decode
@@ -337,7 +356,7 @@ class PipelinedCausalLM:
 
         def feedback(i, t):
             if self.pipe.is_last:
-                return toks[-1]
+                return toks[-1].to(self.pp.handoff)
             cur["tok"] = t
 
         def stage(i, x):
@@ -349,9 +368,9 @@ class PipelinedCausalLM:
                 toks.append(lg[:, -1, :].argmax(-1, keepdim=True).to(torch.int64))
                 if not multi:
                     cur["tok"] = toks[-1]
-            return y
+            return y if self.pipe.is_last else y.to(self.pp.handoff)
 
-        self.pipe.run([(B, 1, self.hidden)] * n_new, stage, self.device, self.dtype,
+        self.pipe.run([(B, 1, self.hidden)] * n_new, stage, self.pp.handoff, self.dtype,
                       token_feedback=feedback if multi else None)
         out = torch.cat(toks, 1) if self.pipe.is_last else None
         if multi:

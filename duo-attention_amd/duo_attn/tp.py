@@ -62,6 +62,24 @@ def balanced_head_assignment(full_attention_heads, tp: int) -> List[List[List[in
     return out
 
 
+def _host_staged(group) -> bool:
+    """gloo cannot reduce / gather device memory: a gloo group with GPU tensors (the one-GPU rehearsal of the
+    multi-rank path — every rank computes on cuda:0 — tests/test_sharded_models_gpu.py) stages through the host.
+    RCCL ("nccl") moves device memory directly."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(y: torch.Tensor, group=None) -> torch.Tensor:
+    """in-place sum over the TP group of a row-parallel output [B, S, hidden]"""
+    if y.is_cuda and _host_staged(group):
+        h = y.detach().to("cpu", torch.float32)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        y.copy_(h.to(y.dtype))
+        return y
+    dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+    return y
+
+
 class RowParallelLinear(nn.Module):
     """y = all_reduce_sum(x_local @ W_local^T): the slice of a Linear over its INPUT features."""
 
@@ -84,9 +102,7 @@ class RowParallelLinear(nn.Module):
         return self.inner.bias
 
     def forward(self, x):
-        y = self.inner(x)
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
-        return y
+        return all_reduce_sum(self.inner(x), self.group)
 
 
 def _slice_rows(linear: nn.Linear, rows: torch.Tensor) -> nn.Linear:
@@ -152,11 +168,14 @@ def gather_full_attention_heads(model, local_heads):
     tp, group = info["tp"], info["group"]
     out = []
     for l, mine in enumerate(local_heads):
-        parts = [torch.empty_like(mine) for _ in range(tp)]
-        dist.all_gather(parts, mine.contiguous(), group=group)
+        src = mine.contiguous()
+        if src.is_cuda and _host_staged(group):
+            src = src.to("cpu", torch.float32)
+        parts = [torch.empty_like(src) for _ in range(tp)]
+        dist.all_gather(parts, src, group=group)
         full = torch.empty(info["num_kv_heads"], dtype=mine.dtype, device=mine.device)
         for r in range(tp):
-            full[torch.tensor(info["assign"][l][r], device=mine.device)] = parts[r]
+            full[torch.tensor(info["assign"][l][r], device=mine.device)] = parts[r].to(mine.device, mine.dtype)
         out.append(full)
     return out
 

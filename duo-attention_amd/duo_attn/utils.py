@@ -142,7 +142,8 @@ def balanced_layer_split(costs, num_stages: int):
     return bounds[::-1]
 
 
-def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_map=True, even_split_layers=True):
+def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_map=True, even_split_layers=True,
+              pp_handoff=None):
     """Single device: ``model.to(device)``.  ``enable_pp`` with a device list is the layer pipeline of reference
     utils.py:228-283 — as ONE PROCESS PER GPU (launch with torch.distributed.run): this rank keeps its contiguous
     block of decoder layers (embedding on the first stage, norm + lm_head on the last) on ``device[rank]`` and
@@ -150,7 +151,8 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
     The calls that follow in the reference's harnesses work unchanged on every rank:
     ``enable_*_duo_attention_static_kv_cache_eval(model, heads)``, ``DuoAttentionStaticKVCache(model, heads, ...)``
     (this rank's pools only) and ``model(input_ids=chunk, past_key_values=kv)`` (logits on the last rank; for a
-    decode step on every rank).  ``reverse_device_map`` (an accelerate hook-ordering detail) has no meaning here."""
+    decode step on every rank).  ``reverse_device_map`` (an accelerate hook-ordering detail) has no meaning here.
+    ``pp_handoff="cpu"``: the hidden state crosses through host memory (a gloo group: one-GPU rehearsal of the path)."""
     if isinstance(device, list):
         if len(device) == 1:
             return model.to(f"cuda:{device[0]}")
@@ -174,7 +176,7 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
             from .pipeline import shard_model_for_pp
 
             dev = device[dist.get_rank()]
-            shard_model_for_pp(model, dev if isinstance(dev, str) else f"cuda:{dev}")
+            shard_model_for_pp(model, dev if isinstance(dev, str) else f"cuda:{dev}", handoff=pp_handoff)
             return model
         raise ValueError("a device list needs enable_pp (or enable_tp)")
     return model.to(device)

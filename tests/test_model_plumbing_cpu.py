@@ -233,3 +233,28 @@ def test_config0_llama2_7b_shape_4k_prompt(exact_backend):
     assert kv2.full_key_states_list[0].shape == (1, N + 8, 8, 128) and kv2.streaming_key_states_list[0].shape == (1, 384, 24, 128)
     assert kv2.memory_usage == 2 * ((N + 8) * 8 + 384 * 24) * 128 * 4              # K and V, fp32 model here
     assert torch.isfinite(outs2[-1]).all() and not torch.allclose(outs2[-1], outs[1], atol=1e-3)   # eviction changes the result
+
+
+def test_int4_cache_is_pipeline_stage_aware():
+    """on a layer-pipeline stage the INT4 cache must hold the pools of the stage's OWN layers (indexed by
+    local layer number, like DuoAttentionStaticKVCache), not of global layers 0..k."""
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+    from duo_attn.pipeline import LayerPipeline, PPState
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+    from helpers import ShapeModel
+
+    heads = [[1, 0, 0, 0], [1, 1, 0, 0], [0, 0, 0, 0], [1, 1, 1, 0], [1, 1, 1, 1]]
+    model = ShapeModel(5, 8, 4, 128, dtype=torch.float16)
+    pipe = LayerPipeline(5, rank=1, world_size=2)                    # even split: stage 1 = layers [3, 5) or [2, 5)
+    model._duo_pp = PPState(pipe, "cpu", 5)
+    lo, hi = pipe.first_layer, pipe.last_layer
+    want = [int(sum(h)) for h in heads[lo:hi]]
+    for rows in (heads, heads[lo:hi]):                                 # whole-model pattern or the stage's rows
+        kv = DuoAttentionStaticINT4KVCache(model, rows, 1, 32, 4, 8, 16)
+        ref = DuoAttentionStaticKVCache(model, rows, 1, 32, 4, 8)
+        assert kv.num_layers == ref.num_layers == hi - lo
+        assert kv.num_full_kv_head_list == ref.num_full_kv_head_list == want
+        assert len(kv.kv_seq_len_list) == hi - lo and kv.kv_seq_len == 0
+        assert [c.quantized_data.shape[2] for c in kv.full_key_caches] == want
+    with pytest.raises(ValueError):
+        DuoAttentionStaticINT4KVCache(model, heads[:4], 1, 32, 4, 8, 16)

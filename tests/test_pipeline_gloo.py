@@ -59,7 +59,7 @@ def _sample(y):
     return y.float().abs().argmax().reshape(1, 1).to(torch.int64) % 97
 
 
-def _worker(rank, world, port, counts, chunks, q):
+def _worker(rank, world, port, counts, chunks, q, subgroups=None):
     _setup_paths()
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -71,8 +71,18 @@ def _worker(rank, world, port, counts, chunks, q):
 
         backend._set_backend_for_testing(OracleBackend())
         Hq, Hkv, D, sink, recent = 4, 2, 128, 2, 4
+        group = None
+        if subgroups is not None:
+            # several pipelines side by side, each on a sub-group whose ranks are NOT 0..n-1 (stage index != global
+            # rank): every process creates every group (torch.distributed's rule), then works in its own
+            groups = [dist.new_group(ranks=r) for r in subgroups]
+            group = groups[[rank in r for r in subgroups].index(True)]
         # ragged costs -> the bottleneck-minimising split (what bench.py uses for N > 1)
-        pipe = LayerPipeline(len(counts), layer_costs=[0.5 + c for c in counts])
+        pipe = LayerPipeline(len(counts), layer_costs=[0.5 + c for c in counts], group=group)
+        if subgroups is not None:
+            mine = [r for r in subgroups if rank in r][0]
+            assert pipe.rank == mine.index(rank) and pipe.world_size == len(mine)
+            assert pipe.peer(pipe.rank) == rank and [pipe.peer(i) for i in range(len(mine))] == mine
         assert pipe.bounds[0][0] == 0 and pipe.bounds[-1][1] == len(counts)
         stage = _hot_path_stage_factory(counts, Hq, Hkv, sink, recent, sum(chunks) + 2,
                                         (pipe.first_layer, pipe.last_layer))
@@ -101,6 +111,28 @@ def _worker(rank, world, port, counts, chunks, q):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def test_pipelines_on_subgroups_address_global_ranks():
+    """Two independent 2-stage pipelines inside one 4-rank world, on the sub-groups {1, 3} and {2, 0}: stage indices are
+    group-relative, the point-to-point peers torch.distributed wants are GLOBAL ranks (LayerPipeline.peer)."""
+    counts, chunks = [1, 0, 2, 1], [9, 7, 5, 1, 1, 1]
+    expected = _single_process(counts, chunks)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    subgroups = [[1, 3], [2, 0]]
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, counts, chunks, q, subgroups)) for r in range(4)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(2)]      # the last stage of each pipeline reports
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for got in results:
+        assert len(got) == len(expected)
+        for a, b in zip(got, expected):
+            assert (a == b).all()
 
 
 def _single_process(counts, chunks):

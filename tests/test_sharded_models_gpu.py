@@ -1,0 +1,275 @@
+"""GPU: the SHARDED model paths on the HIP backend (SURVEY §8 rows (e) layer pipeline and f4 head-parallel TP).
+
+The CPU twins (test_model_pipeline_gloo.py, test_tp_gloo.py) drive the host plumbing with the oracle as device
+backend.  Here the same shardings run the real kernels: N processes, EVERY rank computing on cuda:0 (the box has one
+GPU), a gloo group for the exchange and the hand-off staged through host memory — the `DUO_BENCH_DEBUG_SHARED_GPU`
+pattern.  What the reference's evaluations run (duo_attn/utils.py:206-283, patch/llama.py:601-693) and what a one-GPU
+test cannot reach otherwise: a TP shard's shapes (4 local kv heads, ragged local retrieval-head counts, the
+retrieval-first order produced by `balanced_head_assignment`), a pipeline stage's local layer indexing, row-block
+prefill inside `PipelinedCausalLM`.
+
+Checks, per sharding:
+  * every attention call each rank makes is recorded (inputs + result) and recomputed with the oracle's
+    `flash_attn_func_ref` (tests/test_tuple_path_gpu.py::check_calls_against_oracle) — inside the worker;
+  * logits / greedy tokens against the SAME model run by ONE process on the HIP backend.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+VOCAB = 211
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, "duo-attention_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+# ----------------------------------------------------------------------------- models (same seed in every process)
+def _tp_model():
+    """Llama-3-8B head geometry (32 q heads, 8 kv heads, D = 128) on a narrow hidden size: a TP-2 shard has 4 local kv heads"""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(21)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=3, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=VOCAB, max_position_embeddings=8192,
+                      rope_theta=500000.0, attn_implementation="eager", tie_word_embeddings=False)
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).eval().to(DEV)
+
+
+# retrieval heads scattered over the kv heads: 5, 3 and 6 of 8 -> TP-2 shards hold (3, 2), (1, 2) / (2, 1), (3, 3)
+TP_HEADS = np.array([[1, 0, 1, 1, 0, 1, 0, 1], [0, 0, 1, 0, 0, 1, 1, 0], [1, 1, 0, 1, 1, 1, 0, 1]], dtype=float)
+TP_CHUNKS = (200, 130, 64, 1, 1, 1)
+SINK, RECENT = 16, 48
+
+
+def _pp_model():
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    torch.manual_seed(33)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=5, num_attention_heads=8,
+                      num_key_value_heads=2, head_dim=128, vocab_size=VOCAB, max_position_embeddings=8192,
+                      rope_theta=500000.0, attn_implementation="eager", tie_word_embeddings=False)
+    return LlamaForCausalLM(cfg).to(torch.bfloat16).eval().to(DEV)
+
+
+PP_HEADS = [[1.0, 0.0], [0.0, 0.0], [1.0, 1.0], [0.0, 1.0], [1.0, 0.0]]
+PP_PROMPT, PP_CHUNK, PP_ROWS, PP_NEW = 300, 128, 32, 6
+
+
+def _ids(n, seed):
+    return torch.randint(0, VOCAB, (1, n), generator=torch.Generator().manual_seed(seed))
+
+
+class _NoFusedStep:
+    """HIP backend without the fused decode step: q_len == 1 then goes RoPE -> append -> `attention` (the split-KV
+    decode kernel through duo_attn_decode_bf16), which the Recorder sees."""
+
+    def __init__(self, inner):
+        self._inner = inner
+
+    def __getattr__(self, name):
+        if name in ("decode_layer", "decode_layer_dev"):
+            raise AttributeError(name)
+        return getattr(self._inner, name)
+
+
+def _recording_backend(fused):
+    from duo_attn import backend
+    from test_tuple_path_gpu import Recorder
+
+    inner = backend.HipBackend()
+    rec = Recorder(inner if fused else _NoFusedStep(inner))
+    backend._set_backend_for_testing(rec)
+    return rec
+
+
+def _run_static(model, heads, chunks, ids):
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+
+    enable_llama_duo_attention_static_kv_cache_eval(model, np.array(heads, dtype=float).copy())
+    kv = DuoAttentionStaticKVCache(model, heads, 1, sum(chunks) + 4, SINK, RECENT)
+    outs, pos = [], 0
+    with torch.no_grad():
+        for c in chunks:
+            outs.append(model(input_ids=ids[:, pos:pos + c].to(DEV), past_key_values=kv, use_cache=True).logits.float().cpu())
+            pos += c
+    return torch.cat(outs, 1), kv
+
+
+# ----------------------------------------------------------------------------- workers
+def _init(rank, world, port):
+    _paths()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def _tp_worker(rank, world, port, fused, q):
+    dist = _init(rank, world, port)
+    try:
+        from duo_attn import backend
+        from duo_attn.tp import shard_model_for_tp
+        from test_tuple_path_gpu import check_calls_against_oracle
+
+        model = _tp_model()
+        if world > 1:
+            heads = shard_model_for_tp(model, TP_HEADS)
+            assert heads.shape == (3, 8 // world) and (np.diff(heads, axis=1) <= 0).all()    # retrieval heads first
+            nf = heads.sum(1).astype(int).tolist()
+            assert nf in ([3, 1, 3], [2, 2, 3], [3, 2, 3], [2, 1, 3]), nf                      # ragged per rank
+        else:
+            heads = TP_HEADS
+        rec = _recording_backend(fused)
+        try:
+            logits, kv = _run_static(model, heads, TP_CHUNKS, _ids(sum(TP_CHUNKS), 22))
+        finally:
+            backend._set_backend_for_testing(None)
+        assert rec.calls and kv.kv_seq_len == sum(TP_CHUNKS)
+        if not fused:
+            assert any(c[0].shape[0] == 1 for c in rec.calls)        # the decode steps went through `attention`
+        check_calls_against_oracle(rec.calls, f"tp{world} rank {rank}")
+        if world > 1:      # the TP-aware accessors of the reference (llama.py:601-693) on device tensors
+            from duo_attn.patch import enable_duo_attention_eval, get_full_attention_heads
+
+            m2 = _tp_model()
+            loc2 = shard_model_for_tp(m2, TP_HEADS)
+            enable_duo_attention_eval(m2, loc2.copy(), SINK, RECENT)
+            got = torch.stack(get_full_attention_heads(m2)).float().cpu().numpy()
+            assert np.array_equal(got, TP_HEADS), got
+        if rank == 0:
+            q.put(logits.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _pp_worker(rank, world, port, mode, q):
+    dist = _init(rank, world, port)
+    try:
+        from duo_attn import backend
+        from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+        from duo_attn.pipeline import PipelinedCausalLM
+        from duo_attn.utils import to_device
+        from test_tuple_path_gpu import check_calls_against_oracle
+
+        model = _pp_model()
+        ids = _ids(PP_PROMPT, 34)
+        rec = _recording_backend(True)
+        try:
+            if mode == "drop_in":
+                # the reference harness line for line on every rank (eval/efficiency/benchmark_static.py:35-105)
+                model = to_device(model, [0] * world, enable_pp=True, pp_handoff="cpu") if world > 1 else model
+                enable_llama_duo_attention_static_kv_cache_eval(model, np.array(PP_HEADS))
+                kv = DuoAttentionStaticKVCache(model, PP_HEADS, 1, PP_PROMPT + PP_NEW + 2, SINK, RECENT)
+                with torch.no_grad():
+                    for i in range(0, PP_PROMPT, PP_CHUNK):
+                        last = i + PP_CHUNK >= PP_PROMPT
+                        kw = {"sync_logits": last} if world > 1 else {}
+                        out = model(input_ids=ids[:, i:i + PP_CHUNK].to(DEV), past_key_values=kv, use_cache=True, **kw)
+                    logits = out.logits
+                    tok = logits[:, -1, :].argmax(-1, keepdim=True)
+                    toks = []
+                    for _ in range(PP_NEW):
+                        out = model(input_ids=tok, past_key_values=kv, use_cache=True)
+                        tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
+                        toks.append(int(tok))
+            else:
+                enable_llama_duo_attention_static_kv_cache_eval(model, np.array(PP_HEADS))
+                pl = PipelinedCausalLM(model, PP_HEADS, DEV, handoff="cpu" if world > 1 else None)
+                kv = pl.make_kv_cache(1, PP_PROMPT + PP_NEW + 2, SINK, RECENT)
+                logits = pl.prefill(ids, kv, PP_CHUNK, row_block=PP_ROWS)
+                if world > 1:
+                    logits = pl.pp.broadcast_from_last(logits, (1, 1, VOCAB), torch.bfloat16)
+                tok = logits[:, -1, :].argmax(-1, keepdim=True)
+                out = pl.decode(tok, kv, PP_NEW)
+                toks = [int(t) for t in out[0]]
+                assert kv.kv_seq_len == PP_PROMPT + PP_NEW
+        finally:
+            backend._set_backend_for_testing(None)
+        n_local = len(model.model.layers)
+        assert rec.calls and (world == 1 or n_local < len(PP_HEADS))
+        if mode != "drop_in":
+            assert any(c[0].shape[0] == PP_ROWS for c in rec.calls)     # row-block launches really happened
+        check_calls_against_oracle(rec.calls, f"pp{world} {mode} rank {rank}")
+        if rank == world - 1:
+            q.put((logits.float().cpu().numpy(), toks))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _queue
+    import time
+
+    got, t0 = None, time.time()
+    try:
+        while got is None:
+            try:
+                got = q.get(timeout=5)
+            except _queue.Empty:
+                dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, f"worker died with exit code {dead}"
+                assert time.time() - t0 < 900, "sharded-model workers timed out"
+    finally:
+        for p in procs:
+            p.join(timeout=300)
+            if p.is_alive():
+                p.kill()
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    return got
+
+
+# ----------------------------------------------------------------------------- tests
+@pytest.mark.parametrize("fused", [True, False])
+def test_tp2_on_hip_equals_single_process_hip(fused):
+    """duo_attn.tp.shard_model_for_tp, two ranks on the HIP kernels: per-call oracle replay on every rank, logits against
+    the one-process HIP model (bf16; the two-way sums of the all-reduces only change the rounding order)."""
+    want = _spawn(_tp_worker, 1, fused)
+    got = _spawn(_tp_worker, 2, fused)
+    assert got.shape == want.shape == (1, len(TP_CHUNKS), VOCAB)
+    for i in range(len(TP_CHUNKS)):
+        r = _rel(torch.from_numpy(got[:, i]), torch.from_numpy(want[:, i]))
+        assert r < 2e-2, (i, r)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "row_blocks"), (3, "row_blocks"), (2, "drop_in")])
+def test_pipelined_model_on_hip_equals_single_process_hip(world, mode):
+    """Layer pipeline on the HIP kernels: `PipelinedCausalLM.prefill(..., row_block=32)` + `decode`, and the reference
+    harness's own loop on a `to_device(enable_pp=True)` model — same greedy tokens as ONE process running the same code."""
+    want_logits, want_toks = _spawn(_pp_worker, 1, mode)
+    got_logits, got_toks = _spawn(_pp_worker, world, mode)
+    assert got_toks == want_toks
+    assert _rel(torch.from_numpy(got_logits), torch.from_numpy(want_logits)) < 1e-2

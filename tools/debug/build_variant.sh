@@ -8,7 +8,9 @@ root=$(cd "$(dirname "$0")/../.." && pwd)
 src=$root/duo-attention_amd/csrc
 make -s -C $src
 mkdir -p $root/duo-attention_amd/lib/ab /tmp/ab_$tag
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c $src/$SRC.hip -o /tmp/ab_$tag/$SRC.o
+extra=""   # e.g. EXTRA="-mllvm -amdgpu-kernarg-preload-count=14" (measured: no effect on the decode scan, profiles/r3_decode.md)
+extra="$EXTRA"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c $src/$SRC.hip -o /tmp/ab_$tag/$SRC.o
 objs=""
 for f in duo_decode duo_prefill duo_rope_kv duo_int4; do
   if [ $f = $SRC ]; then objs="$objs /tmp/ab_$tag/$f.o"; else objs="$objs $src/$f.o"; fi
