@@ -40,6 +40,15 @@ import torch.distributed as dist  # noqa: E402
 # retrieval ("full") kv heads per layer: attn_patterns/Llama-3-8B-Instruct-Gradient-1048k,
 # seed_everything(42) + sparsify_attention_heads(sparsity=0.5)  (tests/golden/make_golden.py)
 LLAMA3_8B_FULL_KV_HEADS = [1, 1, 2, 2, 2, 4, 2, 4, 6, 4, 5, 3, 2, 6, 5, 5, 5, 6, 3, 5, 6, 3, 3, 6, 4, 5, 3, 4, 6, 5, 8, 2]
+# BASELINE configs[2] (Mistral-7B-Instruct-v0.2, "shipped attn_pattern"): SURVEY §8d asks for both readings of it —
+# the paper's 50 % sparsity (seed 42) and the raw TSV thresholded at 0.5 (244 of 256 heads stay retrieval heads)
+MISTRAL_7B_V02_FULL_KV_HEADS_50 = [3, 4, 6, 2, 4, 1, 3, 3, 2, 4, 2, 5, 6, 1, 4, 4, 5, 2, 7, 5, 6, 4, 3, 3, 4, 4, 5, 3, 4, 7, 5, 7]
+MISTRAL_7B_V02_FULL_KV_HEADS_RAW = [5, 7, 8, 5, 6, 6, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 7, 8, 8, 8, 8, 8, 8, 8, 8]
+PATTERNS = {
+    "llama3-8b-1048k@0.5": (LLAMA3_8B_FULL_KV_HEADS, "Llama-3-8B-Instruct-Gradient-1048k shape, 50% streaming kv heads"),
+    "mistral-7b-v0.2@0.5": (MISTRAL_7B_V02_FULL_KV_HEADS_50, "Mistral-7B-Instruct-v0.2 shape, shipped pattern at sparsity 0.5"),
+    "mistral-7b-v0.2@raw": (MISTRAL_7B_V02_FULL_KV_HEADS_RAW, "Mistral-7B-Instruct-v0.2 shape, shipped pattern thresholded at 0.5 (95% retrieval heads)"),
+}
 HQ, HKV, D, HIDDEN = 32, 8, 128, 4096
 SINK, RECENT = 128, 256
 ROPE_THETA, ROPE_SCALE = 3580165449.0, 1.0
@@ -325,7 +334,7 @@ def measure_traffic(args):
     out = tempfile.mkdtemp(prefix="duo_traffic_", dir="/tmp")
     cmd = [exe, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", out, "-o", "t", "--", sys.executable,
            os.path.abspath(__file__), "--traffic-probe", "--ctx", str(args.ctx), "--chunk", str(args.chunk),
-           "--layers", str(args.layers)]
+           "--layers", str(args.layers), "--pattern", args.pattern] + (["--no-int4"] if args.no_int4 else [])
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
@@ -337,12 +346,13 @@ def measure_traffic(args):
         cur = sqlite3.connect(dbs[0]).cursor()
         rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection "
                            "where counter_name = 'FETCH_SIZE' group by kernel_name").fetchall()
-        # the prefill attention of a launch runs on duo_prefill_w64_kernel (4 waves x 64 rows) or duo_prefill_kernel
-        # (8 waves x 32 rows: first chunk, split launches): one figure = launch-weighted mean over both
+        # one figure per kernel family = launch-weighted mean (prefill: duo_prefill_w64_kernel, every launch of this
+        # workload; duo_prefill_kernel, the 8-wave A/B kernel, would be counted with it)
         res, n, acc = {}, {}, {}
         for name, mean, cnt in rows:
-            key = "duo_prefill" if ("duo_prefill_w64_kernel" in name or "duo_prefill_kernel" in name) else (
-                "duo_decode_split_kernel" if "duo_decode_split_kernel" in name else None)
+            key = "duo_prefill" if (("duo_prefill_w64_kernel" in name or "duo_prefill_kernel" in name) and "f16" not in name) else (
+                "duo_decode_scan_kernel" if ("duo_decode_scan_kernel" in name or "duo_decode_split_kernel" in name) else (
+                    "duo_int4_decode_mfma_kernel" if "duo_int4_decode_mfma_kernel" in name else None))
             if key:
                 tot, c0 = acc.get(key, (0.0, 0))
                 acc[key] = (tot + float(mean) * cnt, c0 + cnt)
@@ -363,10 +373,13 @@ def traffic_probe(args, device):
     """child of measure_traffic: one prefill pass and a few decode steps, nothing timed"""
     from duo_attn.pipeline import LayerPipeline
 
-    counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
+    counts = PATTERNS[args.pattern][0][: args.layers]
     hp = HotPath(counts, (0, len(counts)), args.ctx, args.chunk, device)
     run_job(hp, LayerPipeline(len(counts), rank=0, world_size=1), 4, 1, device)
     torch.cuda.synchronize()
+    hp.free()
+    if not args.no_int4:
+        int4_leg(device, reps=2, parity=False, prefill=False)     # a few launches of the INT4 decode kernel for FETCH_SIZE
 
 
 def live_parity(device):
@@ -430,6 +443,183 @@ def live_parity(device):
     return res
 
 
+def _exact_rows(q_rows, K, V, vis, scale):
+    """exact-P fp32 softmax attention in plain torch: q_rows [n, g, D], K / V [T, D], row i sees keys [0, vis[i])"""
+    s_ = torch.einsum("ngd,td->ngt", q_rows.float(), K.float()) * scale
+    t = torch.arange(K.shape[0], device=K.device)
+    s_.masked_fill_(t[None, None, :] >= vis[:, None, None], float("-inf"))
+    return torch.einsum("ngt,td->ngd", torch.softmax(s_, -1), V.float())
+
+
+def int4_leg(device, ctx=1048576, reps=5, parity=True, prefill=True):
+    """BASELINE configs[4] (INT4 KV pools), driver-timed: (1) `duo_int4_decode_mfma_kernel` — the fused decode attention
+    of ONE layer (4 retrieval + 4 streaming kv heads) straight on the packed pools at a 1 M-token context: 136 B per
+    (token, kv head) instead of the reference's dequantise-everything + flash_attn_func (demo/int4_kv.py:373-436,
+    demo/w8a8kv4_llama.py:240-274), 570 MB per launch, HBM-bound; (2) one fp16 chunked-prefill launch (chunk 16384 at past
+    114688) over DEQUANTISED pools, which is how the reference prefills; (3) live parity of the decode kernel at 131072
+    context against exact fp32 attention over the pools dequantised in plain torch fp16 arithmetic (hmul then hadd)."""
+    from duo_attn import _hip
+
+    G, nf, ns, W = HQ // HKV, 4, 4, SINK + RECENT
+    g = torch.Generator(device=device).manual_seed(11)
+    scale = D ** -0.5
+
+    def pools(h, T):
+        q_ = torch.randint(0, 256, (h, T, 64), generator=g, device=device, dtype=torch.uint8).permute(1, 0, 2)
+        sz = (torch.rand(h, T, 2, generator=g, device=device) * 0.3 + 0.01).to(torch.float16).permute(1, 0, 2)
+        return q_, sz
+
+    res = {}
+    # ---- (1) decode at `ctx`
+    fkq, fksz = pools(nf, ctx + 1)
+    fvq, fvsz = pools(nf, ctx + 1)
+    skq, sksz = pools(ns, W + 1)
+    svq, svsz = pools(ns, W + 1)
+    full = _hip.make_int4_pool(fkq, fksz, fvq, fvsz, ctx + 1, 0)
+    stream = _hip.make_int4_pool(skq, sksz, svq, svsz, W + 1, nf * G)
+    q = torch.randn(HQ, D, generator=g, device=device).to(torch.float16)
+    out = torch.empty_like(q)
+    rows = nf * (ctx + 1) + ns * (W + 1)
+    nbytes = rows * 2 * 68
+
+    def timed(flags):
+        _hip.set_debug_flags(flags)
+        try:
+            evs = []
+            for i in range(reps + 2):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                _hip.attn_decode_int4(q, out, G, full, stream, scale)
+                b.record()
+                if i >= 2:
+                    evs.append((a, b))
+            torch.cuda.synchronize()
+        finally:
+            _hip.set_debug_flags(0)
+        return sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+
+    t_kernel = timed(2)        # debug bit 1: no merge launch -> the events bracket the split kernel alone
+    t_op = timed(0)            # split + merge: the whole attention of the step
+    res["decode"] = {"context": ctx, "algorithmic_bytes_per_launch": float(nbytes), "rows": rows,
+                     "kernel_ms": t_kernel * 1e3, "op_ms": t_op * 1e3,
+                     "kernel_GBps": nbytes / t_kernel / 1e9, "op_GBps": nbytes / t_op / 1e9,
+                     "rows_per_us": rows / t_op / 1e6,
+                     "bf16_equivalent_GBps": rows * 512 / t_op / 1e9}
+    del fkq, fksz, fvq, fvsz, full
+    torch.cuda.empty_cache()
+    if prefill:
+        # ---- (2) fp16 prefill over dequantised pools: quantise real rows, dequantise them (as the reference's get()), attend
+        from duo_attn.backend import get_backend
+
+        be = get_backend()
+        S, past = 16384, 131072 - 16384
+        mk = lambda h, T: torch.randn(h, T, D, generator=g, device=device, dtype=torch.float32).to(torch.float16).permute(1, 0, 2)
+        kq, ksz = pools(nf, past + S)
+        vq, vsz = pools(nf, past + S)
+        _hip.int4_quantize(mk(nf, past + S), kq, ksz, 0)
+        _hip.int4_quantize(mk(nf, past + S), vq, vsz, 0)
+        fk = _hip.int4_dequantize(kq, ksz, past + S, torch.empty((past + S) * nf * D, dtype=torch.float16, device=device))
+        fv = _hip.int4_dequantize(vq, vsz, past + S, torch.empty((past + S) * nf * D, dtype=torch.float16, device=device))
+        sk, sv = mk(ns, W + S).contiguous(), mk(ns, W + S).contiguous()      # streaming class: pool (W rows) ++ chunk
+        qc = torch.randn(S, HQ, D, generator=g, device=device).to(torch.float16)
+        oc = torch.empty_like(qc)
+        cls_full = (nf, 0, (fk[:past], fv[:past]), (fk[past:], fv[past:]))
+        cls_str = (ns, nf * G, (sk[:W], sv[:W]), (sk[W:], sv[W:]))
+        evs = []
+        for i in range(4):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            be.attention(qc, oc, G, cls_full, cls_str, scale)
+            b.record()
+            if i >= 1:
+                evs.append((a, b))
+        torch.cuda.synchronize()
+        t_pre = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+        tri = S * (S + 1) / 2
+        flops = 4 * D * G * (nf * (S * past + tri) + ns * (S * W + tri))
+        res["prefill_f16_over_dequantised_pools"] = {
+            "kernel": "duo_prefill_w64_f16_kernel", "chunk": S, "past": past, "launch_ms": t_pre * 1e3,
+            "TFLOPs": flops / t_pre / 1e12, "frac_of_2.5PF": flops / t_pre / MFMA_BF16_PEAK}
+        if parity:
+            # ---- (3) decode over the SAME quantised rows at 131072 context vs exact attention over torch-dequantised values
+            N = past + S
+            skq2, sksz2 = pools(ns, W)
+            svq2, svsz2 = pools(ns, W)
+            _hip.int4_quantize(mk(ns, W), skq2, sksz2, 0)
+            _hip.int4_quantize(mk(ns, W), svq2, svsz2, 0)
+            q1 = torch.randn(HQ, D, generator=g, device=device).to(torch.float16)
+            o1 = torch.empty_like(q1)
+            _hip.attn_decode_int4(q1, o1, G, _hip.make_int4_pool(kq, ksz, vq, vsz, N, 0),
+                                  _hip.make_int4_pool(skq2, sksz2, svq2, svsz2, W, nf * G), scale)
+
+            def deq(qp, szp):      # [T, h, 64] u8, [T, h, 2] f16 -> [T, h, 128] f16: hi nibble first, hmul then hadd in fp16
+                codes = torch.stack([qp >> 4, qp & 15], -1).flatten(-2).to(torch.float16)
+                return (codes * szp[..., 0:1]) + szp[..., 1:2]
+
+            ref = torch.empty(1, HQ, D, device=device)
+            one = torch.ones(1, dtype=torch.long, device=device)
+            for h in range(nf):
+                ref[:, h * G:(h + 1) * G] = _exact_rows(q1[None, h * G:(h + 1) * G], deq(kq[:, h], ksz[:, h]),
+                                                        deq(vq[:, h], vsz[:, h]), one * N, scale)
+            for j in range(ns):
+                h = nf + j
+                ref[:, h * G:(h + 1) * G] = _exact_rows(q1[None, h * G:(h + 1) * G], deq(skq2[:, j], sksz2[:, j]),
+                                                        deq(svq2[:, j], svsz2[:, j]), one * W, scale)
+            e = o1[None].float() - ref
+            res["parity_decode_131072"] = {
+                "rms_err_over_rms_ref": float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()),
+                "max_abs_err": float(e.abs().max()), "rms_ref": float(ref.pow(2).mean().sqrt()),
+                "reference": "exact-P fp32 softmax attention in torch over the pools dequantised in torch fp16 (hmul, hadd); "
+                             "fp16 output rounding alone is 2^-11 / sqrt(3) = 2.8e-4 relative"}
+    return res
+
+
+def cpu_cfg1_end_to_end(n_layers):
+    """BASELINE configs[0] end to end on the host: a random-init Llama-2-7B-32K-shape HuggingFace model (MHA 32 heads,
+    linear RoPE factor 8), `enable_duo_attention_eval` (the reference's tuple-cache entry point) at 25 % retrieval heads,
+    the oracle as device backend, one 4096-token prompt + 4 decode steps, all on the CPU.  `n_layers` < 32 builds a
+    shallower model of the same width and scales the figure by 32 / n_layers (labelled)."""
+    import numpy as np
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from duo_attn import backend
+    from duo_attn.patch import enable_duo_attention_eval
+    from oracle.duo_oracle import OracleBackend
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=11008, num_hidden_layers=n_layers, num_attention_heads=32,
+                      num_key_value_heads=32, vocab_size=32000, max_position_embeddings=32768, rope_theta=10000.0,
+                      rope_scaling={"rope_type": "linear", "factor": 8.0}, attn_implementation="eager",
+                      tie_word_embeddings=False)
+    model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+    rng = np.random.RandomState(42)
+    heads = (rng.rand(n_layers, 32) < 0.25).astype(float)
+    enable_duo_attention_eval(model, heads, 128, 256)
+    backend._set_backend_for_testing(OracleBackend())
+    try:
+        ids = torch.randint(0, 32000, (1, 4096), generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            out = model(input_ids=ids, past_key_values=None, use_cache=True)
+            t_pre = time.perf_counter() - t0
+            past, tok = out.past_key_values, out.logits[:, -1:].argmax(-1)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                out = model(input_ids=tok, past_key_values=past, use_cache=True)
+                past, tok = out.past_key_values, out.logits[:, -1:].argmax(-1)
+            t_dec = (time.perf_counter() - t0) / 4
+    finally:
+        backend._set_backend_for_testing(None)
+    k = 32 / n_layers
+    return {"what": "Llama-2-7B-32K shape (random init, bf16) through enable_duo_attention_eval on the host, oracle backend, "
+                    f"25% retrieval heads, sink 128 recent 256: 4096-token prompt + 4 decode steps; {n_layers} of 32 layers"
+                    + ("" if n_layers == 32 else f" built and timed, x{k:g}"),
+            "cores": cores, "layers_timed": n_layers, "prefill_s": t_pre * k, "prefill_tok_s": 4096 / (t_pre * k),
+            "decode_ms_per_token": t_dec * k * 1e3}
+
+
 def model_level(args):
     """The reference's benchmark_static protocol on the whole random-init HF model of the same shape (GEMMs included):
     tools/benchmark_static.py, prefill 1 warm + 1 timed pass, decode through the captured HIP graph."""
@@ -464,6 +654,12 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 FETCH_SIZE child run")
     ap.add_argument("--no-model-level", action="store_true", help="skip the whole-HF-model run (tools/benchmark_static.py)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check")
+    ap.add_argument("--no-int4", action="store_true", help="skip the INT4-KV leg (BASELINE configs[4] kernels)")
+    ap.add_argument("--pattern", default="llama3-8b-1048k@0.5", choices=sorted(PATTERNS),
+                    help="per-layer retrieval-head counts of the job (default = BASELINE configs[1])")
+    ap.add_argument("--cpu-cfg1-layers", type=int, default=1,
+                    help="layers of the Llama-2-7B-shape model of the host end-to-end run (cpu_baseline.cfg1_end_to_end); "
+                         "32 = the whole model (minutes), 0 = skip")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -494,7 +690,7 @@ def main():
 
     from duo_attn.pipeline import LayerPipeline
 
-    counts = LLAMA3_8B_FULL_KV_HEADS[: args.layers]
+    counts = PATTERNS[args.pattern][0][: args.layers]
     L = len(counts)
     # stage boundaries: contiguous layers, split so that the most expensive stage is as cheap as possible
     # (per-layer cost = its algorithmic prefill FLOPs — the ragged retrieval-head counts make the
@@ -549,17 +745,23 @@ def main():
     if not args.no_kernel_roofline:
         pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
-        roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows, every launch of this workload; key-range-split launches of short chunks run duo_prefill_kernel, 8 x 32)",
+        roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows: every prefill launch, whole chunks, key-range-split launches and row blocks alike)",
                 "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
                 "unit": "TFLOP/s", "frac": tp / MFMA_BF16_PEAK,
                 "traffic": traffic.get("duo_prefill"), "traffic_source": traffic_source,
                 "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"],
                 "algorithmic_flops_per_launch": pre["flops"] / pre["launches"]}
-        roof_dec = {"kernel": "duo_decode_split_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
+        step_bytes = float(sum(decode_bytes(counts[lr[0]:lr[1]], args.ctx)))
+        t_tok = t_dec / args.decode_tokens
+        roof_dec = {"kernel": "duo_decode_scan_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": td / HBM_PEAK,
-                    "traffic": traffic.get("duo_decode_split_kernel"), "traffic_source": traffic_source,
+                    "traffic": traffic.get("duo_decode_scan_kernel"), "traffic_source": traffic_source,
                     "avg_launch_ms": dec["seconds"] / dec["launches"] * 1e3, "launches": dec["launches"],
-                    "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"]}
+                    "algorithmic_bytes_per_launch": dec["bytes"] / dec["launches"],
+                    # the whole decode step of the timed job (per layer: scan with RoPE + append folded in, then the merge launch)
+                    "whole_step": {"algorithmic_bytes_per_token": step_bytes, "ms_per_token": t_tok * 1e3,
+                                   "achieved": step_bytes / t_tok / 1e9, "frac": step_bytes / t_tok / HBM_PEAK,
+                                   "launches_per_token": 2 * (lr[1] - lr[0])}}
     def all_ranks_sum(x):
         t = torch.tensor([float(x)], device=handoff, dtype=torch.float64)
         if world > 1:
@@ -589,6 +791,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(counts, args.ctx, args.chunk, args.decode_tokens)
     parity = live_parity(device) if (world == 1 and not args.no_parity) else None
+    int4 = None
+    if world == 1 and not args.no_int4:
+        try:
+            int4 = int4_leg(device)
+            d = int4["decode"]
+            int4["roofline"] = {"kernel": "duo_int4_decode_mfma_kernel", "bound": "hbm", "achieved": d["kernel_GBps"],
+                                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": d["kernel_GBps"] * 1e9 / HBM_PEAK,
+                                "traffic": traffic.get("duo_int4_decode_mfma_kernel"), "traffic_source": traffic_source,
+                                "avg_launch_ms": d["kernel_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"]}
+        except Exception as e:      # extra information: never at the price of the bench line
+            int4 = {"error": f"{type(e).__name__}: {e}"}
+    if cpu is not None and args.cpu_cfg1_layers > 0:
+        try:
+            cpu["cfg1_end_to_end"] = cpu_cfg1_end_to_end(args.cpu_cfg1_layers)
+        except Exception as e:
+            cpu["cfg1_end_to_end"] = {"error": f"{type(e).__name__}: {e}"}
     mlevel = None
     if world == 1 and not args.no_model_level and (args.ctx, L) == (131072, 32):
         try:
@@ -618,9 +836,11 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": (f"Llama-3-8B-Instruct-Gradient-1048k shape, attention hot path only (op level): "
+                "workload": (f"{PATTERNS[args.pattern][1]}, attention hot path only (op level): "
                              f"{args.ctx}-token chunked prefill (chunk {args.chunk}) + {args.decode_tokens} decode "
-                             f"steps at {args.ctx} ctx, {L} layers, 50% streaming kv heads, sink {SINK} recent {RECENT}, B=1"),
+                             f"steps at {args.ctx} ctx, {L} layers ({sum(counts)} of {HKV * L} kv heads retrieval heads), "
+                             f"sink {SINK} recent {RECENT}, B=1"),
+                "pattern": args.pattern,
                 "global_batch": 1,
                 "seq_len": args.ctx,
                 "prefill_chunk": args.chunk,
@@ -644,9 +864,11 @@ def main():
             "duo_job_spread": {"prefill_tok_s_min_max": [args.ctx / max(j[0] for j in duo_jobs), args.ctx / min(j[0] for j in duo_jobs)],
                                "decode_tok_s_min_max": [args.decode_tokens / max(j[1] for j in duo_jobs),
                                                         args.decode_tokens / min(j[1] for j in duo_jobs)]},
-            "decode_note": ("decode speed-up ceiling = K/V byte ratio 1.994x at exactly 50 % streaming heads "
-                            "(8.615 vs 17.18 GB/token); whole step = scan + epilogue launch per layer"),
+            "decode_note": ("decode speed-up ceiling = K/V byte ratio (1.994x at exactly 50 % streaming heads: 8.615 vs "
+                            "17.18 GB/token at 131072 ctx); whole step = scan + merge launch per layer, its HBM fraction is "
+                            "roofline_decode.whole_step"),
             "parity_live": parity,
+            "roofline_int4": int4,
             "model_level": mlevel,
             "pipeline": None if world == 1 else {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),

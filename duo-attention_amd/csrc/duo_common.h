@@ -56,6 +56,7 @@ struct DuoSegDev {
     int64_t token_stride;
     int64_t head_stride;
     int32_t len;
+    int64_t batch_stride;
 };
 struct DuoClassDev {
     int32_t n_kv_heads;
@@ -74,6 +75,7 @@ __device__ __forceinline__ DuoSegDev duo_select(const DuoSegDev &a, const DuoSeg
     r.token_stride = pick_b ? b.token_stride : a.token_stride;
     r.head_stride = pick_b ? b.head_stride : a.head_stride;
     r.len = pick_b ? b.len : a.len;
+    r.batch_stride = pick_b ? b.batch_stride : a.batch_stride;
     return r;
 }
 __device__ __forceinline__ DuoClassDev duo_select(const DuoClassDev &a, const DuoClassDev &b, bool pick_b) {
@@ -85,6 +87,14 @@ __device__ __forceinline__ DuoClassDev duo_select(const DuoClassDev &a, const Du
     return r;
 }
 
+// batched launches: the batch row is a grid dimension; a row's view of a class = the descriptor moved by its strides
+__device__ __forceinline__ void duo_class_batch_row(DuoClassDev &C, int row) {
+    C.a.k += (int64_t)row * C.a.batch_stride;
+    C.a.v += (int64_t)row * C.a.batch_stride;
+    C.b.k += (int64_t)row * C.b.batch_stride;
+    C.b.v += (int64_t)row * C.b.batch_stride;
+}
+
 static inline DuoSegDev duo_seg_dev(const duo_kv_seg &s) {
     DuoSegDev d;
     d.k = (const bf16_t *)s.k;
@@ -92,6 +102,7 @@ static inline DuoSegDev duo_seg_dev(const duo_kv_seg &s) {
     d.token_stride = s.token_stride;
     d.head_stride = s.head_stride;
     d.len = s.len;
+    d.batch_stride = s.batch_stride;
     return d;
 }
 static inline DuoClassDev duo_class_dev(const duo_head_class *c) {
@@ -99,8 +110,8 @@ static inline DuoClassDev duo_class_dev(const duo_head_class *c) {
     if (c == nullptr) {
         d.n_kv_heads = 0;
         d.q_head_offset = 0;
-        d.a = DuoSegDev{nullptr, nullptr, 0, 0, 0};
-        d.b = DuoSegDev{nullptr, nullptr, 0, 0, 0};
+        d.a = DuoSegDev{nullptr, nullptr, 0, 0, 0, 0};
+        d.b = DuoSegDev{nullptr, nullptr, 0, 0, 0, 0};
         return d;
     }
     d.n_kv_heads = c->n_kv_heads;

@@ -65,6 +65,11 @@ struct DecodeParams {
     int32_t one_launch;
     int32_t *tickets;
     uint32_t ws_bytes;       // bytes of the partial workspace behind ws_ml (buffer-descriptor bound)
+    int32_t odd_dw;          // duo_decode_scan_kernel: 64ths of a share that odd-XCD workgroups give up (0 = even deal)
+    // ---- batched launch: grid.z = batch row (all rows at the same lengths / position).  q / out rows are q_bs / out_bs
+    //      elements apart, the segments carry their own batch strides, every row has its own partial area
+    int64_t q_bs, out_bs, app_bs;
+    int64_t ws_row_floats;
 };
 
 constexpr int kTicketWords = DUO_DECODE_TICKET_BYTES / 4;
@@ -188,6 +193,7 @@ struct MergeParams {
     int32_t max_splits;
     // q-head ranges [begin,end) with their split counts; ranges with <=1 split are skipped
     int32_t qh_begin[2], qh_end[2], splits[2];
+    int64_t ws_row_floats, out_bs;     // batched launch (grid.y = batch row)
 };
 
 // Four workgroups (256 threads) per q head, one per 32-dim quarter: 32 split lanes x 8 dim quads, so the
@@ -280,7 +286,7 @@ __device__ __forceinline__ void duo_decode_merge_task(const float *ws_ml, const 
 }
 
 // block of the stand-alone epilogue launch -> (q head, 32-dim quarter)
-__device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk) {
+__device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int blk, int row) {
     int qh = blk >> 2;
     int splits;
     const int n0 = P.splits[0] > 1 ? P.qh_end[0] - P.qh_begin[0] : 0;
@@ -291,7 +297,8 @@ __device__ __forceinline__ void duo_decode_merge_block(const MergeParams &P, int
         qh = qh - n0 + P.qh_begin[1];
         splits = P.splits[1];
     }
-    duo_decode_merge_task<false>(P.ws_ml, P.ws_acc, 0, P.out, P.out_head_stride, P.max_splits, qh, blk & 3, splits);
+    duo_decode_merge_task<false>(P.ws_ml + (int64_t)row * P.ws_row_floats, P.ws_acc + (int64_t)row * P.ws_row_floats, 0,
+                                 P.out + (int64_t)row * P.out_bs, P.out_head_stride, P.max_splits, qh, blk & 3, splits);
 }
 
 
@@ -329,6 +336,10 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
     DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    const int bz = blockIdx.z;      // batch row
+    duo_class_batch_row(C, bz);
+    bf16_t *const out_row = P.out + (int64_t)bz * P.out_bs;
+    float *const ws_ml_row = P.ws_ml + (int64_t)bz * P.ws_row_floats, *const ws_acc_row = P.ws_acc + (int64_t)bz * P.ws_row_floats;
     int app_row = P.app_row;
     float pos = P.pos;
     if constexpr (FUSED) {
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
     float qf[GT][8];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-        const bf16_t *qrow = P.q + (int64_t)(qh0 + g) * P.q_head_stride;
+        const bf16_t *qrow = P.q + (int64_t)bz * P.q_bs + (int64_t)(qh0 + g) * P.q_head_stride;
         const u32x4 w = *reinterpret_cast<const u32x4 *>(qrow + sub * 8);
         if constexpr (FUSED) {
             const u32x4 wp = *reinterpret_cast<const u32x4 *>(qrow + (sub ^ 8) * 8);
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
             // retrieval heads: the rotated key and the value join the pool (row app_row is outside
             // every scan range of this launch)
             if (ci == 0 && blockIdx.y == 0) {
-                const int64_t po = (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
+                const int64_t po = (int64_t)bz * P.app_bs + (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
                 *reinterpret_cast<u32x4 *>(P.app_k + po) = kr;
                 *reinterpret_cast<u32x4 *>(P.app_v + po) = vw;
             }
@@ -595,6 +606,15 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
     if constexpr (FUSED) {
         if (have_state) a_len = ci ? st_str : st_full;
     }
+    const int bz = blockIdx.z;      // batch row (batched launches): row 0 needs nothing from the parameter block here
+    if (bz) {
+        asm volatile("" ::: "memory");
+        q += (int64_t)bz * P.q_bs;
+        ak += (int64_t)bz * (ci ? P.cls[1].a.batch_stride : P.cls[0].a.batch_stride);
+        av += (int64_t)bz * (ci ? P.cls[1].a.batch_stride : P.cls[0].a.batch_stride);
+    }
+    bf16_t *const out_row = P.out + (int64_t)bz * P.out_bs;
+    float *const ws_ml_row = P.ws_ml + (int64_t)bz * P.ws_row_floats, *const ws_acc_row = P.ws_acc + (int64_t)bz * P.ws_row_floats;
     const int kvh = b / splits;
     const int split = b - kvh * splits;
     const int qh0 = qoff + kvh * group + blockIdx.y * GT;
@@ -602,11 +622,25 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
     // balanced static partition (as duo_decode_split_kernel): the head's 64-token units dealt evenly to the splits
     const int L = FUSED ? a_len : a_len + b_len;
     const int units = (L + 63) >> 6;
-    const int uq = units / splits, ur = units - uq * splits;
-    const int u0 = split * uq + min(split, ur);
-    const int un = uq + (split < ur ? 1 : 0);
+    int u0, u1;
+    if (P.odd_dw > 0 && splits > 1 && gridDim.y == 1) {
+        // XCD-weighted deal (experiment, profiles/r3_decode.md): a workgroup on an odd XCD (block id odd: XCD = id % 8)
+        // takes (64 - odd_dw) / 64 of an even one's share.  Same closed form in every workgroup of the head, so the
+        // ranges tile the head exactly; the results stay a fixed function of the launch shape.
+        const int bfirst = (int)blockIdx.x - split;                  // block id of this head's split 0
+        const int wt0 = (bfirst & 1) ? 64 - P.odd_dw : 64;
+        const int pair = 128 - P.odd_dw;
+        auto cum = [&](int s_) { return (s_ >> 1) * pair + ((s_ & 1) ? wt0 : 0); };
+        const float per = (float)units / (float)cum(splits);
+        u0 = split == 0 ? 0 : (int)((float)cum(split) * per);
+        u1 = split + 1 == splits ? units : (int)((float)cum(split + 1) * per);
+    } else {
+        const int uq = units / splits, ur = units - uq * splits;
+        u0 = split * uq + min(split, ur);
+        u1 = u0 + uq + (split < ur ? 1 : 0);
+    }
     const int c0 = u0 << 6;
-    const int c1 = min((u0 + un) << 6, L);
+    const int c1 = min(u1 << 6, L);
     const int per_wave = (((c1 - c0 + 3) >> 2) + 15) & ~15;  // quarter of the chunk, multiple of 16
     const int w0 = __builtin_amdgcn_readfirstlane(c0 + wave * per_wave);
     const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
@@ -639,13 +673,12 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
     //     row 0: an empty segment A is given the base of segment B by the launcher), so the eight loads are
     //     unconditional.  When the wave has a full first group (nfast > 0) no lane is clamped and the registers hold
     //     exactly what load_fast(t_first) would have fetched.
-    // The wave's full groups are visited in ROTATED order (attention does not care, the order is a fixed function of the
-    // block id, so results stay reproducible): all 256 workgroups otherwise walk their equally long, equally aligned
-    // chunks in lockstep — at every instant the whole chip reads the same offset of 256 chunks (debug bit 11: no rotation).
+    // (Visiting the wave's groups in a per-workgroup ROTATED order — so that the 256 workgroups do not walk their equally
+    // long chunks in lockstep — was built and measured: 1.595-1.599 vs 1.582-1.584 ms per token, i.e. slower; the plain
+    // ascending order stays.  profiles/r3_decode.md)
     const int fast_end = min(w1, a_len);
     const int nfast = fast_end > w0 ? (fast_end - w0) / kTokPerIter : 0;
-    const int rot = (nfast > 1 && !(P.dbg & 2048u)) ? (int)((blockIdx.x * 13u + (uint32_t)wave * 8u) % (uint32_t)nfast) : 0;
-    const int t_first = __builtin_amdgcn_readfirstlane(w0 + rot * kTokPerIter);
+    const int t_first = w0;
     u32x4 k0r[4], v0r[4], k1r[4], v1r[4];
     {
         const int last = max(a_len - 1, 0);
@@ -661,7 +694,9 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
     DUO_DT(4);
 
     // ================= everything below runs underneath those loads ================================================
-    const DuoSegDev Bseg = duo_select(P.cls[0].b, P.cls[1].b, ci != 0);
+    DuoSegDev Bseg = duo_select(P.cls[0].b, P.cls[1].b, ci != 0);
+    Bseg.k += (int64_t)bz * Bseg.batch_stride;
+    Bseg.v += (int64_t)bz * Bseg.batch_stride;
     if constexpr (FUSED) {
         if (!have_state) {
             app_row = P.app_row;
@@ -739,28 +774,18 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
     };
     int t_rest = w0;
     if (nfast > 0) {
-        // nfast groups starting at t_first, wrapping from the last one back to w0; the load behind the last group
-        // re-reads it (never consumed), as before
         const int t_last = w0 + (nfast - 1) * kTokPerIter;
-        int t = t_first;
-        for (int i = 0;; i += 2) {
-            int t1 = t + kTokPerIter;
-            t1 = t1 > t_last ? w0 : t1;
-            t1 = i + 1 < nfast ? t1 : t;
-            load_fast(t1, k1r, v1r);
+        for (int t = w0;; t += 2 * kTokPerIter) {
+            load_fast(min(t + kTokPerIter, t_last), k1r, v1r);      // (behind the last group: re-reads it, never consumed)
             __builtin_amdgcn_sched_barrier(0);
             if (P.dbg & 64u) l[0] += __uint_as_float((k0r[0].x ^ k0r[1].y ^ k0r[2].z ^ k0r[3].w ^ v0r[0].x ^ v0r[1].y ^ v0r[2].z ^ v0r[3].w) & 1u);
             else consume_rows<GT, true>(k0r, v0r, t, tg, w1, qf, m, l, acc);
-            if (i + 1 >= nfast) break;
-            int t2 = t1 + kTokPerIter;
-            t2 = t2 > t_last ? w0 : t2;
-            t2 = i + 2 < nfast ? t2 : t1;
-            load_fast(t2, k0r, v0r);
+            if (t >= t_last) break;
+            load_fast(min(t + 2 * kTokPerIter, t_last), k0r, v0r);
             __builtin_amdgcn_sched_barrier(0);
             if (P.dbg & 64u) l[0] += __uint_as_float((k1r[0].x ^ k1r[1].y ^ k1r[2].z ^ k1r[3].w ^ v1r[0].x ^ v1r[1].y ^ v1r[2].z ^ v1r[3].w) & 1u);
-            else consume_rows<GT, true>(k1r, v1r, t1, tg, w1, qf, m, l, acc);
-            if (i + 2 >= nfast) break;
-            t = t2;
+            else consume_rows<GT, true>(k1r, v1r, t + kTokPerIter, tg, w1, qf, m, l, acc);
+            if (t + kTokPerIter >= t_last) break;
         }
         t_rest = w0 + nfast * kTokPerIter;
     }
@@ -806,7 +831,7 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
             // retrieval heads: the rotated key and the value join the pool (row app_row is outside every scan range
             // of this launch)
             if (ci == 0 && blockIdx.y == 0) {
-                const int64_t po = (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
+                const int64_t po = (int64_t)bz * P.app_bs + (int64_t)app_row * P.app_ts + (int64_t)kvh * P.app_hs + sub * 8;
                 *reinterpret_cast<u32x4 *>(P.app_k + po) = kr;
                 *reinterpret_cast<u32x4 *>(P.app_v + po) = nvw;
             }
@@ -820,8 +845,8 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
 // (head, K|V) each (absent when the caller updates the pool separately).
 __global__ __launch_bounds__(256) void duo_decode_post_kernel(const MergeParams M, int n_merge,
                                                              const CompressParams C) {
-    if ((int)blockIdx.x < n_merge) duo_decode_merge_block(M, blockIdx.x);
-    else duo_stream_compress_block(C, blockIdx.x - n_merge);
+    if ((int)blockIdx.x < n_merge) duo_decode_merge_block(M, blockIdx.x, blockIdx.y);
+    else duo_stream_compress_block(C, blockIdx.x - n_merge, blockIdx.y);
 }
 
 }  // namespace
@@ -866,14 +891,22 @@ struct DecodePlan {
     int n_merge;
     int nblk;
     int gt;
+    int n_batch;
 };
 }  // namespace
 
 // validates the two head classes, sizes the splits and fills the kernel parameter blocks
 static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
                        int32_t group, const duo_head_class *full, const duo_head_class *stream_cls,
-                       float scale, void *workspace, int64_t workspace_bytes, DecodePlan &D) {
+                       float scale, void *workspace, int64_t workspace_bytes, DecodePlan &D,
+                       int32_t n_batch = 1, int64_t q_batch_stride = 0, int64_t out_batch_stride = 0) {
     DecodeParams &P = D.P;
+    if (n_batch < 1 || n_batch > 65535 || (n_batch > 1 && ((q_batch_stride & 7) || (out_batch_stride & 3)))) return DUO_EINVAL;
+    D.n_batch = n_batch;
+    P.q_bs = q_batch_stride;
+    P.out_bs = out_batch_stride;
+    P.app_bs = 0;
+    P.ws_row_floats = 0;
     P.q = (const bf16_t *)q;
     P.q_head_stride = q_head_stride;
     P.out = (bf16_t *)out;
@@ -882,6 +915,8 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.cls[1] = duo_class_dev(stream_cls);
     P.group = group;
     P.dbg = duo_get_debug_flags();
+    static const int odd_dw = [] { const char *e = getenv("DUO_DECODE_ODD_XCD_DW"); const int x = e ? atoi(e) : 0; return x > 0 && x < 32 ? x : 0; }();
+    P.odd_dw = odd_dw;
     P.fused = 0;
     P.one_launch = 0;
     P.tickets = nullptr;
@@ -901,10 +936,10 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
         if (C.b.len == 0) { P.cls[c].b = P.cls[c].a; P.cls[c].b.len = 0; }
     }
     // workspace capacity -> max splits per head
-    const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
+    const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float) * n_batch;   // every batch row has its own partials
     const int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
     {
-        const int target = decode_target_wgs();
+        const int target = std::max(1, decode_target_wgs() / n_batch);     // one resident round over all rows
         const int ms = max_splits > 0 ? max_splits : 1;
         const int Ls = P.cls[1].a.len + P.cls[1].b.len, Lf = P.cls[0].a.len + P.cls[0].b.len;
         // the streaming class is a few hundred rows per head: one workgroup each unless it is alone
@@ -923,8 +958,11 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
     D.nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
     D.gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
+    P.ws_row_floats = (int64_t)n_q_heads * P.max_splits * (DUO_HEAD_DIM + 2);
 
     MergeParams &M = D.M;
+    M.ws_row_floats = P.ws_row_floats;
+    M.out_bs = out_batch_stride;
     M.ws_ml = P.ws_ml;
     M.ws_acc = P.ws_acc;
     M.out = P.out;
@@ -958,7 +996,7 @@ template <bool FUSED>
 static int decode_launch_split(const DecodePlan &D, const CompressParams &CP, hipStream_t st) {
     if (D.nblk <= 0) return 0;
     const DecodeParams &P = D.P;
-    dim3 grid(D.nblk, P.group / D.gt), block(256);
+    dim3 grid(D.nblk, P.group / D.gt, D.n_batch), block(256);
     const uint32_t fl = duo_get_debug_flags();
     const bool nt = !(fl & 4u);        // debug bit 2: plain (temporal) K/V loads
     const bool pf = !(fl & 8u);        // debug bit 3: no register prefetch of the next 16 tokens
@@ -1000,16 +1038,38 @@ static int decode_launch_split(const DecodePlan &D, const CompressParams &CP, hi
     return 0;
 }
 
+static int attn_decode_impl(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                            int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch, int32_t group,
+                            const duo_head_class *full, const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                            void *workspace, int64_t workspace_bytes, void *stream);
 extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *out,
                                     int64_t out_head_stride, int32_t group,
                                     const duo_head_class *full, const duo_head_class *stream_cls,
                                     float scale, int32_t head_dim, void *workspace,
                                     int64_t workspace_bytes, void *stream) {
+    return attn_decode_impl(q, 0, q_head_stride, out, 0, out_head_stride, 1, group, full, stream_cls, scale, head_dim,
+                            workspace, workspace_bytes, stream);
+}
+// batched: q / out [B, n_q_heads, 128]; the segments of `full` / `stream_cls` carry their batch strides; every row at
+// the same lengths (the reference's pools and counters, static_kv_cache.py:44-45,60-99); grid.z = batch row
+extern "C" int duo_attn_decode_batched_bf16(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                                            int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch,
+                                            int32_t group, const duo_head_class *full, const duo_head_class *stream_cls,
+                                            float scale, int32_t head_dim, void *workspace, int64_t workspace_bytes,
+                                            void *stream) {
+    if (n_batch <= 0) return n_batch == 0 ? 0 : DUO_EINVAL;
+    return attn_decode_impl(q, q_batch_stride, q_head_stride, out, out_batch_stride, out_head_stride, n_batch, group, full,
+                            stream_cls, scale, head_dim, workspace, workspace_bytes, stream);
+}
+static int attn_decode_impl(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                            int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch, int32_t group,
+                            const duo_head_class *full, const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                            void *workspace, int64_t workspace_bytes, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (q == nullptr || out == nullptr || group <= 0) return DUO_EINVAL;
     DecodePlan D;
     int rc = decode_plan(q, q_head_stride, out, out_head_stride, group, full, stream_cls, scale, workspace,
-                         workspace_bytes, D);
+                         workspace_bytes, D, n_batch, q_batch_stride, out_batch_stride);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     rc = decode_launch_split<false>(D, CompressParams{}, st);
@@ -1017,7 +1077,7 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
     // debug flag bit 1: leave the partials unmerged (profiling the split kernel alone)
     if (D.n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
         CompressParams none{};
-        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge), dim3(256), 0, st, D.M, 4 * D.n_merge, none);
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge, D.n_batch), dim3(256), 0, st, D.M, 4 * D.n_merge, none);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -1027,9 +1087,37 @@ extern "C" int duo_attn_decode_bf16(const void *q, int64_t q_head_stride, void *
 // both head classes with RoPE of q / the new key row and the retrieval-pool append folded in, then
 // merge + streaming-pool update.  See include/duo_attn_hip.h.
 static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream_len, const int32_t *dev_state,
-                             void *workspace, int64_t workspace_bytes, void *tickets, void *stream) {
+                             void *workspace, int64_t workspace_bytes, void *tickets, void *stream,
+                             const duo_decode_batch *B = nullptr) {
     if (!a) return DUO_EINVAL;
     if (a->head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    const int n_batch = B ? B->n_batch : 1;
+    if (n_batch < 1) return n_batch == 0 ? 0 : DUO_EINVAL;
+    if (B && n_batch > 1) {
+        if (((B->q_batch_stride | B->kv_batch_stride | B->out_batch_stride | B->full_batch_stride | B->str_batch_stride) & 7) != 0)
+            return DUO_EINVAL;
+        bool same = true;
+        for (int b = 0; B->pos && b < n_batch; ++b) same = same && B->pos[b] == B->pos[0];
+        if (!same) {
+            // rows at different positions (left-padded batches): one launch pair per row — the lengths, and with them
+            // the partition, are still common
+            for (int b = 0; b < n_batch; ++b) {
+                duo_decode_layer_args r = *a;
+                r.q = (bf16_t *)a->q + b * B->q_batch_stride;
+                r.k = (bf16_t *)a->k + b * B->kv_batch_stride;
+                r.v = (const bf16_t *)a->v + b * B->kv_batch_stride;
+                r.out = (bf16_t *)a->out + b * B->out_batch_stride;
+                if (a->full_k) { r.full_k = (bf16_t *)a->full_k + b * B->full_batch_stride; r.full_v = (bf16_t *)a->full_v + b * B->full_batch_stride; }
+                if (a->str_k) { r.str_k = (bf16_t *)a->str_k + b * B->str_batch_stride; r.str_v = (bf16_t *)a->str_v + b * B->str_batch_stride; }
+                r.pos = B->pos[b];
+                const int rc = decode_layer_impl(&r, new_stream_len, dev_state, workspace, workspace_bytes, nullptr, stream);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
+    const int64_t pos_all = (B && B->pos) ? B->pos[0] : a->pos;
+    const bool batched = n_batch > 1;
     const int nf = a->n_full, nkv = a->n_kv_heads, ns = nkv - nf;
     if (!a->q || !a->k || !a->v || !a->out || nkv <= 0 || nf < 0 || ns < 0 || a->n_q_heads % nkv != 0)
         return DUO_EINVAL;
@@ -1056,9 +1144,15 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
     sc.segA = duo_kv_seg{a->str_k, a->str_v, a->str_token_stride, a->str_head_stride, a->str_len, 0};
     sc.segB = duo_kv_seg{kn + (int64_t)nf * a->kv_head_stride, vn + (int64_t)nf * a->kv_head_stride, 0,
                          a->kv_head_stride, 1, 0};
+    if (batched) {
+        fc.segA.batch_stride = B->full_batch_stride;
+        sc.segA.batch_stride = B->str_batch_stride;
+        fc.segB.batch_stride = sc.segB.batch_stride = B->kv_batch_stride;
+    }
     DecodePlan D;
     int rc = decode_plan(a->q, a->q_head_stride, a->out, a->out_head_stride, group, nf ? &fc : nullptr,
-                         ns ? &sc : nullptr, a->scale, workspace, workspace_bytes, D);
+                         ns ? &sc : nullptr, a->scale, workspace, workspace_bytes, D, n_batch,
+                         batched ? B->q_batch_stride : 0, batched ? B->out_batch_stride : 0);
     if (rc) return rc;
     float inv_freq[64];
     for (int i = 0; i < 64; ++i)
@@ -1069,7 +1163,8 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
     D.P.app_v = (bf16_t *)a->full_v;
     D.P.app_ts = a->full_token_stride;
     D.P.app_hs = a->full_head_stride;
-    D.P.pos = (float)a->pos;
+    D.P.app_bs = batched ? B->full_batch_stride : 0;
+    D.P.pos = (float)pos_all;
     D.P.dev_state = dev_state;
     memcpy(D.P.inv_freq, inv_freq, sizeof(inv_freq));
     // ---- streaming-pool update parameters (launch 2, or folded into launch 1) -----------------------
@@ -1083,13 +1178,15 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
         C = CompressParams{(bf16_t *)a->str_k, (bf16_t *)a->str_v, a->str_token_stride, a->str_head_stride,
                            (const bf16_t *)a->k + (int64_t)nf * a->kv_head_stride,
                            (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride,
-                           ns, a->str_len, 1, a->sink, a->recent, 1, (float)a->pos, {}, dev_state};
+                           ns, a->str_len, 1, a->sink, a->recent, 1, (float)pos_all, {}, dev_state};
         memcpy(C.inv_freq, inv_freq, sizeof(inv_freq));
+        C.p_bs = batched ? B->str_batch_stride : 0;
+        C.n_bs = batched ? B->kv_batch_stride : 0;
         n_compress = 2 * ns;
     }
     // Single launch (duo_decode_step_bf16): the kernel merges and updates the streaming pool itself.  Needs one
     // workgroup row per kv head (group == GT), the ticket area, and room for every head's two counters.
-    const bool one = tickets != nullptr && group == D.gt && 2 * nkv < kTicketWords - 1 && !(duo_get_debug_flags() & 2u);
+    const bool one = tickets != nullptr && !batched && group == D.gt && 2 * nkv < kTicketWords - 1 && !(duo_get_debug_flags() & 2u);
     if (one) {
         D.P.one_launch = 1;
         D.P.tickets = (int32_t *)tickets;
@@ -1107,7 +1204,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
 
     // ---- launch 2: merge (+ streaming-pool update when it was not folded) ----------------------------
     if (D.n_merge + n_compress > 0) {
-        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge + n_compress), dim3(256), 0, st, D.M, 4 * D.n_merge, C);
+        hipLaunchKernelGGL(duo_decode_post_kernel, dim3(4 * D.n_merge + n_compress, n_batch), dim3(256), 0, st, D.M, 4 * D.n_merge, C);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -1116,6 +1213,16 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
 extern "C" int duo_decode_layer_bf16(const duo_decode_layer_args *a, int32_t *new_stream_len,
                                      void *workspace, int64_t workspace_bytes, void *stream) {
     return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, nullptr, stream);
+}
+
+// The step for n_batch rows at once (q [B, Hq, 128], new k / v rows [B, Hkv, 128], pools with a batch stride; every row at
+// the same cache lengths — the reference's scalar counters, static_kv_cache.py:44-45): the batch row is grid.z of the scan
+// and grid.y of the merge launch.  `args` describes row 0.
+extern "C" int duo_decode_layer_batched_bf16(const duo_decode_layer_args *a, const duo_decode_batch *batch,
+                                             int32_t *new_stream_len, void *workspace, int64_t workspace_bytes,
+                                             void *stream) {
+    if (!batch) return DUO_EINVAL;
+    return decode_layer_impl(a, new_stream_len, nullptr, workspace, workspace_bytes, nullptr, stream, batch);
 }
 
 // Same step with the lengths and the position read on the device (see include/duo_attn_hip.h): the

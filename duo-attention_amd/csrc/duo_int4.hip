@@ -125,21 +125,30 @@ __device__ __forceinline__ uint32_t pk_add_f16(uint32_t a, uint32_t b) {
     asm volatile("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t pk_fma_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // w: 4 packed bytes = elements e0..e7 (byte b: e(2b) high nibble, e(2b+1) low nibble); s2 / z2 = the row's
 // scale / zero broadcast to both halves.  o2[b] = half2(dequant(e(2b)), dequant(e(2b+1))).
-__device__ __forceinline__ void dequant8_pk(uint32_t w, uint32_t s2, uint32_t z2, uint32_t (&o2)[4]) {
+// fused == false: hadd(hmul(q, s), z), two roundings — the source as written, what its `-ffp-contract=off` build
+// computes (tests/golden/int4_ref.npz `nocontract`); fused == true: fma(q, s, z), one rounding — what a compiler that
+// contracts the pair emits (the `default` build of the same source here; nvcc under the reference's --use_fast_math
+// may well do the same).  ~48 % of the values differ between the two by one fp16 ulp.
+__device__ __forceinline__ void dequant8_pk(uint32_t w, uint32_t s2, uint32_t z2, uint32_t (&o2)[4], bool fused = false) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const uint32_t byte = (w >> (8 * b)) & 0xffu;
         const uint32_t n2 = (byte >> 4) | ((byte & 0xfu) << 16) | 0x64006400u;   // half2(1024+hi, 1024+lo)
         const uint32_t q2 = pk_add_f16(n2, 0xE400E400u);                         // - 1024: exact
-        o2[b] = pk_add_f16(pk_mul_f16(q2, s2), z2);
+        o2[b] = fused ? pk_fma_f16(q2, s2, z2) : pk_add_f16(pk_mul_f16(q2, s2), z2);
     }
 }
-__device__ __forceinline__ void dequant8(uint32_t w, __half s, __half z, __half (&o)[8]) {
+__device__ __forceinline__ void dequant8(uint32_t w, __half s, __half z, __half (&o)[8], bool fused = false) {
     const uint32_t sb = __half_as_ushort(s), zb = __half_as_ushort(z);
     uint32_t o2[4];
-    dequant8_pk(w, sb | (sb << 16), zb | (zb << 16), o2);
+    dequant8_pk(w, sb | (sb << 16), zb | (zb << 16), o2, fused);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         o[2 * b] = __ushort_as_half((unsigned short)(o2[b] & 0xffffu));
@@ -153,6 +162,7 @@ struct DequantParams {
     int64_t q_ts, q_hs;         // ROW strides
     __half *out;                // [T, h, 128] contiguous
     int32_t n_tokens, n_heads;
+    int32_t fused;              // dequantisation form: 0 = mul then add (two roundings), 1 = fma (one)
 };
 
 __global__ __launch_bounds__(256) void duo_int4_dequantize_kernel(const DequantParams P) {
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void duo_int4_dequantize_kernel(const DequantP
     const int64_t srow = t * P.q_ts + (int64_t)h * P.q_hs;
     const uint32_t w = reinterpret_cast<const uint32_t *>(P.q + srow * 64)[sub];
     __half o[8];
-    dequant8(w, P.sz[srow * 2], P.sz[srow * 2 + 1], o);
+    dequant8(w, P.sz[srow * 2], P.sz[srow * 2 + 1], o, P.fused != 0);
     *reinterpret_cast<u32x4 *>(P.out + row * 128 + sub * 8) = *reinterpret_cast<const u32x4 *>(o);
 }
 
@@ -229,6 +239,7 @@ struct Int4DecodeParams {
     float *ws_ml, *ws_acc;
     int32_t max_splits;
     uint32_t flags;            // debug: bit 5 = loads only (memory-side ceiling of the access pattern)
+    int32_t fused;             // dequantisation form (see dequant8_pk)
 };
 
 __device__ __forceinline__ Int4SegDev i4_select(const Int4SegDev &a, const Int4SegDev &b, bool pb) {
@@ -242,10 +253,10 @@ __device__ __forceinline__ Int4SegDev i4_select(const Int4SegDev &a, const Int4S
     return r;
 }
 
-__device__ __forceinline__ void dequant8_f32(uint32_t w, uint32_t sz2, float (&f)[8]) {
+__device__ __forceinline__ void dequant8_f32(uint32_t w, uint32_t sz2, float (&f)[8], bool fused) {
     const uint32_t sb = sz2 & 0xffffu, zb = sz2 >> 16;    // (scale, zero) pair as stored
     uint32_t o2[4];
-    dequant8_pk(w, sb | (sb << 16), zb | (zb << 16), o2);
+    dequant8_pk(w, sb | (sb << 16), zb | (zb << 16), o2, fused);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const float2 t = __half22float2(*reinterpret_cast<const __half2 *>(&o2[b]));
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float kf[8];
-            dequant8_f32(kw[u], ks[u], kf);
+            dequant8_f32(kw[u], ks[u], kf, P.fused != 0);
 #pragma unroll
             for (int g = 0; g < GT; ++g) {
                 float d = qf[g][0] * kf[0];
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float vf[8];
-            dequant8_f32(vw[u], vs[u], vf);
+            dequant8_f32(vw[u], vs[u], vf, P.fused != 0);
 #pragma unroll
             for (int g = 0; g < GT; ++g)
 #pragma unroll
@@ -486,26 +497,42 @@ __device__ __forceinline__ bool scales_in_fma_range(uint32_t a, uint32_t b, uint
 // one packed dword (8 nibbles) -> 4 x half2 of reference-exact dequantised values, element order
 // [1,5 | 0,4 | 3,7 | 2,6] of the dword's 8 dims.  m0 / m4: nibble masks 0x000f000f / 0x00f000f0 (SGPRs),
 // magic: half2(1024, 1024) (VGPR) — see the note at their definition.
-template <bool FAST>
+// FUSED: the one-rounding form fma(n, s, z) (see dequant8_pk): (1024 + n) - 1024 = n and (1024 + 16 n) - 1024 = 16 n
+// are exact, then one fma against s (or s / 16, exact for voted tiles) — the same 13 / 19 instructions per 8 values.
+template <bool FAST, bool FUSED>
 __device__ __forceinline__ u32x4 dq8(uint32_t w, const RowConst &R, uint32_t m0, uint32_t m4, uint32_t magic) {
 #pragma clang fp contract(off)
     u32x4 o;
+    const h2_t bias = h2_splat(1024.f);
     if constexpr (FAST) {
         const uint32_t w8 = w >> 8;
         const h2_t a0 = as_h2((w & m0) | magic), a1 = as_h2((w & m4) | magic);
         const h2_t a2 = as_h2((w8 & m0) | magic), a3 = as_h2((w8 & m4) | magic);
-        o.x = as_u32(__builtin_elementwise_fma(a0, R.s, R.c) + R.z);
-        o.y = as_u32(__builtin_elementwise_fma(a1, R.s16, R.c16) + R.z);
-        o.z = as_u32(__builtin_elementwise_fma(a2, R.s, R.c) + R.z);
-        o.w = as_u32(__builtin_elementwise_fma(a3, R.s16, R.c16) + R.z);
+        if constexpr (FUSED) {
+            o.x = as_u32(__builtin_elementwise_fma(a0 - bias, R.s, R.z));
+            o.y = as_u32(__builtin_elementwise_fma(a1 - bias, R.s16, R.z));
+            o.z = as_u32(__builtin_elementwise_fma(a2 - bias, R.s, R.z));
+            o.w = as_u32(__builtin_elementwise_fma(a3 - bias, R.s16, R.z));
+        } else {
+            o.x = as_u32(__builtin_elementwise_fma(a0, R.s, R.c) + R.z);
+            o.y = as_u32(__builtin_elementwise_fma(a1, R.s16, R.c16) + R.z);
+            o.z = as_u32(__builtin_elementwise_fma(a2, R.s, R.c) + R.z);
+            o.w = as_u32(__builtin_elementwise_fma(a3, R.s16, R.c16) + R.z);
+        }
     } else {
-        const h2_t bias = h2_splat(1024.f);
         const h2_t a0 = as_h2((w & m0) | magic), a1 = as_h2(((w >> 4) & m0) | magic);
         const h2_t a2 = as_h2(((w >> 8) & m0) | magic), a3 = as_h2(((w >> 12) & m0) | magic);
-        o.x = as_u32((a0 - bias) * R.s + R.z);
-        o.y = as_u32((a1 - bias) * R.s + R.z);
-        o.z = as_u32((a2 - bias) * R.s + R.z);
-        o.w = as_u32((a3 - bias) * R.s + R.z);
+        if constexpr (FUSED) {
+            o.x = as_u32(__builtin_elementwise_fma(a0 - bias, R.s, R.z));
+            o.y = as_u32(__builtin_elementwise_fma(a1 - bias, R.s, R.z));
+            o.z = as_u32(__builtin_elementwise_fma(a2 - bias, R.s, R.z));
+            o.w = as_u32(__builtin_elementwise_fma(a3 - bias, R.s, R.z));
+        } else {
+            o.x = as_u32((a0 - bias) * R.s + R.z);
+            o.y = as_u32((a1 - bias) * R.s + R.z);
+            o.z = as_u32((a2 - bias) * R.s + R.z);
+            o.w = as_u32((a3 - bias) * R.s + R.z);
+        }
     }
     return o;
 }
@@ -526,8 +553,9 @@ struct I4Tile {
 
 typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 
-// MINW: waves per SIMD the register budget is cut for; MODE: dequantisation form (see process()).
-template <int MINW, int MODE>
+// MINW: waves per SIMD the register budget is cut for; MODE: 0 = every tile in the always-exact shifted form, 1 = voted
+// (tiles whose scales allow it take the masked form); FUSED: fma(n, s, z) instead of hadd(hmul(n, s), z) (see dq8).
+template <int MINW, int MODE, bool FUSED>
 __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const Int4DecodeParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -659,7 +687,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST>(kw[kb], R, m0, m4, magic)), qB[kb],
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST, FUSED>(kw[kb], R, m0, m4, magic)), qB[kb],
                                                               S[h], 0, 0, 0);
         }
         // ---- V^ -> LDS (issued early: the writes drain while the softmax runs) -----------------
@@ -669,7 +697,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8<FAST>(vw[j], R, m0, m4, magic);
+                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8<FAST, FUSED>(vw[j], R, m0, m4, magic);
         }
 
         // ---- softmax against the reference maximum ---------------------------------------------
@@ -917,12 +945,12 @@ extern "C" int duo_int4_quantize(const void *src, int32_t src_is_bf16, int64_t s
 
 extern "C" int duo_int4_dequantize_f16(const void *q_pool, const void *sz_pool, int64_t pool_token_stride_rows,
                                        int64_t pool_head_stride_rows, void *out, int32_t n_heads,
-                                       int32_t n_tokens, int32_t head_dim, void *stream) {
+                                       int32_t n_tokens, int32_t head_dim, int32_t fused, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (n_heads <= 0 || n_tokens <= 0) return 0;
     if (!q_pool || !sz_pool || !out) return DUO_EINVAL;
     DequantParams P{(const uint8_t *)q_pool, (const __half *)sz_pool, pool_token_stride_rows,
-                    pool_head_stride_rows, (__half *)out, n_tokens, n_heads};
+                    pool_head_stride_rows, (__half *)out, n_tokens, n_heads, fused != 0};
     const int64_t rows = (int64_t)n_tokens * n_heads;
     hipLaunchKernelGGL(duo_int4_dequantize_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0,
                        (hipStream_t)stream, P);
@@ -955,11 +983,12 @@ static void i4_choose_splits(int n_kv_heads, int L, int max_splits, int budget, 
 
 extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
                                         int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
-                                        float scale, int32_t head_dim, void *workspace, int64_t workspace_bytes,
-                                        void *stream) {
+                                        float scale, int32_t head_dim, int32_t fused, void *workspace,
+                                        int64_t workspace_bytes, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     if (!q || !out || group <= 0) return DUO_EINVAL;
     Int4DecodeParams P;
+    P.fused = fused != 0;
     P.q = (const __half *)q; P.q_head_stride = q_head_stride;
     P.out = (__half *)out; P.out_head_stride = out_head_stride;
     const duo_int4_pool *src[2] = {full, stream_cls};
@@ -1009,10 +1038,15 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
             return x == 0 ? 0 : 1;
         }();
         dim3 grid(nblk), block(256);
-#define DUO_I4_LAUNCH(W_)                                                                                   \
-    do {                                                                                                    \
-        if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 0>), grid, block, 0, st, P);     \
-        else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 1>), grid, block, 0, st, P);               \
+#define DUO_I4_LAUNCH(W_)                                                                                          \
+    do {                                                                                                           \
+        if (P.fused) {                                                                                             \
+            if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 0, true>), grid, block, 0, st, P);  \
+            else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 1, true>), grid, block, 0, st, P);            \
+        } else {                                                                                                   \
+            if (mode == 0) hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 0, false>), grid, block, 0, st, P); \
+            else hipLaunchKernelGGL((duo_int4_decode_mfma_kernel<W_, 1, false>), grid, block, 0, st, P);           \
+        }                                                                                                          \
     } while (0)
         if (occ == 2) DUO_I4_LAUNCH(2);
         else if (occ == 4) DUO_I4_LAUNCH(4);
@@ -1036,7 +1070,8 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
         M.splits[c] = P.splits[c];
         if (P.splits[c] > 1) n_merge += P.cls[c].n_kv_heads * group;
     }
-    if (n_merge > 0) {
+    // debug flag bit 1: leave the partials unmerged (a HIP-event pair then brackets the split kernel alone)
+    if (n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
         hipLaunchKernelGGL(duo_int4_decode_merge_kernel, dim3(n_merge, 4), dim3(256), 0, st, M);
         DUO_HIP_CHECK_LAUNCH();
     }

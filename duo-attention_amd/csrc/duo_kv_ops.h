@@ -55,11 +55,12 @@ struct CompressParams {
     float pos;
     float inv_freq[64];
     const int32_t *dev_state;   // {full_len, str_len, pos, _}: overrides cur / pos when set (captured decode step)
+    int64_t p_bs, n_bs;         // batched launches: elements between the batch rows of the pool / of the new rows
 };
 
 constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
 
-__device__ __forceinline__ void duo_stream_compress_block(const CompressParams &P, int blk) {
+__device__ __forceinline__ void duo_stream_compress_block(const CompressParams &P, int blk, int row = 0) {
     int cur = P.cur;
     float pos = P.pos;
     if (P.dev_state) {
@@ -68,8 +69,8 @@ __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &
     }
     const int h = blk >> 1;
     const bool is_v = blk & 1;
-    bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs;
-    const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs;
+    bf16_t *pool = (is_v ? P.vp : P.kp) + (int64_t)h * P.p_hs + (int64_t)row * P.p_bs;
+    const bf16_t *nw = (is_v ? P.vn : P.kn) + (int64_t)h * P.n_hs + (int64_t)row * P.n_bs;
     const int T = cur + P.n_new;
     const int W = P.sink + P.recent;
     const int ch = threadIdx.x & 15;

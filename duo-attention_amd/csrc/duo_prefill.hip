@@ -52,11 +52,14 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     int b = blockIdx.x;
     const int ci = b < P.nblk_full ? 0 : 1;
     if (ci) b -= P.nblk_full;
-    const DuoClassDev C = duo_select(P.cls[0], P.cls[1], ci != 0);
+    const int by = blockIdx.y;        // batch row
+    DuoClassDev Crow = duo_select(P.cls[0], P.cls[1], ci != 0);
+    duo_class_batch_row(Crow, by);
+    const DuoClassDev C = Crow;
     // key-range split (retrieval class only): the splits of one (q tile, q head) are adjacent block ids
     const int ks = ci == 0 ? P.ksplit : 1;
     const int split = b % ks;
-    const int part_id = b;            // index of this workgroup's partial in the workspace
+    const int part_id = b + by * P.nblk_full;   // index of this workgroup's partial in the workspace
     b /= ks;
     const int nq_c = C.n_kv_heads * P.group;
     const int tile = P.n_qtiles - 1 - b / nq_c;   // heaviest (latest) tiles first
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     // ---- Q fragments (B operand of the swapped QK^T) --------------------------
     bf16x8 qfrag[8];
     {
-        const bf16_t *qp = P.q + (int64_t)my_q_ld * P.q_ts + (int64_t)qh * P.q_hs + hi * 8;
+        const bf16_t *qp = P.q + (int64_t)by * P.q_bs + (int64_t)my_q_ld * P.q_ts + (int64_t)qh * P.q_hs + hi * 8;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qfrag[kk] = *reinterpret_cast<const bf16x8 *>(qp + kk * 16);
     }
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     }
     const float inv = 1.f / lsum;
     if (my_q < S) {
-        bf16_t *op = P.out + (int64_t)my_q * P.o_ts + (int64_t)qh * P.o_hs;
+        bf16_t *op = P.out + (int64_t)by * P.o_bs + (int64_t)my_q * P.o_ts + (int64_t)qh * P.o_hs;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
         const int r = pass * 32 + (threadIdx.x >> 3);
         const int q = tile * QBLK + r;
         if (q >= P.S) continue;
-        const int64_t row0 = (int64_t)b * ks * QBLK + r;     // split s: + s * QBLK
+        const int64_t row0 = ((int64_t)b * ks + (int64_t)blockIdx.y * P.nblk_full) * QBLK + r;     // split s: + s * QBLK
         float M = -INFINITY;
         for (int s = 0; s < ks; ++s) M = fmaxf(M, P.ws_ml[(row0 + (int64_t)s * QBLK) * 2]);
         float L = 0.f;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
             for (int i = 0; i < 4; ++i) acc[i] = acc[i] + src[i] * w;
         }
         const float inv = 1.f / L;
-        bf16_t *op = P.out + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * j;
+        bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * j;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 w2;
@@ -568,11 +571,15 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
                         void *out, int64_t out_token_stride, int64_t out_head_stride,
                         int32_t n_tokens, int32_t group, const duo_head_class *full,
                         const duo_head_class *stream_cls, float scale, int32_t head_dim,
-                        void *workspace, int64_t workspace_bytes, void *stream) {
+                        void *workspace, int64_t workspace_bytes, void *stream,
+                        int32_t n_batch = 1, int64_t q_batch_stride = 0, int64_t out_batch_stride = 0) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
-    if (q == nullptr || out == nullptr || group <= 0 || n_tokens < 0) return DUO_EINVAL;
-    if (n_tokens == 0) return 0;
+    if (q == nullptr || out == nullptr || group <= 0 || n_tokens < 0 || n_batch < 0 || n_batch > 65535) return DUO_EINVAL;
+    if (n_tokens == 0 || n_batch == 0) return 0;
+    if (n_batch > 1 && ((q_batch_stride | out_batch_stride) & 7)) return DUO_EINVAL;
     PrefillParams P;
+    P.q_bs = q_batch_stride;
+    P.o_bs = out_batch_stride;
     P.q = (const bf16_t *)q;
     P.q_ts = q_token_stride;
     P.q_hs = q_head_stride;
@@ -605,10 +612,10 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     P.ws_ml = nullptr;
     if (workspace && long_wgs > 0) {
         const int min_tiles = (P.cls[0].a.len + KVBLK - 1) / KVBLK + 1;   // tiles of the first q tile
-        P.ksplit = prefill_choose_ksplit(long_wgs, min_tiles, workspace_bytes);
+        P.ksplit = prefill_choose_ksplit(long_wgs, min_tiles, workspace_bytes / n_batch);   // every batch row has its own partials
         if (P.ksplit > 1) {
             P.ws_o = (float *)workspace;
-            P.ws_ml = P.ws_o + (int64_t)long_wgs * P.ksplit * QBLK * DUO_HEAD_DIM;
+            P.ws_ml = P.ws_o + (int64_t)n_batch * long_wgs * P.ksplit * QBLK * DUO_HEAD_DIM;
             nblk += long_wgs * (P.ksplit - 1);
         }
     }
@@ -662,21 +669,21 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
                 nblk += periods * rows * row_items - P.nblk_full;     // the padded last period
                 P.nblk_full = periods * rows * row_items;
             }
-            if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
-            else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk), dim3(256), LDS_BYTES, st, P);
+            if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
+            else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
             DUO_HIP_CHECK_LAUNCH();
             if (P.ksplit > 1) {
-                hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs), dim3(256), 0, st, P);
+                hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs, n_batch), dim3(256), 0, st, P);
                 DUO_HIP_CHECK_LAUNCH();
             }
             return 0;
         }
     }
-    if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
-    else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk), dim3(512), LDS_BYTES, st, P);
+    if (tr) hipLaunchKernelGGL((duo_prefill_kernel<true, F16>), dim3(nblk, n_batch), dim3(512), LDS_BYTES, st, P);
+    else hipLaunchKernelGGL((duo_prefill_kernel<false, F16>), dim3(nblk, n_batch), dim3(512), LDS_BYTES, st, P);
     DUO_HIP_CHECK_LAUNCH();
     if (P.ksplit > 1) {
-        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs), dim3(256), 0, st, P);
+        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs, n_batch), dim3(256), 0, st, P);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -704,6 +711,29 @@ extern "C" int duo_attn_prefill_ws_bf16(const void *q, int64_t q_token_stride, i
 
 // fp16 twin (q, K, V, out all fp16): the attention of the INT4 path's chunked prefill over dequantised pools
 // (demo/w8a8kv4_llama.py:226-274) and of fp16 models.
+// Batched forms (n_batch rows of equal length — the reference's pools and forward carry a batch dimension,
+// static_kv_cache.py:60-99, and flash_attn_func batches natively): the batch row is grid.y of the same launches.
+extern "C" int duo_attn_prefill_batched_bf16(const void *q, int64_t q_batch_stride, int64_t q_token_stride,
+                                             int64_t q_head_stride, void *out, int64_t out_batch_stride,
+                                             int64_t out_token_stride, int64_t out_head_stride, int32_t n_batch,
+                                             int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                             const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                             void *workspace, int64_t workspace_bytes, void *stream) {
+    return prefill_impl<false>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                               group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream, n_batch,
+                               q_batch_stride, out_batch_stride);
+}
+extern "C" int duo_attn_prefill_batched_f16(const void *q, int64_t q_batch_stride, int64_t q_token_stride,
+                                            int64_t q_head_stride, void *out, int64_t out_batch_stride,
+                                            int64_t out_token_stride, int64_t out_head_stride, int32_t n_batch,
+                                            int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                            const duo_head_class *stream_cls, float scale, int32_t head_dim,
+                                            void *workspace, int64_t workspace_bytes, void *stream) {
+    return prefill_impl<true>(q, q_token_stride, q_head_stride, out, out_token_stride, out_head_stride, n_tokens,
+                              group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream, n_batch,
+                              q_batch_stride, out_batch_stride);
+}
+
 extern "C" int duo_attn_prefill_f16(const void *q, int64_t q_token_stride, int64_t q_head_stride,
                                     void *out, int64_t out_token_stride, int64_t out_head_stride,
                                     int32_t n_tokens, int32_t group, const duo_head_class *full,

@@ -37,6 +37,9 @@ struct PrefillParams {
     // XCD-aware block order of the retrieval class (4-wave kernel, unsplit launches; see duo_prefill_w64_kernel.inc):
     // q-tile rows per period and workgroups per XCD per period; xmap_q == 0: plain q-tile-major order
     int32_t xmap_rows, xmap_q;
+    // batched launch: grid.y = batch row; q / out rows of a batch row are q_bs / o_bs elements apart, the segments carry
+    // their own batch strides, every row has nblk_full partials of its own in the workspace
+    int64_t q_bs, o_bs;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;

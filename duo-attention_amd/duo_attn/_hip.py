@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 HEAD_DIM = 128
 
 
@@ -144,7 +144,7 @@ _SIGNATURES = {
          c_int32, c_void_p],
     ),
     "duo_int4_dequantize_f16": (
-        ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_void_p],
+        ctypes.c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p],
     ),
     "duo_int4_stream_compress": (
         ctypes.c_int,
@@ -154,7 +154,7 @@ _SIGNATURES = {
     "duo_attn_decode_int4_f16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_void_p, c_int64, c_int32, POINTER(Int4Pool), POINTER(Int4Pool), c_float, c_int32,
-         c_void_p, c_int64, c_void_p],
+         c_int32, c_void_p, c_int64, c_void_p],
     ),
 }
 
@@ -519,8 +519,10 @@ def int4_quantize(src: torch.Tensor, q_pool: torch.Tensor, sz_pool: torch.Tensor
                                  int(dst_row0), src.shape[2], _stream_ptr()), "duo_int4_quantize")
 
 
-def int4_dequantize(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, out: torch.Tensor) -> torch.Tensor:
-    """rows [0, n_tokens) of the pool -> out[: n_tokens*h*128] viewed [n_tokens, h, 128] fp16."""
+def int4_dequantize(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, out: torch.Tensor,
+                    fused: bool = False) -> torch.Tensor:
+    """rows [0, n_tokens) of the pool -> out[: n_tokens*h*128] viewed [n_tokens, h, 128] fp16.  ``fused``: q*s + z as
+    one fma (one rounding) instead of the source's hmul then hadd (two) — see ``duo_int4_dequantize_f16``."""
     lib = load_library()
     h = q_pool.shape[1]
     res = out[: n_tokens * h * HEAD_DIM].view(n_tokens, h, HEAD_DIM)
@@ -530,7 +532,7 @@ def int4_dequantize(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, 
     _require_gpu(out, "out", torch.float16)
     ts, hs = _pool_row_strides(q_pool)
     _check(lib.duo_int4_dequantize_f16(q_pool.data_ptr(), sz_pool.data_ptr(), ts, hs, res.data_ptr(), h,
-                                       int(n_tokens), HEAD_DIM, _stream_ptr()), "duo_int4_dequantize_f16")
+                                       int(n_tokens), HEAD_DIM, int(bool(fused)), _stream_ptr()), "duo_int4_dequantize_f16")
     return res
 
 
@@ -559,8 +561,9 @@ def make_int4_pool(kq, ksz, vq, vsz, length: int, q_head_offset: int) -> Optiona
 
 
 def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[Int4Pool],
-                     stream: Optional[Int4Pool], scale: float):
-    """q, out [Hq, 128] fp16: decode attention over the packed pools, dequantisation in registers."""
+                     stream: Optional[Int4Pool], scale: float, fused: bool = False):
+    """q, out [Hq, 128] fp16: decode attention over the packed pools, dequantisation in registers (``fused``: the
+    one-rounding form, as ``int4_dequantize``)."""
     lib = load_library()
     _require_gpu(q, "q", torch.float16)
     _require_gpu(out, "out", torch.float16)
@@ -569,7 +572,8 @@ def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optio
     _check(lib.duo_attn_decode_int4_f16(q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), int(group),
                                         byref(full) if full is not None else None,
                                         byref(stream) if stream is not None else None, float(scale), q.shape[1],
-                                        ws.data_ptr(), ws.numel() * 4, _stream_ptr()), "duo_attn_decode_int4_f16")
+                                        int(bool(fused)), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+           "duo_attn_decode_int4_f16")
 
 
 def set_debug_flags(flags: int):

@@ -39,7 +39,11 @@ class QuantizedCache:
 
 class DuoAttentionStaticINT4KVCache:
     def __init__(self, model, full_attention_heads, batch_size, max_size, sink_size, recent_size,
-                 prefilling_chunk_size):
+                 prefilling_chunk_size, fused_dequant: bool = False):
+        """``fused_dequant``: dequantise as ONE fma(q, s, z) instead of the source's hmul-then-hadd (two roundings, the
+        default here).  Which of the two the reference's own build computes depends on whether its compiler contracts
+        ``__hadd(__hmul(f, s), z)``; both forms are pinned against builds of the reference's kernel."""
+        self.fused_dequant = bool(fused_dequant)
         self.batch_size, self.max_size = batch_size, max_size
         self.sink_size, self.recent_size = sink_size, recent_size
         self.prefilling_chunk_size = prefilling_chunk_size
@@ -136,7 +140,8 @@ class DuoAttentionStaticINT4KVCache:
             out = self._buf(name, B * rows * heads * self.head_dim)
             per = rows * heads * self.head_dim
             for b in range(B):
-                _hip.int4_dequantize(cache.quantized_data[b], cache.scale_zero[b], rows, out[b * per:(b + 1) * per])
+                _hip.int4_dequantize(cache.quantized_data[b], cache.scale_zero[b], rows, out[b * per:(b + 1) * per],
+                                     fused=self.fused_dequant)
             return out[: B * per].view(B, rows, heads, self.head_dim)
 
         return (deq(self.full_key_caches[layer_idx], n, nf, "fk"), deq(self.full_value_caches[layer_idx], n, nf, "fv"),
@@ -222,5 +227,5 @@ class DuoAttentionStaticINT4KVCache:
                                        fv.scale_zero[b], n, 0) if nf else None
             stream = _hip.make_int4_pool(sk.quantized_data[b], sk.scale_zero[b], sv.quantized_data[b],
                                          sv.scale_zero[b], m, nf * G) if ns else None
-            _hip.attn_decode_int4(query_states[b, 0], out[b, 0], G, full, stream, scale)
+            _hip.attn_decode_int4(query_states[b, 0], out[b, 0], G, full, stream, scale, fused=self.fused_dequant)
         return out

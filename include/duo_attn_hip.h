@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DUO_ABI_VERSION 1
+#define DUO_ABI_VERSION 2
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
@@ -68,6 +68,7 @@ typedef struct duo_kv_seg {
     int64_t head_stride;
     int32_t len;   /* rows in this segment                                    */
     int32_t _pad;
+    int64_t batch_stride;  /* elements between the batch rows of this segment (batched entry points; 0 otherwise) */
 } duo_kv_seg;
 
 /*
@@ -197,6 +198,63 @@ typedef struct duo_decode_layer_args {
 int duo_decode_layer_bf16(const duo_decode_layer_args *args, int32_t *new_stream_len,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- batched forms ---------------------------------------------------------------------------------------------
+ * The reference's pools, counters and forward carry a batch dimension (static_kv_cache.py:60-125, llama.py:309-434;
+ * flash_attn_func batches natively).  Every batch row has the same lengths (the reference keeps ONE counter per layer);
+ * rows may start at different RoPE positions (position_ids[:, 0], llama.py:347-352).  The batch row is a grid
+ * dimension of the same kernels: one launch (pair) for all rows instead of one per row.  Strides in elements; the
+ * duo_kv_seg::batch_stride fields of the head classes say how far apart the rows of each segment are.           */
+typedef struct duo_decode_batch {
+    int32_t n_batch;
+    int32_t _pad;
+    int64_t q_batch_stride;      /* q   [B, n_q_heads, 128]                                   */
+    int64_t kv_batch_stride;     /* k/v [B, n_kv_heads, 128]: the new token's rows            */
+    int64_t out_batch_stride;
+    int64_t full_batch_stride;   /* retrieval pool                                            */
+    int64_t str_batch_stride;    /* streaming pool                                            */
+    const int64_t *pos;          /* HOST array of n_batch position ids, or NULL: args->pos for every row.  Rows at
+                                    different positions are issued as one launch pair per row.                    */
+} duo_decode_batch;
+/* `args` describes batch row 0; *new_stream_len as duo_decode_layer_bf16 (the same for every row) */
+int duo_decode_layer_batched_bf16(const duo_decode_layer_args *args, const duo_decode_batch *batch,
+                                  int32_t *new_stream_len, void *workspace, int64_t workspace_bytes, void *stream);
+int duo_attn_decode_batched_bf16(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                                 int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch, int32_t group,
+                                 const duo_head_class *full, const duo_head_class *stream_cls, float scale,
+                                 int32_t head_dim, void *workspace, int64_t workspace_bytes, void *stream);
+int duo_attn_prefill_batched_bf16(const void *q, int64_t q_batch_stride, int64_t q_token_stride, int64_t q_head_stride,
+                                  void *out, int64_t out_batch_stride, int64_t out_token_stride, int64_t out_head_stride,
+                                  int32_t n_batch, int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                  const duo_head_class *stream_cls, float scale, int32_t head_dim, void *workspace,
+                                  int64_t workspace_bytes, void *stream);
+int duo_attn_prefill_batched_f16(const void *q, int64_t q_batch_stride, int64_t q_token_stride, int64_t q_head_stride,
+                                 void *out, int64_t out_batch_stride, int64_t out_token_stride, int64_t out_head_stride,
+                                 int32_t n_batch, int32_t n_tokens, int32_t group, const duo_head_class *full,
+                                 const duo_head_class *stream_cls, float scale, int32_t head_dim, void *workspace,
+                                 int64_t workspace_bytes, void *stream);
+/* pos0: HOST array of n_batch first positions; equal positions -> one launch, else one per row */
+int duo_rope_inplace_batched_bf16(void *q, int64_t q_batch_stride, int64_t q_token_stride, int64_t q_head_stride,
+                                  int32_t n_q_heads, void *k, int64_t k_batch_stride, int64_t k_token_stride,
+                                  int64_t k_head_stride, int32_t n_kv_heads, int32_t n_batch, int32_t n_tokens,
+                                  const int64_t *pos0, float rope_scale, float rope_theta, int32_t head_dim,
+                                  void *stream);
+int duo_rope_inplace_batched_f16(void *q, int64_t q_batch_stride, int64_t q_token_stride, int64_t q_head_stride,
+                                 int32_t n_q_heads, void *k, int64_t k_batch_stride, int64_t k_token_stride,
+                                 int64_t k_head_stride, int32_t n_kv_heads, int32_t n_batch, int32_t n_tokens,
+                                 const int64_t *pos0, float rope_scale, float rope_theta, int32_t head_dim,
+                                 void *stream);
+int duo_kv_append_batched_bf16(const void *k_src, const void *v_src, int64_t src_batch_stride,
+                               int64_t src_token_stride, int64_t src_head_stride, void *k_pool, void *v_pool,
+                               int64_t pool_batch_stride, int64_t pool_token_stride, int64_t pool_head_stride,
+                               int32_t n_batch, int32_t n_heads, int32_t n_tokens, int32_t dst_row0,
+                               int32_t head_dim, void *stream);
+int duo_stream_compress_batched_bf16(void *k_pool, void *v_pool, int64_t pool_batch_stride,
+                                     int64_t pool_token_stride, int64_t pool_head_stride, const void *k_new,
+                                     const void *v_new, int64_t new_batch_stride, int64_t new_token_stride,
+                                     int64_t new_head_stride, int32_t n_batch, int32_t n_heads, int32_t cur_len,
+                                     int32_t n_new, int32_t sink, int32_t recent, int32_t head_dim,
+                                     int32_t *new_len, void *stream);
+
 /* ---- the same step with device-side lengths (graph-captured decode) ----------------
  * The reference keeps the cache lengths as Python ints (static_kv_cache.py:44-45), which bakes them
  * into every launch and rules out capturing the decode step in a graph.  Here each layer has a
@@ -301,10 +359,15 @@ int duo_int4_quantize(const void *src, int32_t src_is_bf16, int64_t src_token_st
                       int32_t n_heads, int32_t n_tokens, int32_t dst_row0, int32_t head_dim,
                       void *stream);
 /* pool rows [0, n_tokens) x n_heads -> out [n_tokens, n_heads, 128] fp16 contiguous
- * (quantize_int4.cu:9-71; kept for DuoAttentionStaticINT4KVCache.get())                    */
+ * (quantize_int4.cu:9-71; kept for DuoAttentionStaticINT4KVCache.get()).
+ * `fused` picks the rounding of q*s + z: 0 = hadd(hmul(q, s), z), two roundings — the source as written
+ * (quantize_int4.cu:38-39) and what its -ffp-contract=off build computes; 1 = one fma, what a compiler that
+ * contracts the pair emits (hipcc by default; plausibly nvcc under the reference's --use_fast_math,
+ * demo/int4_kv.py:46-56).  Both are pinned bit for bit against builds of the reference's own file
+ * (tests/golden/int4_ref.npz: `nocontract` / `default`); they differ by one fp16 ulp on ~48 % of the values.   */
 int duo_int4_dequantize_f16(const void *q_pool, const void *sz_pool, int64_t pool_token_stride_rows,
                             int64_t pool_head_stride_rows, void *out, int32_t n_heads,
-                            int32_t n_tokens, int32_t head_dim, void *stream);
+                            int32_t n_tokens, int32_t head_dim, int32_t fused, void *stream);
 /* streaming pool: keep the first `sink` and the last `recent` of `len` rows, in place
  * (DuoAttentionStaticINT4KVCache.compress, demo/int4_kv.py:438-492)                        */
 int duo_int4_stream_compress(void *k_q, void *k_sz, void *v_q, void *v_sz,
@@ -313,11 +376,13 @@ int duo_int4_stream_compress(void *k_q, void *k_sz, void *v_q, void *v_sz,
                              int32_t *new_len, void *stream);
 /* decode attention (one fp16 query token) straight over the packed pools: dequantisation in
  * registers instead of the reference's dequantise-everything-to-scratch + flash_attn_func
- * (demo/int4_kv.py:373-436, demo/w8a8kv4_llama.py:240-274).  q/out [n_q_heads, 128] fp16.  */
+ * (demo/int4_kv.py:373-436, demo/w8a8kv4_llama.py:240-274).  q/out [n_q_heads, 128] fp16.
+ * `fused`: the dequantisation form, as duo_int4_dequantize_f16 (the attention then sees exactly the values
+ * that function would have written to scratch).                                                      */
 int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
                              int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
-                             float scale, int32_t head_dim, void *workspace, int64_t workspace_bytes,
-                             void *stream);
+                             float scale, int32_t head_dim, int32_t fused, void *workspace,
+                             int64_t workspace_bytes, void *stream);
 
 /* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
 int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,

@@ -4,7 +4,8 @@ tests/golden/make_int4_golden.py -> tests/golden/int4_ref.npz).
 
 CPU: the numpy oracle reproduces the `nocontract` build (the source as written) bit for bit, the `default`
 build with ``fused=True``, and bounds its distance to the `fast` (approximate-reciprocal) build.
-GPU: the product's duo_int4_quantize / duo_int4_dequantize_f16 reproduce the `nocontract` build bit for bit.
+GPU: the product's duo_int4_quantize reproduces the `nocontract` build bit for bit, duo_int4_dequantize_f16 the `nocontract`
+build (fused=False, the default) and the `default` build (fused=True); the fused decode kernels dequantise in the same form.
 """
 import json
 import os
@@ -142,26 +143,72 @@ def test_hip_quantize_equals_reference_kernel(g, head_major):
 
 
 @gpu
-def test_hip_dequantize_equals_reference_kernel(g):
+@pytest.mark.parametrize("fused,variant", [(False, "nocontract"), (True, "default")])
+def test_hip_dequantize_equals_reference_kernel(g, fused, variant):
+    """both rounding forms of the product against the matching build of the reference's own kernel, bit for bit:
+    hmul-then-hadd == the `nocontract` build (the source as written), fma == the `default` build (contracted)"""
     from duo_attn import _hip
 
     for name in case_names(g):
-        qg = g[f"q|{name}|nocontract"]
+        qg = g[f"q|{name}|{variant}"]
         S, h, _ = qg.shape
         q, sz = _pools(S, h, True)
         q.copy_(torch.from_numpy(qg))
-        sz[..., 0].copy_(torch.from_numpy(f16(g[f"s|{name}|nocontract"]).copy()))
-        sz[..., 1].copy_(torch.from_numpy(f16(g[f"z|{name}|nocontract"]).copy()))
+        sz[..., 0].copy_(torch.from_numpy(f16(g[f"s|{name}|{variant}"]).copy()))
+        sz[..., 1].copy_(torch.from_numpy(f16(g[f"z|{name}|{variant}"]).copy()))
         out = torch.empty(S * h * 128, dtype=torch.float16, device=DEV)
-        got = _hip.int4_dequantize(q, sz, S, out).cpu().numpy().view(np.uint16)
-        assert np.array_equal(got, g[f"dq|{name}|nocontract"]), name
+        got = _hip.int4_dequantize(q, sz, S, out, fused=fused).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, g[f"dq|{name}|{variant}"]), name
     N = g["rawq"].shape[0]
     q, sz = _pools(N, 1, False)
     q[:, 0].copy_(torch.from_numpy(g["rawq"]))
     sz[:, 0, 0].copy_(torch.from_numpy(f16(g["raws"]).copy()))
     sz[:, 0, 1].copy_(torch.from_numpy(f16(g["rawz"]).copy()))
     out = torch.empty(N * 128, dtype=torch.float16, device=DEV)
-    got = _hip.int4_dequantize(q, sz, N, out).cpu().numpy().reshape(N, 128)
-    want = f16(g["rawdq|nocontract"])
+    got = _hip.int4_dequantize(q, sz, N, out, fused=fused).cpu().numpy().reshape(N, 128)
+    want = f16(g[f"rawdq|{variant}"])
     same = (got.view(np.uint16) == want.view(np.uint16)) | (np.isnan(got) & np.isnan(want))
     assert same.all()
+
+
+@gpu
+@pytest.mark.parametrize("scalar_kernel", [False, True])
+@pytest.mark.parametrize("fused", [False, True])
+def test_hip_int4_decode_dequantises_in_the_requested_form(fused, scalar_kernel):
+    """The fused decode attention must see exactly the values duo_int4_dequantize_f16 writes in the same form.  With a
+    ONE-HOT softmax (one key scores far above the rest) the output is that key's dequantised V row, so the two rounding
+    forms — which differ by one fp16 ulp on about half the values — are told apart in the attention's OUTPUT:
+    out == dequantised V row (requested form) bit for bit, and != the other form's row."""
+    from duo_attn import _hip
+
+    gen = torch.Generator().manual_seed(3 + fused)
+    T, h, G = 200, 2, 4
+    kq, ksz = _pools(T, h, True)
+    vq, vsz = _pools(T, h, True)
+    k = torch.randn(T, h, 128, generator=gen).half() * 0.05
+    v = (torch.randn(T, h, 128, generator=gen) * 3.0).half()
+    hot = [57, 133]
+    for j in range(h):
+        k[hot[j], j] = torch.sign(torch.randn(128, generator=gen)).half() * 4.0          # |k_hot| = 4 in every dim
+    _hip.int4_quantize(k.to(DEV), kq, ksz, 0)
+    _hip.int4_quantize(v.to(DEV), vq, vsz, 0)
+    scratch = torch.empty(T * h * 128, dtype=torch.float16, device=DEV)
+    rows = {f: _hip.int4_dequantize(vq, vsz, T, scratch, fused=f).clone() for f in (False, True)}
+    kd = _hip.int4_dequantize(kq, ksz, T, scratch, fused=fused).clone()
+    q = torch.empty(h * G, 128, dtype=torch.float16, device=DEV)
+    for j in range(h):
+        q[j * G:(j + 1) * G] = kd[hot[j], j] * 8.0        # q.k_hot * scale = 128 * 16 * 8 / 11.3 >> any other score
+    out = torch.empty_like(q)
+    pool = _hip.make_int4_pool(kq, ksz, vq, vsz, T, 0)
+    _hip.set_debug_flags(16 if scalar_kernel else 0)
+    try:
+        _hip.attn_decode_int4(q, out, G, pool, None, 128 ** -0.5, fused=fused)
+    finally:
+        _hip.set_debug_flags(0)
+    differ = 0
+    for j in range(h):
+        want, other = rows[fused][hot[j], j], rows[not fused][hot[j], j]
+        differ += int((want != other).sum())
+        for gq in range(G):
+            assert torch.equal(out[j * G + gq], want), (j, gq, (out[j * G + gq] != want).sum())
+    assert differ > 0        # the fixture really distinguishes the two forms
