@@ -1186,7 +1186,10 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
     }
     // Single launch (duo_decode_step_bf16): the kernel merges and updates the streaming pool itself.  Needs one
     // workgroup row per kv head (group == GT), the ticket area, and room for every head's two counters.
-    const bool one = tickets != nullptr && !batched && group == D.gt && 2 * nkv < kTicketWords - 1 && !(duo_get_debug_flags() & 2u);
+    // (... and a grid that is certainly resident at once — one workgroup per CU: the mergers spin while they hold their CU,
+    // so a workgroup that has not been dispatched yet must never be waited for)
+    const bool one = tickets != nullptr && !batched && group == D.gt && 2 * nkv < kTicketWords - 1 && D.nblk <= 256 &&
+                     !(duo_get_debug_flags() & 2u);
     if (one) {
         D.P.one_launch = 1;
         D.P.tickets = (int32_t *)tickets;

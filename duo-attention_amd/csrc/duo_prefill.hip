@@ -1,5 +1,12 @@
 // duo_prefill.hip — chunked-prefill flash attention for both DuoAttention head
-// classes in one launch (gfx950, bf16 MFMA 32x32x16).
+// classes in one launch (gfx950, bf16 MFMA 32x32x16): the launcher / C entry points of BOTH prefill kernels, the
+// key-range-split merge kernel, and the 8-wave x 32-row kernel.
+//
+// Which kernel runs: every product launch runs duo_prefill_w64_kernel (4 waves x 64 rows, duo_prefill_w64.h) since
+// round 2.  The 8-wave kernel below is kept as ONE clean body for two purposes only: the gather (non-transposed-LDS)
+// debug layout behind debug bit 0, and the same-box A/B against the w64 kernel (debug bit 7, DUO_PREFILL_W64=0); the GPU
+// tests run every prefill case on both.  (Its measurement / ablation switches of rounds 1-2 were resolved out of this
+// file in round 3: the object code did not change by a byte.)
 //
 // Replaces flash_attn_func at duo_attn/patch/llama.py:366-372 (first chunk: all
 // heads causal over the chunk) and llama.py:392-421 (later chunks: retrieval
@@ -105,18 +112,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     float mrow = -INFINITY;
     float lsum = 0.f;
     const float c = P.scale_log2e;
-#ifdef DUO_PSUM_MFMA
-    // Row sums on the matrix pipe: one more accumulator fed with an all-ones A operand, osum^T[d][q] =
-    // sum_k 1 * P^T[k][q] — every register of a lane holds its query row's running sum over BOTH 32-key
-    // halves (the MFMA reduces over lanes l and l^32), of the bf16-rounded P that also enters P.V.  Replaces
-    // 32 v_add_f32 per lane and tile by 4 MFMAs on a pipe that is half idle.
-    f32x16 osum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
-    bf16x8 ones_frag;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) ones_frag[r] = F16 ? (short)0x3C00 : (short)0x3F80;
-#endif
 
     // ---- loop invariants: LDS read offsets and DMA lane offsets -----------------
     const uint32_t smem_lds = lds_addr(smem);
@@ -153,25 +148,16 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     for (int kk = 0; kk < 8; ++kk) asm volatile("" ::"v"(qfrag[kk]));
     __builtin_amdgcn_sched_barrier(0);
 
-#ifdef DUO_STATIC_PRIO
-    // static priority for the second-dispatched half of the workgroup (waves 4-7 lose VALU arbitration to the
-    // older half on every segment); no per-cluster flips
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#define DUO_SETPRIO(x)
-#else
 #define DUO_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
     // One tile.  SLOT (= t % 3) is a compile-time constant so that every LDS address of the body is
     // a loop-invariant VGPR plus an immediate: the tile loop is unrolled by the ring depth.
     auto tile_body = [&](auto slot_c, int t) {
         constexpr int SLOT = decltype(slot_c)::value;
         constexpr int SOFF = SLOT * STAGE_BYTES;
         const bool more2 = t + 2 < nT;
-#ifndef DUO_ABLATE_STAGE
         // ring slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, which every wave left through
         // that iteration's barrier
         if (more2) issue_dma(t + 2, (SLOT + 2) % NSTAGE);
-#endif
         const bool inB = t >= nA;
         const int key0 = inB ? (t - nA) * KVBLK : t * KVBLK;   // first key of the tile in its segment
         const int cnt = inB ? min(KVBLK, lenB - key0) : min(KVBLK, lenA - key0);
@@ -188,20 +174,12 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
             // sets); left to hipcc, each step's two ds_read_b128 are issued into the same registers only after
             // the previous step's MFMAs, so every step pays the LDS latency.  asm reads + counted lgkmcnt, as
             // for the V^T reads below.
-#ifndef DUO_K_BUILTIN
             {
                 constexpr int KO = SOFF >= 32768 ? 0 : SOFF;          // 16-bit ds offset field
                 u32x4 kf[2][2];
-#ifdef DUO_ABLATE_KREAD
-                kf[0][0] = kf[0][1] = kf[1][0] = kf[1][1] = u32x4{0x3c003c00u + (uint32_t)lane, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-#endif
-#ifdef DUO_ABLATE_KREAD      /* measurement only: K fragments are whatever the registers hold (no LDS read) */
-#define DUO_K_READ(dst, kk_, bb_) asm volatile("" : "+v"(dst))
-#else
 #define DUO_K_READ(dst, kk_, bb_)                                                                         \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(koff[kk_] + (SOFF >= 32768 ? SOFF : 0)),  \
                  "n"(KO + (bb_) * 8192) : "memory")
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_K_READ(kf[0][0], 0, 0);
                 DUO_K_READ(kf[0][1], 0, 1);
@@ -223,17 +201,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 }
 #undef DUO_K_READ
             }
-#else
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
-                    const bf16x8 kf = *(lds_frag_t *)(uintptr_t)(koff[kk] + SOFF + bb * 8192);
-                    sc[bb] = mfma32x32x16<F16>(kf, qfrag[kk], kk == 0 ? zero16 : sc[bb]);
-                }
-            }
-#endif
             DUO_SETPRIO(0);
             // ---- mask ----------------------------------------------------------
             const bool need_mask = inB ? (key0 + KVBLK - 1 > wq0 + qoff) : (cnt < KVBLK);
@@ -248,10 +215,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     }
             }
             // ---- online softmax (lane = one query row; partner lane^32 holds the other keys)
-#ifdef DUO_MEAS_ALT_MAX
-            // MEASUREMENT ONLY (not overflow-safe): row max / rescale decision on every other tile
-            if (!((t & 1) && t > t_begin + 1 && !need_mask)) {
-#endif
             float t0 = fmaxf(fmaxf(sc[0][0], sc[0][1]), sc[0][2]);
             float t1 = fmaxf(fmaxf(sc[1][0], sc[1][1]), sc[1][2]);
 #pragma unroll
@@ -276,20 +239,13 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 // (a row that has seen no key yet — possible when a key-range split starts on causal tiles
                 // beyond it — keeps m = -inf; -inf - -inf must not reach exp2)
                 const float alpha = mnew == -INFINITY ? 1.f : fast_exp2((mrow - mnew) * c);
-#ifdef DUO_PSUM_MFMA
-                osum[0] *= alpha;      // only register 0 is ever read back
-#else
                 lsum *= alpha;
-#endif
                 mrow = mnew;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             }
-#ifdef DUO_MEAS_ALT_MAX
-            }
-#endif
             const float mc = mrow == -INFINITY ? 0.f : mrow * c;   // all scores -inf: p = exp2(-inf - 0) = 0
             float psum = 0.f;
             bf16x8 pf[4];   // P^T B operands of the four PV k-steps (step = 2*bb + s)
@@ -298,14 +254,8 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 float pv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-#ifdef DUO_ABLATE_SOFTMAX
-                    pv[r] = sc[bb][r] - mc;
-#else
                     pv[r] = fast_exp2(fmaf(sc[bb][r], c, -mc));
-#ifndef DUO_PSUM_MFMA
                     psum += pv[r];
-#endif
-#endif
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -317,15 +267,12 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                     pf[2 * bb + s] = *reinterpret_cast<bf16x8 *>(&w);
                 }
             }
-#ifndef DUO_PSUM_MFMA
             lsum += psum;
-#endif
 
             // ---- O^T += V^T . P^T ----------------------------------------------
             // k-step `step` covers keys 32*bb + 16*s + {4hi..4hi+3, 8+4hi..8+4hi+3}: key quads
             // kq = 4*step + hi and kq + 2; quad kq / dim block blk16 sits at byte (kq*8 + blk16)*128.
             if constexpr (USE_TR) {
-#ifndef DUO_PV_BUILTIN
                 // hand-pipelined: the 8 transpose reads of k-step n+1 are issued before the 4 MFMAs of
                 // k-step n, completion counted with lgkmcnt (asm loads are invisible to hipcc's waitcnt
                 // pass, rule 18: sched_barrier after each wait).
@@ -333,10 +280,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                 const uint32_t va_ = SOFF >= 32768 ? vaddr + SOFF : vaddr;
                 constexpr int VO = SOFF >= 32768 ? 0 : SOFF;
                 u32x2 va[8], vb[8];
-#ifdef DUO_ABLATE_VREAD
-#pragma unroll
-                for (int i_ = 0; i_ < 8; ++i_) va[i_] = vb[i_] = u32x2{0x3c003c00u, 0x3c003c00u + (uint32_t)lane};
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(va, va_, VO, 0);
                 DUO_TR_STEP(vb, va_, VO, 1);
@@ -346,9 +289,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[0], o[db]);
-#ifdef DUO_PSUM_MFMA
-                osum = mfma32x32x16<F16>(ones_frag, pf[0], osum);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(va, va_, VO, 2);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -356,9 +296,6 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[1], o[db]);
-#ifdef DUO_PSUM_MFMA
-                osum = mfma32x32x16<F16>(ones_frag, pf[1], osum);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 DUO_TR_STEP(vb, va_, VO, 3);
                 asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -366,42 +303,12 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(va[2 * db], va[2 * db + 1]), pf[2], o[db]);
-#ifdef DUO_PSUM_MFMA
-                osum = mfma32x32x16<F16>(ones_frag, pf[2], osum);
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int db = 0; db < 4; ++db)
                     o[db] = mfma32x32x16<F16>(join_frag(vb[2 * db], vb[2 * db + 1]), pf[3], o[db]);
-#ifdef DUO_PSUM_MFMA
-                osum = mfma32x32x16<F16>(ones_frag, pf[3], osum);
-#endif
                 DUO_SETPRIO(0);
-#else
-                // alternative (-DDUO_PV_BUILTIN): builtin transpose reads scheduled by hipcc — measured
-                // 1.5 % slower than the hand-pipelined asm reads above (same run, nf=4 past=64K).
-                typedef __attribute__((ext_vector_type(4))) short s16x4;
-                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                DUO_SETPRIO(1);
-#pragma unroll
-                for (int step = 0; step < 4; ++step)
-#pragma unroll
-                    for (int db = 0; db < 4; ++db) {
-                        const uint32_t a0 = vaddr + SOFF + step * 4096 + db * 256;
-                        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)a0);
-                        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(uintptr_t)(a0 + 2048));
-                        bf16x8 vf;
-                        vf[0] = x[0]; vf[1] = x[1]; vf[2] = x[2]; vf[3] = x[3];
-                        vf[4] = y[0]; vf[5] = y[1]; vf[6] = y[2]; vf[7] = y[3];
-                        o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
-                    }
-#ifdef DUO_PSUM_MFMA
-#pragma unroll
-                for (int step = 0; step < 4; ++step) osum = mfma32x32x16<F16>(ones_frag, pf[step], osum);
-#endif
-                DUO_SETPRIO(0);
-#endif
             } else {
                 // debugging aid (duo_set_debug_flags bit 0): scalar LDS gathers instead of the transpose read
                 const char *vst = smem + SOFF + K_TILE_BYTES;
@@ -419,23 +326,15 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
                         }
                         o[db] = mfma32x32x16<F16>(vf, pf[step], o[db]);
                     }
-#ifdef DUO_PSUM_MFMA
-#pragma unroll
-                for (int step = 0; step < 4; ++step) osum = mfma32x32x16<F16>(ones_frag, pf[step], osum);
-#endif
             }
         }
 
         // ---- tile t+1 must have landed (tile t+2 may stay in flight), then ONE barrier:
         //      it publishes tile t+1 and retires every read of ring slot t%3
         __builtin_amdgcn_sched_barrier(0);
-#ifndef DUO_ABLATE_STAGE
         if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-#ifndef DUO_ABLATE_BARRIER
         __builtin_amdgcn_s_barrier();
-#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -446,11 +345,7 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     }
 
     // ---- epilogue: O^T / l -> out[q][qh][d], or the un-normalised partial -> workspace ---------
-#ifdef DUO_PSUM_MFMA
-    lsum = osum[0];                        // already summed over both key halves
-#else
     lsum += __shfl_xor(lsum, 32);
-#endif
     if (ks > 1) {
         const int64_t row = (int64_t)part_id * QBLK + wave * 32 + l31;
         float *wo = P.ws_o + row * DUO_HEAD_DIM;

@@ -207,12 +207,8 @@ __device__ __forceinline__ void stage_dma_full(const TileSrc &s, const DmaLane &
 // LDS-DMA in flight and drains it (s_waitcnt vmcnt(0)) before the first read of every tile, which
 // would undo the counted-vmcnt pipeline.  asm loads are invisible to the waitcnt pass, so their
 // completion is waited for by hand (lgkmcnt) before the MFMAs that consume them.
-#ifdef DUO_ABLATE_VREAD      /* measurement only: V^T fragments are whatever the registers hold (no LDS read) */
-#define DUO_TR_READ(dst, addr, off) asm volatile("" : "+v"(dst))
-#else
 #define DUO_TR_READ(dst, addr, off) \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#endif
 
 // the 8 transpose reads (4 output dim blocks x 2 key quads) of PV k-step `step` (= 2*bb + s)
 #define DUO_TR_STEP(buf, vaddr, ibase, step)                                          \

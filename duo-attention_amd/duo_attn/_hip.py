@@ -34,6 +34,7 @@ class KVSeg(Structure):
         ("head_stride", c_int64),
         ("len", c_int32),
         ("_pad", c_int32),
+        ("batch_stride", c_int64),
     ]
 
 
@@ -73,6 +74,22 @@ class DecodeLayerArgs(Structure):
         ("pos", c_int64), ("rope_scale", c_float), ("rope_theta", c_float), ("scale", c_float), ("_pad2", c_float),
     ]
 
+
+class DecodeBatch(Structure):
+    """``duo_decode_batch``"""
+
+    _fields_ = [
+        ("n_batch", c_int32), ("_pad", c_int32),
+        ("q_batch_stride", c_int64), ("kv_batch_stride", c_int64), ("out_batch_stride", c_int64),
+        ("full_batch_stride", c_int64), ("str_batch_stride", c_int64),
+        ("pos", POINTER(c_int64)),
+    ]
+
+
+_PREFILL_BATCHED = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32,
+                    POINTER(HeadClass), POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p]
+_ROPE_BATCHED = [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
+                 c_int32, POINTER(c_int64), c_float, c_float, c_int32, c_void_p]
 
 _SIGNATURES = {
     "duo_abi_version": (ctypes.c_int, []),
@@ -127,6 +144,28 @@ _SIGNATURES = {
          POINTER(HeadClass), c_float, c_int32, c_void_p],
     ),
     "duo_attn_prefill_workspace_bytes": (c_int64, []),
+    "duo_attn_prefill_batched_bf16": (ctypes.c_int, _PREFILL_BATCHED),
+    "duo_attn_prefill_batched_f16": (ctypes.c_int, _PREFILL_BATCHED),
+    "duo_attn_decode_batched_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
+         POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_decode_layer_batched_bf16": (
+        ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(DecodeBatch), POINTER(c_int32), c_void_p, c_int64, c_void_p],
+    ),
+    "duo_rope_inplace_batched_bf16": (ctypes.c_int, _ROPE_BATCHED),
+    "duo_rope_inplace_batched_f16": (ctypes.c_int, _ROPE_BATCHED),
+    "duo_kv_append_batched_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "duo_stream_compress_batched_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_void_p],
+    ),
     "duo_attn_prefill_ws_bf16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
@@ -208,30 +247,41 @@ def _require_gpu_bf16(t: torch.Tensor, name: str, dtype=torch.bfloat16):
         raise DuoHipError(f"{name} must be {dtype}, got {t.dtype}")
     if t.stride(-1) != 1:
         raise DuoHipError(f"{name}: last (head_dim) dimension must be contiguous")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise DuoHipError(
+            f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: launches go to "
+            "the current device's stream — wrap the call in `with torch.cuda.device(tensor.device):`")
 
 
-def _stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream_ptr(device=None) -> int:
+    """the stream the launch goes to = the current stream of the CURRENT device.  Every wrapper below launches on the
+    device its tensors live on only if that is the current device (the workspaces are keyed the same way), which
+    ``_require_gpu_bf16`` enforces — a process that drives several GPUs switches with ``torch.cuda.device(...)``."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def make_seg(k: Optional[torch.Tensor], v: Optional[torch.Tensor], dtype=torch.bfloat16) -> KVSeg:
-    """k, v: views [T, h, D] (any token/head stride, D contiguous) or None for an empty segment."""
+    """k, v: views [T, h, D] (any token/head stride, D contiguous), or [B, T, h, D] for the batched entry points,
+    or None for an empty segment."""
     s = KVSeg()
-    if k is None or k.shape[0] == 0 or k.shape[1] == 0:
+    batched = k is not None and k.dim() == 4
+    if k is None or k.shape[-3] == 0 or k.shape[-2] == 0:
         s.k = None
         s.v = None
         s.token_stride = 0
         s.head_stride = 0
         s.len = 0
+        s.batch_stride = 0
         return s
     _require_gpu_bf16(k, "k segment", dtype)
     _require_gpu_bf16(v, "v segment", dtype)
-    assert k.dim() == 3 and v.shape == k.shape and k.stride() == v.stride() and k.shape[2] == HEAD_DIM
+    assert k.dim() in (3, 4) and v.shape == k.shape and k.stride() == v.stride() and k.shape[-1] == HEAD_DIM
     s.k = k.data_ptr()
     s.v = v.data_ptr()
-    s.token_stride = k.stride(0)
-    s.head_stride = k.stride(1)
-    s.len = k.shape[0]
+    s.token_stride = k.stride(-3)
+    s.head_stride = k.stride(-2)
+    s.len = k.shape[-3]
+    s.batch_stride = k.stride(0) if batched else 0
     return s
 
 
@@ -259,6 +309,66 @@ def rope_inplace(q: torch.Tensor, k: torch.Tensor, pos0: int, rope_scale: float,
            k.shape[1], q.shape[0], int(pos0), float(rope_scale), float(rope_theta), q.shape[2], _stream_ptr()),
         "duo_rope_inplace_f16" if f16 else "duo_rope_inplace_bf16",
     )
+
+
+def rope_inplace_batched(q: torch.Tensor, k: torch.Tensor, pos0, rope_scale: float, rope_theta: float):
+    """q [B, S, Hq, D], k [B, S, Hkv, D] rotated in place; ``pos0``: one first position per batch row (list) or one int
+    for all rows.  Equal positions = ONE launch for the whole batch."""
+    lib = load_library()
+    f16 = q.dtype == torch.float16
+    _require_gpu_bf16(q, "q", q.dtype if f16 else torch.bfloat16)
+    _require_gpu_bf16(k, "k", q.dtype if f16 else torch.bfloat16)
+    assert q.dim() == 4 and k.dim() == 4 and q.shape[:2] == k.shape[:2]
+    B = q.shape[0]
+    rows = [int(pos0)] * B if not isinstance(pos0, (list, tuple)) else [int(p) for p in pos0]
+    assert len(rows) == B
+    arr = (c_int64 * B)(*rows)
+    fn = lib.duo_rope_inplace_batched_f16 if f16 else lib.duo_rope_inplace_batched_bf16
+    _check(fn(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), q.shape[2], k.data_ptr(), k.stride(0), k.stride(1),
+              k.stride(2), k.shape[2], B, q.shape[1], arr, float(rope_scale), float(rope_theta), q.shape[3],
+              _stream_ptr()), "duo_rope_inplace_batched")
+
+
+def kv_append_batched(k_src, v_src, k_pool, v_pool, dst_row0: int):
+    """src [B, S, h, D], pools [B, T, h, D] views: pool[:, dst_row0:dst_row0+S] = src in one launch."""
+    lib = load_library()
+    if k_src.shape[0] == 0 or k_src.shape[1] == 0 or k_src.shape[2] == 0:
+        return
+    for t, n in ((k_src, "k_src"), (v_src, "v_src"), (k_pool, "k_pool"), (v_pool, "v_pool")):
+        _require_gpu_bf16(t, n)
+    assert k_src.dim() == 4 and k_src.stride() == v_src.stride() and k_pool.stride() == v_pool.stride()
+    assert k_pool.shape[0] == k_src.shape[0] and dst_row0 + k_src.shape[1] <= k_pool.shape[1]
+    _check(
+        lib.duo_kv_append_batched_bf16(
+            k_src.data_ptr(), v_src.data_ptr(), k_src.stride(0), k_src.stride(1), k_src.stride(2), k_pool.data_ptr(),
+            v_pool.data_ptr(), k_pool.stride(0), k_pool.stride(1), k_pool.stride(2), k_src.shape[0], k_src.shape[2],
+            k_src.shape[1], int(dst_row0), k_src.shape[3], _stream_ptr(),
+        ),
+        "duo_kv_append_batched_bf16",
+    )
+
+
+def stream_compress_batched(k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recent: int) -> int:
+    """pools [B, W, h, D], new rows [B, S, h, D]: the sink+recent update of every batch row in one launch."""
+    lib = load_library()
+    new_len = c_int32(0)
+    n_heads = k_pool.shape[2]
+    live = n_heads > 0 and k_new.shape[1] > 0 and k_pool.shape[0] > 0
+    if live:
+        for t, n in ((k_pool, "k_pool"), (v_pool, "v_pool"), (k_new, "k_new"), (v_new, "v_new")):
+            _require_gpu_bf16(t, n)
+        assert k_new.stride() == v_new.stride() and k_pool.stride() == v_pool.stride()
+        assert k_pool.shape[1] >= sink + recent and k_pool.shape[0] == k_new.shape[0]
+    _check(
+        lib.duo_stream_compress_batched_bf16(
+            k_pool.data_ptr() if live else None, v_pool.data_ptr() if live else None, k_pool.stride(0), k_pool.stride(1),
+            k_pool.stride(2), k_new.data_ptr() if live else None, v_new.data_ptr() if live else None, k_new.stride(0),
+            k_new.stride(1), k_new.stride(2), k_pool.shape[0], n_heads, int(cur_len), k_new.shape[1], int(sink),
+            int(recent), HEAD_DIM, byref(new_len), _stream_ptr(),
+        ),
+        "duo_stream_compress_batched_bf16",
+    )
+    return int(new_len.value)
 
 
 def kv_append(k_src, v_src, k_pool, v_pool, dst_row0: int):
@@ -324,6 +434,38 @@ def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def release_workspaces(device=None) -> None:
+    """Free the cached scratch buffers (split-KV partials ~8.5 MB, prefill key-range partials, arrival tickets) of one
+    device, or of all.  They are kept per (device, stream) so that concurrent streams never share partials and a
+    captured graph keeps pointing at live memory: call this only when no graph captured on those streams will be
+    replayed again (a process that rotates through many streams would otherwise accumulate one set per stream)."""
+    idx = None if device is None else (torch.device(device).index if torch.device(device).index is not None
+                                       else torch.cuda.current_device())
+    for cache in (_workspaces, _tickets, _prefill_ws):
+        for key in [k for k in cache if idx is None or k[0] == idx]:
+            del cache[key]
+
+
+def check_decode_tickets(device=None) -> None:
+    """Single-launch decode step (opt-in): every launch must leave the arrival tickets zeroed and the give-up flag clear.
+    One device read-back — call it at sequence boundaries, not per step (``DuoAttentionStaticKVCache.clear`` does when the
+    single-launch step was used).  A set flag means a merger stopped waiting and merged incomplete partials: the tickets
+    are re-armed and DuoHipError is raised."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    bad = []
+    for key, t in _tickets.items():
+        if key[0] == idx and int(t.abs().sum()) != 0:
+            bad.append((key, int(t[-1])))
+            t.zero_()
+    if bad:
+        raise DuoHipError(f"single-launch decode step left its arrival tickets non-zero (stream, give-up flag): {bad}; "
+                          "results of that sequence are not trustworthy — use the default two-launch step")
+
+
+_one_launch_used = False
 
 
 def decode_tickets(device: torch.device) -> torch.Tensor:
@@ -404,6 +546,8 @@ def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, s
         _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
                "duo_decode_layer_bf16")
     else:
+        global _one_launch_used
+        _one_launch_used = True
         _check(lib.duo_decode_step_bf16(byref(a), byref(new_len), None, ws.data_ptr(), ws.numel() * 4,
                                         decode_tickets(q.device).data_ptr(), _stream_ptr()), "duo_decode_step_bf16")
     return int(new_len.value)
@@ -423,6 +567,8 @@ def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k,
         _check(lib.duo_decode_layer_dev_bf16(byref(a), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                              _stream_ptr()), "duo_decode_layer_dev_bf16")
     else:
+        global _one_launch_used
+        _one_launch_used = True
         _check(lib.duo_decode_step_bf16(byref(a), None, dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                         decode_tickets(q.device).data_ptr(), _stream_ptr()), "duo_decode_step_bf16")
 
@@ -469,6 +615,60 @@ def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[
         ),
         "duo_attn_prefill_ws_f16" if q.dtype == torch.float16 else "duo_attn_prefill_ws_bf16",
     )
+
+
+def attention_batched(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
+                      stream: Optional[HeadClass], scale: float):
+    """q, out: [B, S, Hq, D] views; the classes' segments were built from [B, T, h, D] views (``make_seg``).  S > 1:
+    MFMA prefill, S == 1: split-KV decode — one launch (pair) for all batch rows."""
+    lib = load_library()
+    if q.dtype not in (torch.bfloat16, torch.float16):
+        raise DuoHipError(f"q must be bfloat16 or float16, got {q.dtype}")
+    _require_gpu_bf16(q, "q", q.dtype)
+    _require_gpu_bf16(out, "out", q.dtype)
+    assert q.dim() == 4 and out.shape == q.shape
+    B, S = q.shape[0], q.shape[1]
+    fc, sc = (byref(full) if full is not None else None), (byref(stream) if stream is not None else None)
+    if S == 1:
+        if q.dtype != torch.bfloat16:
+            raise DuoHipError("single-token attention is bf16 (static pools) or INT4 (attn_decode_int4)")
+        ws = decode_workspace(q.device, q.shape[2])      # every batch row gets its own share of the partial area
+        _check(lib.duo_attn_decode_batched_bf16(q.data_ptr(), q.stride(0), q.stride(2), out.data_ptr(), out.stride(0),
+                                                out.stride(2), B, int(group), fc, sc, float(scale), q.shape[3],
+                                                ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+               "duo_attn_decode_batched_bf16")
+        return
+    fn = lib.duo_attn_prefill_batched_f16 if q.dtype == torch.float16 else lib.duo_attn_prefill_batched_bf16
+    ws = prefill_workspace(q.device)
+    _check(fn(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), out.data_ptr(), out.stride(0), out.stride(1),
+              out.stride(2), B, S, int(group), fc, sc, float(scale), q.shape[3], ws.data_ptr(), ws.numel() * 4,
+              _stream_ptr()), "duo_attn_prefill_batched")
+
+
+def decode_layer_batched(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
+                         rope_scale, rope_theta, scale) -> int:
+    """The fused decode step of one layer for ALL batch rows in one launch pair: q/out [B, Hq, D]; k/v [B, Hkv, D] new
+    rows; full_k/full_v [B, T, nf, D], str_k/str_v [B, W, ns, D] pool views; ``pos``: one int or one per row."""
+    lib = load_library()
+    B = q.shape[0]
+    a = _decode_layer_args(q[0], k[0], v[0], out[0], n_full, full_k[0] if n_full > 0 else None,
+                           full_v[0] if n_full > 0 else None, full_len, str_k[0] if k.shape[1] - n_full > 0 else None,
+                           str_v[0] if k.shape[1] - n_full > 0 else None, str_len, sink, recent,
+                           pos[0] if isinstance(pos, (list, tuple)) else pos, rope_scale, rope_theta, scale)
+    rows = [int(pos)] * B if not isinstance(pos, (list, tuple)) else [int(p) for p in pos]
+    arr = (c_int64 * B)(*rows)
+    bt = DecodeBatch()
+    bt.n_batch = B
+    bt.q_batch_stride, bt.kv_batch_stride, bt.out_batch_stride = q.stride(0), k.stride(0), out.stride(0)
+    assert v.stride(0) == k.stride(0)
+    bt.full_batch_stride = full_k.stride(0) if n_full > 0 else 0
+    bt.str_batch_stride = str_k.stride(0) if k.shape[1] - n_full > 0 else 0
+    bt.pos = arr
+    ws = decode_workspace(q.device, q.shape[1])
+    new_len = c_int32(0)
+    _check(lib.duo_decode_layer_batched_bf16(byref(a), byref(bt), byref(new_len), ws.data_ptr(), ws.numel() * 4,
+                                             _stream_ptr()), "duo_decode_layer_batched_bf16")
+    return int(new_len.value)
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:

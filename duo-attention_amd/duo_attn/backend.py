@@ -63,6 +63,24 @@ class HipBackend:
         else:
             self._hip.attn_prefill(q, out, group, fc, sc, scale)
 
+    # -- batched forms: the batch row is a grid dimension of the same kernels (one launch for all rows).  Views carry a
+    #    leading batch dimension: q/out [B, S, Hq, D], segments [B, T, h, D]
+    def attention_batched(self, q, out, group: int, full: ClassDesc, stream: ClassDesc, scale: float):
+        fc, sc = self._cls(full, q.dtype), self._cls(stream, q.dtype)
+        self._hip.attention_batched(q, out, group, fc, sc, scale)
+
+    def rope_inplace_batched(self, q, k, pos0, rope_scale: float, rope_theta: float):
+        self._hip.rope_inplace_batched(q, k, pos0, rope_scale, rope_theta)
+
+    def kv_append_batched(self, k_src, v_src, k_pool, v_pool, dst_row0: int):
+        self._hip.kv_append_batched(k_src, v_src, k_pool, v_pool, dst_row0)
+
+    def stream_compress_batched(self, k_pool, v_pool, k_new, v_new, cur_len: int, sink: int, recent: int) -> int:
+        return self._hip.stream_compress_batched(k_pool, v_pool, k_new, v_new, cur_len, sink, recent)
+
+    def decode_layer_batched(self, *args, **kw) -> int:
+        return self._hip.decode_layer_batched(*args, **kw)
+
     # -- a whole decode step of one layer (reference llama.py:332-425, q_len == 1): scan + epilogue launch (or one launch)
     def decode_layer(self, q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink,
                      recent, pos, rope_scale, rope_theta, scale) -> int:

@@ -87,9 +87,12 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
 
     attn_output = torch.empty_like(query_states)
     scale = head_dim ** -0.5
+    batched = bsz > 1 and hasattr(be, "attention_batched")      # one launch for all batch rows (the C ABI's batched forms)
     if q_len == kv_seq_len:
         # initial pre-filling: every head is causal over the chunk (:364-372)
-        for b in range(bsz):
+        if batched:
+            be.attention_batched(query_states, attn_output, groups, (num_kv, 0, None, (key_states, value_states)), None, scale)
+        for b in range(0 if batched else bsz):
             be.attention(query_states[b], attn_output[b], groups,
                          (num_kv, 0, None, (key_states[b], value_states[b])), None, scale)
     else:
@@ -99,7 +102,12 @@ def duo_static_attention_core(query_states, key_states, value_states, kv_cache, 
         ns = num_kv - nf
         pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
         ck, cv = kv_cache.get_streaming_kv(layer_idx)
-        for b in range(bsz):
+        if batched:
+            full = (nf, 0, (pk[:, :past_l], pv[:, :past_l]),
+                    (pk[:, past_l:past_l + q_len], pv[:, past_l:past_l + q_len])) if nf > 0 else None
+            stream = (ns, nf * groups, (ck, cv), (sk, sv)) if ns > 0 else None
+            be.attention_batched(query_states, attn_output, groups, full, stream, scale)
+        for b in range(0 if batched else bsz):
             full = (nf, 0, (pk[b, :past_l], pv[b, :past_l]),
                     (pk[b, past_l:past_l + q_len], pv[b, past_l:past_l + q_len])) if nf > 0 else None
             stream = (ns, nf * groups, (ck[b], cv[b]), (sk[b], sv[b])) if ns > 0 else None
@@ -187,6 +195,12 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
         be.decode_layer_dev(query_states[0, 0], key_states[0, 0], value_states[0, 0], attn_output[0, 0], nf,
                             pk[0], pv[0], cur, sk[0], sv[0], str_len, kv_cache.sink_size, kv_cache.recent_size,
                             pos_rows[0], rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
+    elif bsz > 1 and hasattr(be, "decode_layer_batched"):
+        # every batch row in ONE launch pair (grid-level batch rows; rows at different positions fall back to a launch
+        # pair per row inside the library)
+        new_len = be.decode_layer_batched(query_states[:, 0], key_states[:, 0], value_states[:, 0], attn_output[:, 0], nf,
+                                          pk, pv, cur, sk, sv, str_len, kv_cache.sink_size, kv_cache.recent_size,
+                                          pos_rows, rope_scale, rope_theta, head_dim ** -0.5)
     else:
         for b in range(bsz):
             new_len = be.decode_layer(query_states[b, 0], key_states[b, 0], value_states[b, 0], attn_output[b, 0], nf,

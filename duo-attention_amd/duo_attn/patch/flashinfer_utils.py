@@ -46,6 +46,9 @@ def apply_rope_inplace(q: torch.Tensor, k: torch.Tensor, offsets, rope_scale: fl
     else:
         offs = [int(offsets)] * bsz
     be = get_backend()
+    if bsz > 1 and hasattr(be, "rope_inplace_batched"):
+        be.rope_inplace_batched(q, k, offs, rope_scale, rope_theta)     # one launch when the rows share their position
+        return q, k
     for b in range(bsz):
         be.rope_inplace(q[b], k[b], offs[b], rope_scale, rope_theta)
     return q, k

@@ -97,7 +97,11 @@ class DuoAttentionStaticKVCache:
             )
         be = get_backend()
         kp, vp = self.full_key_states_list[layer_idx], self.full_value_states_list[layer_idx]
-        for b in range(full_key_states.shape[0]):
+        nb = full_key_states.shape[0]
+        if nb > 1 and hasattr(be, "kv_append_batched"):      # all batch rows in one launch
+            be.kv_append_batched(full_key_states, full_value_states, kp, vp, cur)
+            nb = 0
+        for b in range(nb):
             be.kv_append(full_key_states[b], full_value_states[b], kp[b], vp[b], cur)
         self.kv_seq_len_list[layer_idx] += incoming
         return self.get_full_kv(layer_idx)
@@ -135,7 +139,11 @@ class DuoAttentionStaticKVCache:
         be = get_backend()
         kp, vp = self.streaming_key_states_list[layer_idx], self.streaming_value_states_list[layer_idx]
         if kp.shape[2] > 0:
-            for b in range(new_key_states.shape[0]):
+            nb = new_key_states.shape[0]
+            if nb > 1 and hasattr(be, "stream_compress_batched"):      # all batch rows in one launch
+                be.stream_compress_batched(kp, vp, new_key_states, new_value_states, cur, self.sink_size, self.recent_size)
+                nb = 0
+            for b in range(nb):
                 be.stream_compress(kp[b], vp[b], new_key_states[b], new_value_states[b], cur,
                                    self.sink_size, self.recent_size)
         self.streaming_kv_seq_len_list[layer_idx] = min(cur + new_key_states.shape[1], W)
@@ -171,6 +179,10 @@ class DuoAttentionStaticKVCache:
         for i in range(self.num_layers):
             self.kv_seq_len_list[i] = 0
             self.streaming_kv_seq_len_list[i] = 0
+        be = get_backend()
+        if getattr(getattr(be, "_hip", None), "_one_launch_used", False) and self.device.type == "cuda":
+            # the opt-in single-launch decode step: a sequence boundary is where its arrival tickets get audited
+            be._hip.check_decode_tickets(self.device)
 
     def evict_last(self, num_tokens):
         for i in range(self.num_layers):

@@ -33,12 +33,34 @@ def test_header_symbols_are_exported_and_typed():
     assert b"head_dim" in lib.duo_error_string(-2)
 
 
-def test_struct_layout_matches_header():
+def test_struct_layout_matches_header(tmp_path):
+    """every struct that crosses the boundary: sizeof and every field offset of the ctypes mirror == what a C compiler
+    makes of include/duo_attn_hip.h (a probe program compiled with gcc against the header itself)"""
+    import shutil
+    import subprocess
+
     from duo_attn import _hip
 
-    assert ctypes.sizeof(_hip.KVSeg) == 40          # 2 ptr + 2 int64 + 2 int32
-    assert ctypes.sizeof(_hip.HeadClass) == 8 + 2 * 40
-    assert _hip.HeadClass.segA.offset == 8 and _hip.HeadClass.segB.offset == 48
+    pairs = {"duo_kv_seg": _hip.KVSeg, "duo_head_class": _hip.HeadClass, "duo_int4_pool": _hip.Int4Pool,
+             "duo_decode_layer_args": _hip.DecodeLayerArgs, "duo_decode_batch": _hip.DecodeBatch}
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0; }")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run([gcc, "-std=c11", "-o", str(exe), str(src)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert ctypes.sizeof(_hip.KVSeg) == 48 and _hip.HeadClass.segB.offset == 8 + 48      # ABI v2: + batch_stride
 
 
 def test_argument_errors_without_gpu():

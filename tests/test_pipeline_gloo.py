@@ -114,14 +114,14 @@ def _worker(rank, world, port, counts, chunks, q, subgroups=None):
 
 
 def test_pipelines_on_subgroups_address_global_ranks():
-    """Two independent 2-stage pipelines inside one 4-rank world, on the sub-groups {1, 3} and {2, 0}: stage indices are
+    """Two independent 2-stage pipelines inside one 4-rank world, on the sub-groups {1, 3} and {0, 2}: stage indices are
     group-relative, the point-to-point peers torch.distributed wants are GLOBAL ranks (LayerPipeline.peer)."""
     counts, chunks = [1, 0, 2, 1], [9, 7, 5, 1, 1, 1]
     expected = _single_process(counts, chunks)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    subgroups = [[1, 3], [2, 0]]
+    subgroups = [[1, 3], [0, 2]]      # (new_group orders a group's ranks ascending)
     procs = [ctx.Process(target=_worker, args=(r, 4, port, counts, chunks, q, subgroups)) for r in range(4)]
     for p in procs:
         p.start()

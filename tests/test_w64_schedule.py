@@ -120,3 +120,39 @@ def test_gap_loads_are_balanced():
     loads = [sum(op.n for op in stmt if not op.text.startswith("@MFMA@")) for stmt in gen.build_gaps("STEADY")]
     assert sum(loads) == 330
     assert max(loads) <= 8 and sorted(loads)[4] >= 4      # the two FIN gaps carry 7-8, the gap before block A's FIN 1
+
+
+def test_xmap_is_a_bijection():
+    """XCD-aware block order of the retrieval class (duo_prefill_w64_kernel.inc + the launcher in duo_prefill.hip), restated:
+    every (q tile, kv head, q-head-in-group) exactly once, the padded blocks of the last period leave, and an XCD
+    (block id % 8) sees at most two kv heads."""
+    def blocks(nf, G, nqt):
+        row_items = nf * G
+        rows = 1
+        while (rows * row_items) % 8:
+            rows *= 2
+        periods = (nqt + rows - 1) // rows
+        q = rows * row_items // 8
+        seen, per_xcd = set(), {}
+        for b in range(periods * rows * row_items):
+            x, r = b & 7, b >> 3
+            per, j = divmod(r, q)
+            w = x * q + j
+            kvh, e = divmod(w, rows * G)
+            row, g = divmod(e, G)
+            rank = per * rows + row
+            if rank >= nqt:
+                continue
+            item = (nqt - 1 - rank, kvh, g)
+            assert 0 <= kvh < nf and item not in seen
+            seen.add(item)
+            per_xcd.setdefault(x, set()).add(kvh)
+        assert len(seen) == nf * G * nqt
+        return max(len(v) for v in per_xcd.values())
+
+    for nf in range(1, 9):
+        for G in (1, 2, 3, 4, 6, 8):
+            for nqt in (1, 2, 3, 7, 64, 125):
+                heads = blocks(nf, G, nqt)
+                if G == 4 and nqt == 64:
+                    assert heads <= 2
