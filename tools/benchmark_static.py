@@ -84,6 +84,14 @@ def run(args, quiet=False):
     # (sparsify_attention_heads then takes the global quantile exactly as the reference does)
     heads = np.random.RandomState(0).rand(L, Hkv)
     heads, sparsity = sparsify_attention_heads(heads, None, args.sparsity)
+    if getattr(args, "pattern", None):
+        # per-layer retrieval-head counts of a shipped pattern (bench.PATTERNS: recorded from the reference's TSVs)
+        import bench
+
+        counts = bench.PATTERNS[args.pattern][0]
+        assert len(counts) == L and max(counts) <= Hkv
+        heads = np.array([[1.0] * c + [0.0] * (Hkv - c) for c in counts])
+        sparsity = 1.0 - sum(counts) / (L * Hkv)
     say(f"True Sparsity: {sparsity}")
     mod = __import__("duo_attn.patch." + ("mistral" if is_mistral else "llama"), fromlist=["x"])
     enable = getattr(mod, f"enable_{'mistral' if is_mistral else 'llama'}_duo_attention_static_kv_cache_eval")
@@ -297,6 +305,8 @@ def parse(argv=None):
     ap.add_argument("--max_length", type=int, default=131072)
     ap.add_argument("--prefilling_chunk_size", type=int, default=16384)
     ap.add_argument("--sparsity", type=float, default=0.5)
+    ap.add_argument("--pattern", default=None, help="per-layer retrieval-head counts of a shipped pattern (a key of "
+                    "bench.PATTERNS, e.g. mistral-7b-v0.2@raw) instead of a synthetic matrix at --sparsity")
     ap.add_argument("--sink_size", type=int, default=128)
     ap.add_argument("--recent_size", type=int, default=256)
     ap.add_argument("--prefill_steps", type=int, default=2)
