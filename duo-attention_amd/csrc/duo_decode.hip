@@ -229,37 +229,33 @@ __device__ __forceinline__ void duo_decode_merge_task(const float *ws_ml, const 
 
     float m = kNegSentinel, Lsum = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    int s = sl;
-    for (; s + 96 < splits; s += 128) {       // 4 splits (stride 32) per step, all 8 loads in flight together
+    // 4 splits (stride 32) per step with all 8 loads in flight together, for EVERY split count: the usual 60-odd splits of a
+    // retrieval head are ONE round trip per thread (round 2 walked a head with fewer than 128 splits one split at a time —
+    // two dependent round trips at 63 splits, most of the launch).  Lanes past the end re-read a valid split with weight 0.
+    for (int s = sl; s < splits; s += 128) {
         u32x2 w[4];
         f32x4 a[4];
+        bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            w[u] = ld_ml(s + 32 * u);
-            a[u] = ld_ac(s + 32 * u);
+            ok[u] = s + 32 * u < splits;
+            const int si = ok[u] ? s + 32 * u : s;
+            w[u] = ld_ml(si);
+            a[u] = ld_ac(si);
         }
         float mx = m;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, __uint_as_float(w[u].x));
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, ok[u] ? __uint_as_float(w[u].x) : kNegSentinel);
         const float f = fast_exp2(m - mx);
         Lsum *= f;
         o = o * f;
         m = mx;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float wu = fast_exp2(__uint_as_float(w[u].x) - m);
+            const float wu = ok[u] ? fast_exp2(__uint_as_float(w[u].x) - m) : 0.f;
             Lsum = fmaf(__uint_as_float(w[u].y), wu, Lsum);
             o = o + a[u] * wu;
         }
-    }
-    for (; s < splits; s += 32) {
-        const u32x2 w = ld_ml(s);
-        const f32x4 a = ld_ac(s);
-        const float mx = fmaxf(m, __uint_as_float(w.x));
-        const float f = fast_exp2(m - mx), wu = fast_exp2(__uint_as_float(w.x) - mx);
-        Lsum = fmaf(__uint_as_float(w.y), wu, Lsum * f);
-        o = o * f + a * wu;
-        m = mx;
     }
     if (dq == 0) sm[sl] = m;
     slm[sl][dq] = Lsum;

@@ -890,32 +890,55 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
     const int d0 = blockIdx.y * 32 + dq * 4;
     const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
     const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
-    __shared__ float red[4];
+    __shared__ float sm[32];
     __shared__ float slm[32][8];
     __shared__ f32x4 so[32][8];
-    float M = kNegSentinelI4;
-    for (int s = threadIdx.x; s < splits; s += 256) M = fmaxf(M, ml[s * 2]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = M;
-    __syncthreads();
-    M = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float Lsum = 0.f;
+    // single pass (as the bf16 merge, duo_decode_merge_task): every split lane folds its own splits against its own
+    // running maximum, 4 splits per step with all 8 loads in flight; the 32 lanes are combined through LDS with their maxima
+    float m = kNegSentinelI4, Lsum = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int s = sl; s < splits; s += 32) {
-        const float wu = fast_exp2(ml[s * 2] - M);
-        Lsum = fmaf(ml[s * 2 + 1], wu, Lsum);
-        o = o + *reinterpret_cast<const f32x4 *>(ac + (int64_t)s * DUO_HEAD_DIM) * wu;
+    for (int s = sl; s < splits; s += 128) {
+        float wm[4], wl[4];
+        f32x4 a[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = s + 32 * u < splits;
+            const int si = ok[u] ? s + 32 * u : s;
+            wm[u] = ml[si * 2];
+            wl[u] = ml[si * 2 + 1];
+            a[u] = *reinterpret_cast<const f32x4 *>(ac + (int64_t)si * DUO_HEAD_DIM);
+        }
+        float mx = m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mx = fmaxf(mx, ok[u] ? wm[u] : kNegSentinelI4);
+        const float f = fast_exp2(m - mx);
+        Lsum *= f;
+        o = o * f;
+        m = mx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wu = ok[u] ? fast_exp2(wm[u] - m) : 0.f;
+            Lsum = fmaf(wl[u], wu, Lsum);
+            o = o + a[u] * wu;
+        }
     }
+    if (dq == 0) sm[sl] = m;
     slm[sl][dq] = Lsum;
     so[sl][dq] = o;
     __syncthreads();
     if (sl == 0) {
+        float M = sm[0];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) M = fmaxf(M, sm[i]);
         float LL = 0.f;
         f32x4 oo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { LL += slm[i][dq]; oo = oo + so[i][dq]; }
+        for (int i = 0; i < 32; ++i) {
+            const float f = fast_exp2(sm[i] - M);      // lanes without a split: exp2(-huge) = 0
+            LL = fmaf(slm[i][dq], f, LL);
+            oo = oo + so[i][dq] * f;
+        }
         const float inv = 1.f / LL;
         __half h4[4] = {__float2half(oo.x * inv), __float2half(oo.y * inv), __float2half(oo.z * inv),
                         __float2half(oo.w * inv)};

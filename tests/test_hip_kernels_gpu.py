@@ -751,3 +751,46 @@ def test_row_blocks_equal_whole_chunk_on_gpu():
                          (c0.streaming_key_states_list, c1.streaming_key_states_list, m),
                          (c0.streaming_value_states_list, c1.streaming_value_states_list, m)):
             assert torch.equal(x[l][:, :ln], y[l][:, :ln])
+
+
+# ----------------------------------------------------------------------------- the fallback scan kernel stays tested
+@pytest.mark.parametrize("case", [DECODE_CASES[2], DECODE_CASES[5], DECODE_CASES[8], DECODE_CASES[10], DECODE_CASES[12]])
+def test_decode_on_the_long_prologue_scan_kernel(case):
+    """duo_decode_split_kernel (round 2's scan) is what a launch falls back to when a stride does not fit the packed
+    argument fields of duo_decode_scan_kernel; debug bit 9 selects it for any launch."""
+    h = _hip()
+    group, nf, ns, n_full, n_stream = case
+    h.set_debug_flags(512)
+    try:
+        out, ref, bud = _attention_case(1, group, nf, ns, n_full, n_stream, True, seed=hash(case) % 1000 + 1)
+    finally:
+        h.set_debug_flags(0)
+    attn_close(out, ref, f"decode (long-prologue kernel) {case}", bud)
+
+
+def test_decode_falls_back_when_a_stride_does_not_fit_the_packed_fields():
+    """q rows 70 000 elements apart (> 16 bits): the launcher must take the general kernel, with the same result as the
+    short-prologue kernel on a compact copy of the same q."""
+    from duo_attn.backend import HipBackend
+
+    g = torch.Generator().manual_seed(77)
+    group, nf, ns, N = 4, 2, 2, 3000
+    Hq = (nf + ns) * group
+    wide = torch.zeros(Hq, 70000, dtype=torch.bfloat16, device=DEV)
+    wide[:, :D] = _rand((Hq, D), g).to(DEV)
+    q_wide = wide[:, :D][None]                      # [1, Hq, D] view, head stride 70 000
+    q_compact = q_wide.contiguous()
+    fk, fv, fkd, fvd = _make_pool(N, nf, g, True)
+    sk, sv, skd, svd = _make_pool(64, ns, g, True)
+    kn, vn = _rand((1, nf + ns, D), g).to(DEV), _rand((1, nf + ns, D), g).to(DEV)
+    full = (nf, 0, (fkd, fvd), (kn[:, :nf], vn[:, :nf]))
+    stream = (ns, nf * group, (skd, svd), (kn[:, nf:], vn[:, nf:]))
+    be = HipBackend()
+    outs = []
+    for q in (q_wide, q_compact):
+        out = torch.full((1, Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        be.attention(q, out, group, full, stream, D ** -0.5)
+        outs.append(out)
+    assert torch.isfinite(outs[0].float()).all()
+    # same partition, same arithmetic per workgroup up to the fold order of the epilogue (shared): equal to the bf16 ulp
+    assert (outs[0].float() - outs[1].float()).abs().max() <= 2.0 ** -7 * outs[1].float().abs().max()
