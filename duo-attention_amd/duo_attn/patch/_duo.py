@@ -415,7 +415,13 @@ def _reorder_layer(module, layer_full_attention_heads):
 def _layer_rows(model, full_attention_heads):
     """the head-pattern rows of the layers this process holds (all of them, or a pipeline stage's block)"""
     pp = getattr(model, "_duo_pp", None)
-    return pp.local_rows(full_attention_heads) if pp is not None else full_attention_heads
+    if pp is not None:
+        full_attention_heads = pp.local_rows(full_attention_heads)
+    if getattr(model, "_duo_tp", None) is not None:      # head-parallel shard: this rank's heads of every row
+        from ..tp import tp_local_rows
+
+        full_attention_heads = tp_local_rows(model, full_attention_heads)
+    return full_attention_heads
 
 
 def enable_duo_attention_eval(model, full_attention_heads, sink_size, recent_size):
@@ -423,6 +429,10 @@ def enable_duo_attention_eval(model, full_attention_heads, sink_size, recent_siz
     enable_tuple_kv_cache_for_model(model)
     device = next(model.parameters()).device
     dtype = next(model.parameters()).dtype
+    if getattr(model, "_duo_tp", None) is not None:
+        from ..tp import tp_local_rows
+
+        full_attention_heads = tp_local_rows(model, full_attention_heads)
     for idx, layer in enumerate(model.model.layers):
         module = layer.self_attn
         layer_heads = torch.as_tensor(full_attention_heads[idx]).to(device=device, dtype=dtype)

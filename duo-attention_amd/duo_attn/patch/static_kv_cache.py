@@ -43,6 +43,10 @@ class DuoAttentionStaticKVCache:
         pp = getattr(model, "_duo_pp", None)
         if pp is not None:
             full_attention_heads = pp.local_rows(full_attention_heads)
+        if getattr(model, "_duo_tp", None) is not None:     # head-parallel shard: a whole-model pattern is sliced to this rank's heads
+            from ..tp import tp_local_rows
+
+            full_attention_heads = tp_local_rows(model, full_attention_heads)
         self.num_layers = len(full_attention_heads) if pp is not None else model.config.num_hidden_layers
         self.num_heads = model.config.num_attention_heads
         self.num_kv_heads = model.config.num_key_value_heads

@@ -160,6 +160,24 @@ def shard_model_for_tp(model, full_attention_heads, rank: Optional[int] = None, 
     return local
 
 
+def tp_local_rows(model, full_attention_heads):
+    """Head-pattern rows for THIS rank of a model sharded with ``shard_model_for_tp`` / ``to_device(enable_tp=True)``: a
+    whole-model pattern ``[L, Hkv]`` (original kv-head order) is sliced through the rank's head assignment — the rank's
+    heads come retrieval-first BY THE PATTERN THE MODEL WAS SHARDED WITH; with another pattern the rows are simply the
+    rank's heads in its local order (the enablers' weight reorder then sorts them).  Rows that already have the local
+    width pass through."""
+    info = getattr(model, "_duo_tp", None)
+    if info is None:
+        return full_attention_heads
+    rows = [np.asarray(torch.as_tensor(r).float().cpu() if torch.is_tensor(r) else r, dtype=float).reshape(-1)
+            for r in full_attention_heads]
+    if not rows or rows[0].shape[0] != info["num_kv_heads"]:
+        return full_attention_heads
+    if len(rows) != len(info["assign"]):
+        raise ValueError(f"{len(rows)} pattern rows for {len(info['assign'])} layers")
+    return np.stack([rows[l][info["assign"][l][info["rank"]]] for l in range(len(rows))])
+
+
 def gather_full_attention_heads(model, local_heads):
     """``local_heads``: this rank's per-layer buffers ``[Hkv / tp]`` (rank-local order, retrieval heads first).
     Returns the whole model's per-layer ``[Hkv]`` tensors in the ORIGINAL kv-head order, identical on every rank —

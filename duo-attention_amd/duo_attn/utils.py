@@ -143,7 +143,7 @@ def balanced_layer_split(costs, num_stages: int):
 
 
 def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_map=True, even_split_layers=True,
-              pp_handoff=None):
+              pp_handoff=None, full_attention_heads=None):
     """Single device: ``model.to(device)``.  ``enable_pp`` with a device list is the layer pipeline of reference
     utils.py:228-283 — as ONE PROCESS PER GPU (launch with torch.distributed.run): this rank keeps its contiguous
     block of decoder layers (embedding on the first stage, norm + lm_head on the last) on ``device[rank]`` and
@@ -157,12 +157,33 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
         if len(device) == 1:
             return model.to(f"cuda:{device[0]}")
         if enable_tp:
-            raise NotImplementedError(
-                "The reference shards an already patched model with the third-party `tensor_parallel` package "
-                "(utils.py:206-227).  Here tensor parallelism is one process per GPU: call "
-                "duo_attn.tp.shard_model_for_tp(model, full_attention_heads) on every rank BEFORE "
-                "enable_*_duo_attention*_eval, and pass the pattern it returns to the enabler and the KV cache."
-            )
+            # Reference utils.py:206-227 shards with the third-party `tensor_parallel` package inside one process; here it
+            # is one process per GPU (launch with torch.distributed.run): this rank keeps Hkv / tp kv heads of every layer
+            # (duo_attn.tp.shard_model_for_tp).  Call it BEFORE enable_*_duo_attention*_eval — the enablers and the KV cache
+            # then take the WHOLE-model pattern and slice it to this rank's heads themselves.  `full_attention_heads`
+            # (optional, the pattern the model will run with) lets the split deal the retrieval heads evenly over the
+            # ranks; without it rank d takes the d-th contiguous block of kv heads, as the reference's split does.
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                raise RuntimeError(
+                    "Tensor parallelism = one process per GPU: launch with torch.distributed.run "
+                    "(--nproc-per-node = number of devices); each rank then calls to_device(model, devices, enable_tp=True)."
+                )
+            if dist.get_world_size() != len(device):
+                raise ValueError(f"{len(device)} devices for {dist.get_world_size()} ranks")
+            if any(hasattr(l.self_attn, "full_attention_heads") for l in model.model.layers):
+                raise ValueError("to_device(enable_tp=True) must run BEFORE the DuoAttention enabler (the shard keeps "
+                                 "whole kv heads in their original order; the enabler then reorders this rank's heads)")
+            from .tp import shard_model_for_tp
+
+            dev = device[dist.get_rank()]
+            model.to(dev if isinstance(dev, str) else f"cuda:{dev}")
+            cfg = model.config
+            heads = full_attention_heads if full_attention_heads is not None else \
+                np.zeros((cfg.num_hidden_layers, cfg.num_key_value_heads))
+            shard_model_for_tp(model, heads)
+            return model
         if enable_pp:
             import torch.distributed as dist
 

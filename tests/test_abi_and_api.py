@@ -190,15 +190,15 @@ def test_pattern_files_round_trip(tmp_path):
 
 
 def test_to_device_contract():
-    """single device passes through; a device list without a mode is an error; TP points at duo_attn.tp"""
+    """single device passes through; a device list without a mode is an error; TP / PP are one process per GPU"""
     from duo_attn.utils import to_device
 
     m = torch.nn.Linear(2, 2)
     assert to_device(m, "cpu") is m
     with pytest.raises(ValueError):
         to_device(m, [0, 1])
-    with pytest.raises(NotImplementedError, match="shard_model_for_tp"):
-        to_device(m, [0, 1], enable_tp=True)
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        to_device(m, [0, 1], enable_tp=True)          # (the sharding itself: tests/test_tp_gloo.py)
 
 
 def test_generated_prefill_schedule_is_in_sync(tmp_path):

@@ -48,7 +48,7 @@ def _run(model, heads, max_size=64):
     return torch.cat(outs, 1)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="explicit"):
     _paths()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -59,6 +59,20 @@ def _worker(rank, world, port, q):
 
         backend._set_backend_for_testing(OracleBackend(round_p=False))
         model = _tiny()
+        if mode != "explicit":
+            # the reference's call shape (utils.py:206-227) as a drop-in: shard first, then hand the WHOLE-model pattern to
+            # the enabler and the cache — they slice it to this rank's heads.  "balanced": the split knows the pattern;
+            # "contiguous": it does not (rank d = the d-th block of kv heads, like the reference's tensor_parallel split)
+            from duo_attn.utils import to_device
+
+            to_device(model, ["cpu"] * world, enable_tp=True, full_attention_heads=HEADS if mode == "balanced" else None)
+            if mode == "contiguous":
+                assert model._duo_tp["assign"][0] == [[0, 1], [2, 3]]
+            out = _run(model, HEADS)
+            if rank == 0:
+                q.put(out.numpy())
+            dist.barrier()
+            return
         local = shard_model_for_tp(model, HEADS)
         assert local.shape == (3, 2) and (np.diff(local, axis=1) <= 0).all()     # retrieval heads first
         out = _run(model, local)
@@ -106,6 +120,31 @@ def test_tp2_equals_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     # fp32 model; the two-way sums of the all-reduces change the rounding order only
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("mode", ["balanced", "contiguous"])
+def test_to_device_enable_tp_is_a_drop_in(mode):
+    """to_device(model, devices, enable_tp=True) + the whole-model pattern handed to the enabler and the KV cache."""
+    _paths()
+    from duo_attn import backend
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend(round_p=False))
+    try:
+        want = _run(_tiny(), HEADS).numpy()
+    finally:
+        backend._set_backend_for_testing(None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
     assert np.allclose(got, want, rtol=2e-4, atol=2e-4), np.abs(got - want).max()
 
 
