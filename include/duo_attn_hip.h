@@ -29,6 +29,12 @@
  *   duo_rmsnorm_bf16          flashinfer.norm.rmsnorm, flashinfer_utils.py:9-16
  *   duo_int4_quantize / duo_int4_dequantize_f16 / duo_int4_stream_compress /
  *   duo_attn_decode_int4_f16  demo/quantize_int4.cu:9-178, demo/int4_kv.py:261-492
+ *   *_batched_*               the same calls with the reference's batch dimension
+ *                             (static_kv_cache.py:60-125; flash_attn_func batches natively):
+ *                             the batch row is a grid dimension, one launch for all rows
+ *
+ * ABI version 2 (round 3): duo_kv_seg gained `batch_stride`, the `_batched` entry points were
+ * added, duo_int4_dequantize_f16 / duo_attn_decode_int4_f16 take a `fused` flag.
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
