@@ -199,11 +199,19 @@ class DuoAttentionStaticINT4KVCache:
         G = self.num_kv_groups
         scale = self.head_dim ** -0.5 if scale is None else scale
         out = torch.empty_like(query_states)
+        batched = B > 1 and hasattr(be, "attention_batched")      # fp16 prefill: one launch for all batch rows
         if n == S:      # first chunk
-            for b in range(B):
+            if batched:
+                be.attention_batched(query_states, out, G, (nf + ns, 0, None, (key_states, value_states)), None, scale)
+            for b in range(0 if batched else B):
                 be.attention(query_states[b], out[b], G, (nf + ns, 0, None, (key_states[b], value_states[b])), None, scale)
             return out
         fk, fv, sk, sv = self.get(layer_idx)
+        if batched:
+            full = (nf, 0, (fk[:, :n - S], fv[:, :n - S]), (fk[:, n - S:n], fv[:, n - S:n])) if nf else None
+            stream = (ns, nf * G, (sk[:, :m - S], sv[:, :m - S]), (sk[:, m - S:m], sv[:, m - S:m])) if ns else None
+            be.attention_batched(query_states, out, G, full, stream, scale)
+            return out
         for b in range(B):
             full = (nf, 0, (fk[b, :n - S], fv[b, :n - S]), (fk[b, n - S:n], fv[b, n - S:n])) if nf else None
             stream = (ns, nf * G, (sk[b, :m - S], sv[b, :m - S]), (sk[b, m - S:m], sv[b, m - S:m])) if ns else None

@@ -324,3 +324,44 @@ def test_int4_cache_chunked_prefill_attention():
             if h["sk"].shape[0] > W:        # the reference keeps sink + recent rows of the streaming pool
                 h["sk"] = torch.cat([h["sk"][:sink], h["sk"][-recent:]])
                 h["sv"] = torch.cat([h["sv"][:sink], h["sv"][-recent:]])
+
+
+@gpu
+def test_int4_cache_batch_rows_equal_single_rows():
+    """B = 2 through DuoAttentionStaticINT4KVCache (put / chunked prefill attention in ONE batched fp16 launch / decode /
+    compress) == each row through its own B = 1 cache: packed pools bit for bit, prefill outputs bit for bit with the
+    key-range split disabled (same tiles), decode outputs bit for bit (per-row launches either way)."""
+    from duo_attn import _hip
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+
+    counts, Hq, Hkv, sink, recent, chunk = [1, 3, 0, 4], 16, 4, 16, 48, 300
+    heads = heads_from_counts(counts, Hkv)
+    model = ShapeModel(len(counts), Hq, Hkv, 128, device=DEV, dtype=torch.float16)
+    both = DuoAttentionStaticINT4KVCache(model, heads, 2, 900, sink, recent, chunk)
+    solo = [DuoAttentionStaticINT4KVCache(model, heads, 1, 900, sink, recent, chunk) for _ in range(2)]
+    g = torch.Generator().manual_seed(9)
+    _hip.set_debug_flags(256)
+    try:
+        for S in (300, 257, 1, 1):
+            for l in range(len(counts)):
+                q = torch.randn(2, S, Hq, 128, generator=g).to(torch.float16).to(DEV)
+                k = torch.randn(2, S, Hkv, 128, generator=g).to(torch.float16).to(DEV)
+                v = torch.randn(2, S, Hkv, 128, generator=g).to(torch.float16).to(DEV)
+                outs = []
+                for cache, sl in [(both, slice(0, 2))] + [(solo[b], slice(b, b + 1)) for b in range(2)]:
+                    past = cache.kv_seq_len_list[l]
+                    cache.put(l, k[sl], v[sl], dequantize=False)
+                    o = cache.decode_attention(l, q[sl]) if (S == 1 and past > 0) else cache.prefill_attention(l, q[sl], k[sl], v[sl])
+                    cache.compress(l)
+                    outs.append(o)
+                assert torch.equal(outs[0][0:1], outs[1]) and torch.equal(outs[0][1:2], outs[2]), (S, l)
+    finally:
+        _hip.set_debug_flags(0)
+    for l in range(len(counts)):
+        n, m = both.kv_seq_len_list[l], both.streaming_kv_seq_len_list[l]
+        for b in range(2):
+            assert (solo[b].kv_seq_len_list[l], solo[b].streaming_kv_seq_len_list[l]) == (n, m)
+            for name, rows in (("full_key_caches", n), ("full_value_caches", n), ("streaming_key_caches", m), ("streaming_value_caches", m)):
+                A, Bc = getattr(both, name)[l], getattr(solo[b], name)[l]
+                assert torch.equal(A.quantized_data[b, :rows], Bc.quantized_data[0, :rows]), (name, l, b)
+                assert torch.equal(A.scale_zero[b, :rows], Bc.scale_zero[0, :rows]), (name, l, b)
