@@ -68,6 +68,7 @@ struct QuantParams {
     __half *sz;                 // (scale, zero) pool, row (t, h) at sz + (t*q_ts + h*q_hs) * 2
     int64_t q_ts, q_hs;         // ROW strides of the pool
     int32_t n_tokens, n_heads, dst_row0;
+    int64_t s_bs, q_bs;         // batched launch (grid.y = batch row): elements / pool rows between batch rows
 };
 
 // 16 lanes per (token, head) row, 16 rows per 256-thread block
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void duo_int4_quantize_kernel(const QuantParam
     const int h = (int)(r % P.n_heads);
     const int64_t t = r / P.n_heads;
     float x[8];
-    load8_as_f32<BF16>((const char *)P.src + (t * P.s_ts + (int64_t)h * P.s_hs + sub * 8) * 2, x);
+    load8_as_f32<BF16>((const char *)P.src + ((int64_t)blockIdx.y * P.s_bs + t * P.s_ts + (int64_t)h * P.s_hs + sub * 8) * 2, x);
     float mn = x[0], mx = x[0];
 #pragma unroll
     for (int e = 1; e < 8; ++e) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void duo_int4_quantize_kernel(const QuantParam
         packed |= qi << (8 * (e >> 1) + ((e & 1) ? 0 : 4));
     }
     if (live) {
-        const int64_t drow = (P.dst_row0 + t) * P.q_ts + (int64_t)h * P.q_hs;
+        const int64_t drow = (int64_t)blockIdx.y * P.q_bs + (P.dst_row0 + t) * P.q_ts + (int64_t)h * P.q_hs;
         reinterpret_cast<uint32_t *>(P.q + drow * 64)[sub] = packed;
         if (sub == 0) {
             P.sz[drow * 2 + 0] = __float2half(scale);
@@ -163,6 +164,7 @@ struct DequantParams {
     __half *out;                // [T, h, 128] contiguous
     int32_t n_tokens, n_heads;
     int32_t fused;              // dequantisation form: 0 = mul then add (two roundings), 1 = fma (one)
+    int64_t q_bs, o_bs;         // batched launch (grid.y = batch row): pool rows / output elements between batch rows
 };
 
 __global__ __launch_bounds__(256) void duo_int4_dequantize_kernel(const DequantParams P) {
@@ -171,11 +173,11 @@ __global__ __launch_bounds__(256) void duo_int4_dequantize_kernel(const DequantP
     if (row >= (int64_t)P.n_tokens * P.n_heads) return;
     const int h = (int)(row % P.n_heads);
     const int64_t t = row / P.n_heads;
-    const int64_t srow = t * P.q_ts + (int64_t)h * P.q_hs;
+    const int64_t srow = (int64_t)blockIdx.y * P.q_bs + t * P.q_ts + (int64_t)h * P.q_hs;
     const uint32_t w = reinterpret_cast<const uint32_t *>(P.q + srow * 64)[sub];
     __half o[8];
     dequant8(w, P.sz[srow * 2], P.sz[srow * 2 + 1], o, P.fused != 0);
-    *reinterpret_cast<u32x4 *>(P.out + row * 128 + sub * 8) = *reinterpret_cast<const u32x4 *>(o);
+    *reinterpret_cast<u32x4 *>(P.out + (int64_t)blockIdx.y * P.o_bs + row * 128 + sub * 8) = *reinterpret_cast<const u32x4 *>(o);
 }
 
 // ----------------------------------------------------------------------------- pool compaction
@@ -187,13 +189,14 @@ struct Int4CompressParams {
     __half *ksz, *vsz;
     int64_t q_ts, q_hs;
     int32_t n_heads, len, sink, recent;
+    int64_t q_bs;               // batched launch (grid.y = batch row): pool rows between batch rows
 };
 
 __global__ __launch_bounds__(256) void duo_int4_compress_kernel(const Int4CompressParams P) {
     const int h = blockIdx.x >> 1;
     const bool is_v = blockIdx.x & 1;
-    uint8_t *q = (is_v ? P.vq : P.kq) + (int64_t)h * P.q_hs * 64;
-    __half *sz = (is_v ? P.vsz : P.ksz) + (int64_t)h * P.q_hs * 2;
+    uint8_t *q = (is_v ? P.vq : P.kq) + ((int64_t)h * P.q_hs + (int64_t)blockIdx.y * P.q_bs) * 64;
+    __half *sz = (is_v ? P.vsz : P.ksz) + ((int64_t)h * P.q_hs + (int64_t)blockIdx.y * P.q_bs) * 2;
     const int shift = P.len - P.recent - P.sink;     // > 0
     const int sub = threadIdx.x & 15;                // 4 bytes of the 64-byte row
     const int r_in = threadIdx.x >> 4;               // 16 rows per pass
@@ -224,6 +227,7 @@ struct Int4SegDev {
     int32_t len;
     int32_t n_kv_heads;
     int32_t q_head_offset;
+    int64_t bs;                // batched launch: pool rows between batch rows
 };
 
 struct Int4DecodeParams {
@@ -240,6 +244,8 @@ struct Int4DecodeParams {
     int32_t max_splits;
     uint32_t flags;            // debug: bit 5 = loads only (memory-side ceiling of the access pattern)
     int32_t fused;             // dequantisation form (see dequant8_pk)
+    int64_t q_bs, out_bs;      // batched launch (grid.z = batch row): q / out elements between batch rows
+    int64_t ws_row_floats;     // ... and floats between the rows' partial areas
 };
 
 __device__ __forceinline__ Int4SegDev i4_select(const Int4SegDev &a, const Int4SegDev &b, bool pb) {
@@ -250,6 +256,7 @@ __device__ __forceinline__ Int4SegDev i4_select(const Int4SegDev &a, const Int4S
     r.len = pb ? b.len : a.len;
     r.n_kv_heads = pb ? b.n_kv_heads : a.n_kv_heads;
     r.q_head_offset = pb ? b.q_head_offset : a.q_head_offset;
+    r.bs = pb ? b.bs : a.bs;
     return r;
 }
 
@@ -295,15 +302,16 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
     const int w0 = c0 + wave * per_wave;
     const int w1 = min(w0 + per_wave, c1);
 
-    const uint8_t *kq = C.kq + (int64_t)kvh * C.hs * 64 + sub * 4;
-    const uint8_t *vq = C.vq + (int64_t)kvh * C.hs * 64 + sub * 4;
-    const __half *ksz = C.ksz + (int64_t)kvh * C.hs * 2;
-    const __half *vsz = C.vsz + (int64_t)kvh * C.hs * 2;
+    const int64_t head_row = (int64_t)kvh * C.hs + (int64_t)blockIdx.z * C.bs;     // (grid.z = batch row)
+    const uint8_t *kq = C.kq + head_row * 64 + sub * 4;
+    const uint8_t *vq = C.vq + head_row * 64 + sub * 4;
+    const __half *ksz = C.ksz + head_row * 2;
+    const __half *vsz = C.vsz + head_row * 2;
 
     float qf[GT][8];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-        load8_as_f32<false>(P.q + (int64_t)(qh0 + g) * P.q_head_stride + sub * 8, qf[g]);
+        load8_as_f32<false>(P.q + (int64_t)blockIdx.z * P.q_bs + (int64_t)(qh0 + g) * P.q_head_stride + sub * 8, qf[g]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[g][e] *= P.scale_log2e;
     }
@@ -422,13 +430,13 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
         }
         const int qh = qh0 + g;
         if (splits == 1) {
-            P.out[(int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
+            P.out[(int64_t)blockIdx.z * P.out_bs + (int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
         } else {
             const int64_t slot = (int64_t)qh * P.max_splits + split;
-            P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
+            P.ws_acc[(int64_t)blockIdx.z * P.ws_row_floats + slot * DUO_HEAD_DIM + d] = o;
             if (d == 0) {
-                P.ws_ml[slot * 2 + 0] = M;
-                P.ws_ml[slot * 2 + 1] = Lsum;
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 0] = M;
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 1] = Lsum;
             }
         }
     }
@@ -583,10 +591,11 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
     const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
 
     // uniform (SGPR) row bases of this kv head + per-lane 32-bit byte offsets inside a 32-key tile
-    const uint8_t *kq = C.kq + (int64_t)kvh * C.hs * 64;
-    const uint8_t *vq = C.vq + (int64_t)kvh * C.hs * 64;
-    const uint8_t *ksz = reinterpret_cast<const uint8_t *>(C.ksz) + (int64_t)kvh * C.hs * 4;
-    const uint8_t *vsz = reinterpret_cast<const uint8_t *>(C.vsz) + (int64_t)kvh * C.hs * 4;
+    const int64_t head_row = (int64_t)kvh * C.hs + (int64_t)blockIdx.z * C.bs;     // (grid.z = batch row)
+    const uint8_t *kq = C.kq + head_row * 64;
+    const uint8_t *vq = C.vq + head_row * 64;
+    const uint8_t *ksz = reinterpret_cast<const uint8_t *>(C.ksz) + head_row * 4;
+    const uint8_t *vsz = reinterpret_cast<const uint8_t *>(C.vsz) + head_row * 4;
     const int64_t ts = C.ts;
     const uint32_t row_b = (uint32_t)ts * 64u, sz_b = (uint32_t)ts * 4u;   // bytes per token step
     const uint32_t qoff0 = (uint32_t)r * row_b + g * 16, qoff1 = qoff0 + 16u * row_b;
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
     for (int kb = 0; kb < 4; ++kb) {
         u32x4 w = {0u, 0u, 0u, 0u};
         if (r < P.group)
-            w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)(qh0 + r) * P.q_head_stride + 32 * g + 8 * kb);
+            w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)blockIdx.z * P.q_bs + (int64_t)(qh0 + r) * P.q_head_stride + 32 * g + 8 * kb);
         // w = (d0 d1)(d2 d3)(d4 d5)(d6 d7), low half first
         u32x4 o;
         o.x = (w.x >> 16) | (w.z & 0xffff0000u);          // d1, d5
@@ -857,13 +866,13 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         }
         const int qh = qh0 + q;
         if (splits == 1) {
-            P.out[(int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
+            P.out[(int64_t)blockIdx.z * P.out_bs + (int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
         } else {
             const int64_t slot = (int64_t)qh * P.max_splits + split;
-            P.ws_acc[slot * DUO_HEAD_DIM + d] = o;
+            P.ws_acc[(int64_t)blockIdx.z * P.ws_row_floats + slot * DUO_HEAD_DIM + d] = o;
             if (d == 0) {
-                P.ws_ml[slot * 2 + 0] = M;
-                P.ws_ml[slot * 2 + 1] = Lsum;
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 0] = M;
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 1] = Lsum;
             }
         }
     }
@@ -875,6 +884,7 @@ struct Int4MergeParams {
     int64_t out_head_stride;
     int32_t max_splits;
     int32_t qh_begin[2], qh_end[2], splits[2];
+    int64_t ws_row_floats, out_bs;      // batched launch (grid.z = batch row)
 };
 
 __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4MergeParams P) {
@@ -888,8 +898,8 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
     // lanes deep, so even ~200 splits are 6 dependent steps instead of 24
     const int sl = threadIdx.x >> 3, dq = threadIdx.x & 7;
     const int d0 = blockIdx.y * 32 + dq * 4;
-    const float *ml = P.ws_ml + (int64_t)qh * P.max_splits * 2;
-    const float *ac = P.ws_acc + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
+    const float *ml = P.ws_ml + (int64_t)blockIdx.z * P.ws_row_floats + (int64_t)qh * P.max_splits * 2;
+    const float *ac = P.ws_acc + (int64_t)blockIdx.z * P.ws_row_floats + (int64_t)qh * P.max_splits * DUO_HEAD_DIM + d0;
     __shared__ float sm[32];
     __shared__ float slm[32][8];
     __shared__ f32x4 so[32][8];
@@ -942,56 +952,99 @@ __global__ __launch_bounds__(256) void duo_int4_decode_merge_kernel(const Int4Me
         const float inv = 1.f / LL;
         __half h4[4] = {__float2half(oo.x * inv), __float2half(oo.y * inv), __float2half(oo.z * inv),
                         __float2half(oo.w * inv)};
-        *reinterpret_cast<u32x2 *>(P.out + (int64_t)qh * P.out_head_stride + d0) = *reinterpret_cast<const u32x2 *>(h4);
+        *reinterpret_cast<u32x2 *>(P.out + (int64_t)blockIdx.z * P.out_bs + (int64_t)qh * P.out_head_stride + d0) = *reinterpret_cast<const u32x2 *>(h4);
     }
 }
 
 }  // namespace
 
+// The `_batched` forms (ABI v2): the batch row is grid.y (grid.z for the decode) of the same kernels; the un-batched entry
+// points are the n_batch = 1 case.
+extern "C" int duo_int4_quantize_batched(const void *src, int32_t src_is_bf16, int64_t src_batch_stride,
+                                         int64_t src_token_stride, int64_t src_head_stride, void *q_pool, void *sz_pool,
+                                         int64_t pool_batch_stride_rows, int64_t pool_token_stride_rows,
+                                         int64_t pool_head_stride_rows, int32_t n_batch, int32_t n_heads,
+                                         int32_t n_tokens, int32_t dst_row0, int32_t head_dim, void *stream);
 extern "C" int duo_int4_quantize(const void *src, int32_t src_is_bf16, int64_t src_token_stride,
                                  int64_t src_head_stride, void *q_pool, void *sz_pool,
                                  int64_t pool_token_stride_rows, int64_t pool_head_stride_rows,
                                  int32_t n_heads, int32_t n_tokens, int32_t dst_row0, int32_t head_dim,
                                  void *stream) {
+    return duo_int4_quantize_batched(src, src_is_bf16, 0, src_token_stride, src_head_stride, q_pool, sz_pool, 0,
+                                     pool_token_stride_rows, pool_head_stride_rows, 1, n_heads, n_tokens, dst_row0,
+                                     head_dim, stream);
+}
+extern "C" int duo_int4_quantize_batched(const void *src, int32_t src_is_bf16, int64_t src_batch_stride,
+                                         int64_t src_token_stride, int64_t src_head_stride, void *q_pool, void *sz_pool,
+                                         int64_t pool_batch_stride_rows, int64_t pool_token_stride_rows,
+                                         int64_t pool_head_stride_rows, int32_t n_batch, int32_t n_heads,
+                                         int32_t n_tokens, int32_t dst_row0, int32_t head_dim, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
-    if (n_heads <= 0 || n_tokens <= 0) return 0;
-    if (!src || !q_pool || !sz_pool || dst_row0 < 0 || ((src_token_stride | src_head_stride) & 7)) return DUO_EINVAL;
+    if (n_heads <= 0 || n_tokens <= 0 || n_batch <= 0) return 0;
+    if (!src || !q_pool || !sz_pool || dst_row0 < 0 || n_batch > 65535 ||
+        ((src_token_stride | src_head_stride | src_batch_stride) & 7))
+        return DUO_EINVAL;
     QuantParams P{src, src_token_stride, src_head_stride, (uint8_t *)q_pool, (__half *)sz_pool,
-                  pool_token_stride_rows, pool_head_stride_rows, n_tokens, n_heads, dst_row0};
+                  pool_token_stride_rows, pool_head_stride_rows, n_tokens, n_heads, dst_row0,
+                  src_batch_stride, pool_batch_stride_rows};
     const int64_t rows = (int64_t)n_tokens * n_heads;
-    dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    dim3 grid((unsigned)((rows + 15) / 16), (unsigned)n_batch), block(256);
     if (src_is_bf16) hipLaunchKernelGGL(duo_int4_quantize_kernel<true>, grid, block, 0, (hipStream_t)stream, P);
     else hipLaunchKernelGGL(duo_int4_quantize_kernel<false>, grid, block, 0, (hipStream_t)stream, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int duo_int4_dequantize_batched_f16(const void *q_pool, const void *sz_pool, int64_t pool_batch_stride_rows,
+                                               int64_t pool_token_stride_rows, int64_t pool_head_stride_rows, void *out,
+                                               int64_t out_batch_stride, int32_t n_batch, int32_t n_heads,
+                                               int32_t n_tokens, int32_t head_dim, int32_t fused, void *stream);
 extern "C" int duo_int4_dequantize_f16(const void *q_pool, const void *sz_pool, int64_t pool_token_stride_rows,
                                        int64_t pool_head_stride_rows, void *out, int32_t n_heads,
                                        int32_t n_tokens, int32_t head_dim, int32_t fused, void *stream) {
+    return duo_int4_dequantize_batched_f16(q_pool, sz_pool, 0, pool_token_stride_rows, pool_head_stride_rows, out, 0, 1,
+                                           n_heads, n_tokens, head_dim, fused, stream);
+}
+// out: [B][n_tokens, n_heads, 128] fp16, batch rows out_batch_stride elements apart
+extern "C" int duo_int4_dequantize_batched_f16(const void *q_pool, const void *sz_pool, int64_t pool_batch_stride_rows,
+                                               int64_t pool_token_stride_rows, int64_t pool_head_stride_rows, void *out,
+                                               int64_t out_batch_stride, int32_t n_batch, int32_t n_heads,
+                                               int32_t n_tokens, int32_t head_dim, int32_t fused, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
-    if (n_heads <= 0 || n_tokens <= 0) return 0;
-    if (!q_pool || !sz_pool || !out) return DUO_EINVAL;
+    if (n_heads <= 0 || n_tokens <= 0 || n_batch <= 0) return 0;
+    if (!q_pool || !sz_pool || !out || n_batch > 65535 || (out_batch_stride & 7)) return DUO_EINVAL;
     DequantParams P{(const uint8_t *)q_pool, (const __half *)sz_pool, pool_token_stride_rows,
-                    pool_head_stride_rows, (__half *)out, n_tokens, n_heads, fused != 0};
+                    pool_head_stride_rows, (__half *)out, n_tokens, n_heads, fused != 0,
+                    pool_batch_stride_rows, out_batch_stride};
     const int64_t rows = (int64_t)n_tokens * n_heads;
-    hipLaunchKernelGGL(duo_int4_dequantize_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0,
+    hipLaunchKernelGGL(duo_int4_dequantize_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)n_batch), dim3(256), 0,
                        (hipStream_t)stream, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int duo_int4_stream_compress_batched(void *kq, void *ksz, void *vq, void *vsz, int64_t pool_batch_stride_rows,
+                                                int64_t pool_token_stride_rows, int64_t pool_head_stride_rows,
+                                                int32_t n_batch, int32_t n_heads, int32_t len, int32_t sink,
+                                                int32_t recent, int32_t *new_len, void *stream);
 extern "C" int duo_int4_stream_compress(void *kq, void *ksz, void *vq, void *vsz, int64_t pool_token_stride_rows,
                                         int64_t pool_head_stride_rows, int32_t n_heads, int32_t len,
                                         int32_t sink, int32_t recent, int32_t *new_len, void *stream) {
-    if (len < 0 || sink < 0 || recent < 0) return DUO_EINVAL;
+    return duo_int4_stream_compress_batched(kq, ksz, vq, vsz, 0, pool_token_stride_rows, pool_head_stride_rows, 1, n_heads,
+                                            len, sink, recent, new_len, stream);
+}
+extern "C" int duo_int4_stream_compress_batched(void *kq, void *ksz, void *vq, void *vsz, int64_t pool_batch_stride_rows,
+                                                int64_t pool_token_stride_rows, int64_t pool_head_stride_rows,
+                                                int32_t n_batch, int32_t n_heads, int32_t len, int32_t sink,
+                                                int32_t recent, int32_t *new_len, void *stream) {
+    if (len < 0 || sink < 0 || recent < 0 || n_batch < 0 || n_batch > 65535) return DUO_EINVAL;
     const int W = sink + recent;
     if (new_len) *new_len = len <= W ? len : W;
-    if (len <= W || n_heads <= 0) return 0;
+    if (len <= W || n_heads <= 0 || n_batch == 0) return 0;
     if (!kq || !ksz || !vq || !vsz) return DUO_EINVAL;
     Int4CompressParams P{(uint8_t *)kq, (uint8_t *)vq, (__half *)ksz, (__half *)vsz, pool_token_stride_rows,
-                         pool_head_stride_rows, n_heads, len, sink, recent};
-    hipLaunchKernelGGL(duo_int4_compress_kernel, dim3(2 * n_heads), dim3(256), 0, (hipStream_t)stream, P);
+                         pool_head_stride_rows, n_heads, len, sink, recent, pool_batch_stride_rows};
+    hipLaunchKernelGGL(duo_int4_compress_kernel, dim3(2 * n_heads, n_batch), dim3(256), 0, (hipStream_t)stream, P);
     DUO_HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -1004,33 +1057,51 @@ static void i4_choose_splits(int n_kv_heads, int L, int max_splits, int budget, 
     splits = std::max(1, std::min(s, std::min(units, max_splits)));
 }
 
+extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                                                int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch,
+                                                int32_t group, const duo_int4_pool *full,
+                                                const duo_int4_pool *stream_cls, float scale, int32_t head_dim,
+                                                int32_t fused, void *workspace, int64_t workspace_bytes, void *stream);
 extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
                                         int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
                                         float scale, int32_t head_dim, int32_t fused, void *workspace,
                                         int64_t workspace_bytes, void *stream) {
+    return duo_attn_decode_int4_batched_f16(q, 0, q_head_stride, out, 0, out_head_stride, 1, group, full, stream_cls, scale,
+                                            head_dim, fused, workspace, workspace_bytes, stream);
+}
+// q / out [B, n_q_heads, 128] fp16; the pools' batch rows are duo_int4_pool::batch_stride_rows apart; grid.z = batch row
+extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                                                int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch,
+                                                int32_t group, const duo_int4_pool *full,
+                                                const duo_int4_pool *stream_cls, float scale, int32_t head_dim,
+                                                int32_t fused, void *workspace, int64_t workspace_bytes, void *stream) {
     if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
-    if (!q || !out || group <= 0) return DUO_EINVAL;
+    if (!q || !out || group <= 0 || n_batch < 0 || n_batch > 65535) return DUO_EINVAL;
+    if (n_batch == 0) return 0;
+    if (n_batch > 1 && ((q_batch_stride & 7) || (out_batch_stride & 3))) return DUO_EINVAL;
     Int4DecodeParams P;
     P.fused = fused != 0;
+    P.q_bs = q_batch_stride;
+    P.out_bs = out_batch_stride;
     P.q = (const __half *)q; P.q_head_stride = q_head_stride;
     P.out = (__half *)out; P.out_head_stride = out_head_stride;
     const duo_int4_pool *src[2] = {full, stream_cls};
     int n_q_heads = 0;
     for (int c = 0; c < 2; ++c) {
         Int4SegDev &S = P.cls[c];
-        S = Int4SegDev{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+        S = Int4SegDev{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
         if (!src[c] || src[c]->n_kv_heads <= 0) continue;
         const duo_int4_pool &p = *src[c];
         if (!p.k_q || !p.v_q || !p.k_sz || !p.v_sz || p.len <= 0) return DUO_EINVAL;
         S = Int4SegDev{(const uint8_t *)p.k_q, (const uint8_t *)p.v_q, (const __half *)p.k_sz, (const __half *)p.v_sz,
-                       p.token_stride_rows, p.head_stride_rows, p.len, p.n_kv_heads, p.q_head_offset};
+                       p.token_stride_rows, p.head_stride_rows, p.len, p.n_kv_heads, p.q_head_offset, p.batch_stride_rows};
         n_q_heads += p.n_kv_heads * group;
     }
     if (n_q_heads <= 0) return 0;
     P.group = group;
     P.flags = duo_get_debug_flags();
     P.scale_log2e = scale * 1.4426950408889634f;
-    const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float);
+    const int64_t per_split = (int64_t)n_q_heads * (DUO_HEAD_DIM + 2) * (int64_t)sizeof(float) * n_batch;   // partials per batch row
     const int max_splits = workspace ? (int)std::min<int64_t>(workspace_bytes / per_split, 1024) : 0;
     const int ms = max_splits > 0 ? max_splits : 1;
     // matrix-core form for GQA groups up to 16 q heads per kv head; debug flag bit 4 (and wider groups)
@@ -1042,7 +1113,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
         return (x >= 2 && x <= 4) ? x : 2;
     }();
     // one resident round: 256 CUs x (workgroups per CU = waves per SIMD of the kernel in use)
-    const int target = 256 * (mfma ? occ : 2);
+    const int target = std::max(1, 256 * (mfma ? occ : 2) / n_batch);      // one resident round over all batch rows
     i4_choose_splits(P.cls[1].n_kv_heads, P.cls[1].len, ms, P.cls[0].n_kv_heads > 0 ? P.cls[1].n_kv_heads : target, P.splits[1]);
     i4_choose_splits(P.cls[0].n_kv_heads, P.cls[0].len, ms,
                      std::max(target - P.cls[1].n_kv_heads * P.splits[1], P.cls[0].n_kv_heads), P.splits[0]);
@@ -1051,6 +1122,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     P.max_splits = need > 1 ? need : 1;
     P.ws_ml = (float *)workspace;
     P.ws_acc = P.ws_ml ? P.ws_ml + (int64_t)n_q_heads * P.max_splits * 2 : nullptr;
+    P.ws_row_floats = (int64_t)n_q_heads * P.max_splits * (DUO_HEAD_DIM + 2);
     P.nblk_full = P.cls[0].n_kv_heads * P.splits[0];
     const int nblk = P.nblk_full + P.cls[1].n_kv_heads * P.splits[1];
     hipStream_t st = (hipStream_t)stream;
@@ -1060,7 +1132,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
             const int x = e ? atoi(e) : 1;
             return x == 0 ? 0 : 1;
         }();
-        dim3 grid(nblk), block(256);
+        dim3 grid(nblk, 1, n_batch), block(256);
 #define DUO_I4_LAUNCH(W_)                                                                                          \
     do {                                                                                                           \
         if (P.fused) {                                                                                             \
@@ -1077,7 +1149,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
 #undef DUO_I4_LAUNCH
     } else {
         const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
-        dim3 grid(nblk, group / gt), block(256);
+        dim3 grid(nblk, group / gt, n_batch), block(256);
         if (gt == 4) hipLaunchKernelGGL(duo_int4_decode_split_kernel<4>, grid, block, 0, st, P);
         else if (gt == 2) hipLaunchKernelGGL(duo_int4_decode_split_kernel<2>, grid, block, 0, st, P);
         else hipLaunchKernelGGL(duo_int4_decode_split_kernel<1>, grid, block, 0, st, P);
@@ -1086,6 +1158,8 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     Int4MergeParams M;
     M.ws_ml = P.ws_ml; M.ws_acc = P.ws_acc; M.out = P.out; M.out_head_stride = out_head_stride;
     M.max_splits = P.max_splits;
+    M.ws_row_floats = P.ws_row_floats;
+    M.out_bs = out_batch_stride;
     int n_merge = 0;
     for (int c = 0; c < 2; ++c) {
         M.qh_begin[c] = P.cls[c].q_head_offset;
@@ -1095,7 +1169,7 @@ extern "C" int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, vo
     }
     // debug flag bit 1: leave the partials unmerged (a HIP-event pair then brackets the split kernel alone)
     if (n_merge > 0 && !(duo_get_debug_flags() & 2u)) {
-        hipLaunchKernelGGL(duo_int4_decode_merge_kernel, dim3(n_merge, 4), dim3(256), 0, st, M);
+        hipLaunchKernelGGL(duo_int4_decode_merge_kernel, dim3(n_merge, 4, n_batch), dim3(256), 0, st, M);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;

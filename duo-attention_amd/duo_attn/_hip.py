@@ -56,6 +56,7 @@ class Int4Pool(Structure):
         ("k_q", c_void_p), ("v_q", c_void_p), ("k_sz", c_void_p), ("v_sz", c_void_p),
         ("token_stride_rows", c_int64), ("head_stride_rows", c_int64),
         ("len", c_int32), ("n_kv_heads", c_int32), ("q_head_offset", c_int32), ("_pad", c_int32),
+        ("batch_stride_rows", c_int64),
     ]
 
 
@@ -189,6 +190,26 @@ _SIGNATURES = {
         ctypes.c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32,
          POINTER(c_int32), c_void_p],
+    ),
+    "duo_int4_quantize_batched": (
+        ctypes.c_int,
+        [c_void_p, c_int32, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
+         c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "duo_int4_dequantize_batched_f16": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+         c_void_p],
+    ),
+    "duo_int4_stream_compress_batched": (
+        ctypes.c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
+         POINTER(c_int32), c_void_p],
+    ),
+    "duo_attn_decode_int4_batched_f16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(Int4Pool), POINTER(Int4Pool),
+         c_float, c_int32, c_int32, c_void_p, c_int64, c_void_p],
     ),
     "duo_attn_decode_int4_f16": (
         ctypes.c_int,
@@ -695,10 +716,11 @@ def _require_gpu(t: torch.Tensor, name: str, dtype):
 
 
 def _pool_row_strides(q_pool: torch.Tensor):
-    """q_pool: [T, h, 64] uint8 view (row = 64 contiguous bytes) -> (token, head) strides in rows."""
-    assert q_pool.dim() == 3 and q_pool.shape[2] == 64 and q_pool.stride(2) == 1
-    assert q_pool.stride(0) % 64 == 0 and q_pool.stride(1) % 64 == 0
-    return q_pool.stride(0) // 64, q_pool.stride(1) // 64
+    """q_pool: [T, h, 64] uint8 view (row = 64 contiguous bytes) -> (token, head) strides in rows; a 4-D view
+    [B, T, h, 64] -> (batch, token, head)."""
+    assert q_pool.dim() in (3, 4) and q_pool.shape[-1] == 64 and q_pool.stride(-1) == 1
+    assert all(st % 64 == 0 for st in q_pool.stride()[:-1])
+    return tuple(st // 64 for st in q_pool.stride()[:-1])
 
 
 def int4_quantize(src: torch.Tensor, q_pool: torch.Tensor, sz_pool: torch.Tensor, dst_row0: int):
@@ -717,6 +739,58 @@ def int4_quantize(src: torch.Tensor, q_pool: torch.Tensor, sz_pool: torch.Tensor
     _check(lib.duo_int4_quantize(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), src.stride(1),
                                  q_pool.data_ptr(), sz_pool.data_ptr(), ts, hs, src.shape[1], src.shape[0],
                                  int(dst_row0), src.shape[2], _stream_ptr()), "duo_int4_quantize")
+
+
+def int4_quantize_batched(src: torch.Tensor, q_pool: torch.Tensor, sz_pool: torch.Tensor, dst_row0: int):
+    """src [B, S, h, 128] fp16/bf16 -> rows dst_row0.. of q_pool [B, T, h, 64] u8 / sz_pool [B, T, h, 2] f16, every batch
+    row in one launch."""
+    lib = load_library()
+    if src.shape[0] == 0 or src.shape[1] == 0 or src.shape[2] == 0:
+        return
+    if src.dtype not in (torch.float16, torch.bfloat16):
+        raise DuoHipError(f"int4_quantize: fp16 or bf16 input, got {src.dtype}")
+    _require_gpu(src, "src", src.dtype)
+    _require_gpu(q_pool, "q_pool", torch.uint8)
+    _require_gpu(sz_pool, "sz_pool", torch.float16)
+    bs, ts, hs = _pool_row_strides(q_pool)
+    assert sz_pool.stride() == (2 * bs, 2 * ts, 2 * hs, 1)
+    assert src.dim() == 4 and src.stride(3) == 1 and dst_row0 + src.shape[1] <= q_pool.shape[1] and q_pool.shape[0] == src.shape[0]
+    _check(lib.duo_int4_quantize_batched(src.data_ptr(), int(src.dtype == torch.bfloat16), src.stride(0), src.stride(1),
+                                         src.stride(2), q_pool.data_ptr(), sz_pool.data_ptr(), bs, ts, hs, src.shape[0],
+                                         src.shape[2], src.shape[1], int(dst_row0), src.shape[3], _stream_ptr()),
+           "duo_int4_quantize_batched")
+
+
+def int4_dequantize_batched(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, out: torch.Tensor,
+                            fused: bool = False) -> torch.Tensor:
+    """rows [0, n_tokens) of every batch row of the pool [B, T, h, 64] -> out viewed [B, n_tokens, h, 128] fp16."""
+    lib = load_library()
+    B, h = q_pool.shape[0], q_pool.shape[2]
+    per = n_tokens * h * HEAD_DIM
+    res = out[: B * per].view(B, n_tokens, h, HEAD_DIM)
+    if n_tokens == 0 or h == 0 or B == 0:
+        return res
+    _require_gpu(q_pool, "q_pool", torch.uint8)
+    _require_gpu(out, "out", torch.float16)
+    bs, ts, hs = _pool_row_strides(q_pool)
+    _check(lib.duo_int4_dequantize_batched_f16(q_pool.data_ptr(), sz_pool.data_ptr(), bs, ts, hs, res.data_ptr(), per, B, h,
+                                               int(n_tokens), HEAD_DIM, int(bool(fused)), _stream_ptr()),
+           "duo_int4_dequantize_batched_f16")
+    return res
+
+
+def int4_stream_compress_batched(kq, ksz, vq, vsz, length: int, sink: int, recent: int) -> int:
+    """pools [B, T, h, ...]: keep sink + recent of `length` rows in every batch row, one launch"""
+    lib = load_library()
+    new_len = c_int32(0)
+    B, h = kq.shape[0], kq.shape[2]
+    bs, ts, hs = _pool_row_strides(kq) if (h and B) else (0, 0, 0)
+    live = bool(h and B)
+    _check(lib.duo_int4_stream_compress_batched(kq.data_ptr() if live else None, ksz.data_ptr() if live else None,
+                                                vq.data_ptr() if live else None, vsz.data_ptr() if live else None, bs, ts,
+                                                hs, B, h, int(length), int(sink), int(recent), byref(new_len),
+                                                _stream_ptr()), "duo_int4_stream_compress_batched")
+    return int(new_len.value)
 
 
 def int4_dequantize(q_pool: torch.Tensor, sz_pool: torch.Tensor, n_tokens: int, out: torch.Tensor,
@@ -749,14 +823,16 @@ def int4_stream_compress(kq, ksz, vq, vsz, length: int, sink: int, recent: int) 
 
 
 def make_int4_pool(kq, ksz, vq, vsz, length: int, q_head_offset: int) -> Optional[Int4Pool]:
-    """kq/vq [T, h, 64] u8, ksz/vsz [T, h, 2] f16 views of one head class."""
-    if kq is None or kq.shape[1] == 0 or length <= 0:
+    """kq/vq [T, h, 64] u8, ksz/vsz [T, h, 2] f16 views of one head class (or [B, T, h, ...] for the batched decode)."""
+    if kq is None or kq.shape[-2] == 0 or length <= 0:
         return None
     p = Int4Pool()
     p.k_q, p.v_q, p.k_sz, p.v_sz = kq.data_ptr(), vq.data_ptr(), ksz.data_ptr(), vsz.data_ptr()
-    p.token_stride_rows, p.head_stride_rows = _pool_row_strides(kq)
-    assert _pool_row_strides(vq) == (p.token_stride_rows, p.head_stride_rows)
-    p.len, p.n_kv_heads, p.q_head_offset = int(length), kq.shape[1], int(q_head_offset)
+    strides = _pool_row_strides(kq)
+    assert _pool_row_strides(vq) == strides
+    p.token_stride_rows, p.head_stride_rows = strides[-2], strides[-1]
+    p.batch_stride_rows = strides[0] if kq.dim() == 4 else 0
+    p.len, p.n_kv_heads, p.q_head_offset = int(length), kq.shape[-2], int(q_head_offset)
     return p
 
 
@@ -774,6 +850,22 @@ def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optio
                                         byref(stream) if stream is not None else None, float(scale), q.shape[1],
                                         int(bool(fused)), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
            "duo_attn_decode_int4_f16")
+
+
+def attn_decode_int4_batched(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[Int4Pool],
+                             stream: Optional[Int4Pool], scale: float, fused: bool = False):
+    """q, out [B, Hq, 128] fp16; pools built from [B, T, h, ...] views: every batch row in one launch pair"""
+    lib = load_library()
+    _require_gpu(q, "q", torch.float16)
+    _require_gpu(out, "out", torch.float16)
+    assert q.dim() == 3 and q.stride(2) == 1 and out.shape == q.shape
+    ws = decode_workspace(q.device, q.shape[1])
+    _check(lib.duo_attn_decode_int4_batched_f16(q.data_ptr(), q.stride(0), q.stride(1), out.data_ptr(), out.stride(0),
+                                                out.stride(1), q.shape[0], int(group),
+                                                byref(full) if full is not None else None,
+                                                byref(stream) if stream is not None else None, float(scale), q.shape[2],
+                                                int(bool(fused)), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+           "duo_attn_decode_int4_batched_f16")
 
 
 def set_debug_flags(flags: int):

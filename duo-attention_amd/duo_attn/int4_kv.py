@@ -118,11 +118,11 @@ class DuoAttentionStaticINT4KVCache:
             raise ValueError(
                 f"Trying to put {incoming} KVs into a streaming cache of {self._cap_s} rows, current size: {cur_s}."
             )
-        for b in range(key_states.shape[0]):
-            for src, fc, sc in ((key_states, self.full_key_caches, self.streaming_key_caches),
-                                (value_states, self.full_value_caches, self.streaming_value_caches)):
-                _hip.int4_quantize(src[b, :, :nf], fc[layer_idx].quantized_data[b], fc[layer_idx].scale_zero[b], cur)
-                _hip.int4_quantize(src[b, :, nf:], sc[layer_idx].quantized_data[b], sc[layer_idx].scale_zero[b], cur_s)
+        for src, fc, sc in ((key_states, self.full_key_caches, self.streaming_key_caches),
+                            (value_states, self.full_value_caches, self.streaming_value_caches)):
+            # every batch row of a head class in ONE launch (batch row = a grid dimension)
+            _hip.int4_quantize_batched(src[:, :, :nf], fc[layer_idx].quantized_data, fc[layer_idx].scale_zero, cur)
+            _hip.int4_quantize_batched(src[:, :, nf:], sc[layer_idx].quantized_data, sc[layer_idx].scale_zero, cur_s)
         self.kv_seq_len_list[layer_idx] += incoming
         self.streaming_kv_seq_len_list[layer_idx] += incoming
         return self.get(layer_idx) if dequantize else None
@@ -138,11 +138,7 @@ class DuoAttentionStaticINT4KVCache:
             if heads == 0:
                 return empty
             out = self._buf(name, B * rows * heads * self.head_dim)
-            per = rows * heads * self.head_dim
-            for b in range(B):
-                _hip.int4_dequantize(cache.quantized_data[b], cache.scale_zero[b], rows, out[b * per:(b + 1) * per],
-                                     fused=self.fused_dequant)
-            return out[: B * per].view(B, rows, heads, self.head_dim)
+            return _hip.int4_dequantize_batched(cache.quantized_data, cache.scale_zero, rows, out, fused=self.fused_dequant)
 
         return (deq(self.full_key_caches[layer_idx], n, nf, "fk"), deq(self.full_value_caches[layer_idx], n, nf, "fv"),
                 deq(self.streaming_key_caches[layer_idx], m, ns, "sk"), deq(self.streaming_value_caches[layer_idx], m, ns, "sv"))
@@ -154,9 +150,8 @@ class DuoAttentionStaticINT4KVCache:
             return
         kc, vc = self.streaming_key_caches[layer_idx], self.streaming_value_caches[layer_idx]
         if self.num_streaming_kv_head_list[layer_idx] > 0:
-            for b in range(self.batch_size):
-                _hip.int4_stream_compress(kc.quantized_data[b], kc.scale_zero[b], vc.quantized_data[b],
-                                          vc.scale_zero[b], m, self.sink_size, self.recent_size)
+            _hip.int4_stream_compress_batched(kc.quantized_data, kc.scale_zero, vc.quantized_data, vc.scale_zero, m,
+                                              self.sink_size, self.recent_size)
             # (the reference only moves the counter when the layer has streaming heads, :444-492)
             self.streaming_kv_seq_len_list[layer_idx] = self.recent_size + self.sink_size
 
@@ -230,10 +225,7 @@ class DuoAttentionStaticINT4KVCache:
         scale = self.head_dim ** -0.5 if scale is None else scale
         fk, fv = self.full_key_caches[layer_idx], self.full_value_caches[layer_idx]
         sk, sv = self.streaming_key_caches[layer_idx], self.streaming_value_caches[layer_idx]
-        for b in range(query_states.shape[0]):
-            full = _hip.make_int4_pool(fk.quantized_data[b], fk.scale_zero[b], fv.quantized_data[b],
-                                       fv.scale_zero[b], n, 0) if nf else None
-            stream = _hip.make_int4_pool(sk.quantized_data[b], sk.scale_zero[b], sv.quantized_data[b],
-                                         sv.scale_zero[b], m, nf * G) if ns else None
-            _hip.attn_decode_int4(query_states[b, 0], out[b, 0], G, full, stream, scale, fused=self.fused_dequant)
+        full = _hip.make_int4_pool(fk.quantized_data, fk.scale_zero, fv.quantized_data, fv.scale_zero, n, 0) if nf else None
+        stream = _hip.make_int4_pool(sk.quantized_data, sk.scale_zero, sv.quantized_data, sv.scale_zero, m, nf * G) if ns else None
+        _hip.attn_decode_int4_batched(query_states[:, 0], out[:, 0], G, full, stream, scale, fused=self.fused_dequant)
         return out

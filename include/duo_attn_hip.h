@@ -355,6 +355,7 @@ typedef struct duo_int4_pool {
     int32_t n_kv_heads;           /* 0 => class absent                                     */
     int32_t q_head_offset;
     int32_t _pad;
+    int64_t batch_stride_rows;    /* pool rows between batch rows (batched entry points; 0 otherwise) */
 } duo_int4_pool;
 
 /* quantise n_tokens rows of n_heads heads of src ([T, h, 128] fp16 or bf16, element strides)
@@ -390,6 +391,26 @@ int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, in
                              int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
                              float scale, int32_t head_dim, int32_t fused, void *workspace,
                              int64_t workspace_bytes, void *stream);
+
+/* batched forms of the INT4 entry points (as the bf16 ones above: the batch row is a grid dimension; rows of a pool are
+ * `pool_batch_stride_rows` apart, dequantised output rows `out_batch_stride` elements apart)                              */
+int duo_int4_quantize_batched(const void *src, int32_t src_is_bf16, int64_t src_batch_stride, int64_t src_token_stride,
+                              int64_t src_head_stride, void *q_pool, void *sz_pool, int64_t pool_batch_stride_rows,
+                              int64_t pool_token_stride_rows, int64_t pool_head_stride_rows, int32_t n_batch,
+                              int32_t n_heads, int32_t n_tokens, int32_t dst_row0, int32_t head_dim, void *stream);
+int duo_int4_dequantize_batched_f16(const void *q_pool, const void *sz_pool, int64_t pool_batch_stride_rows,
+                                    int64_t pool_token_stride_rows, int64_t pool_head_stride_rows, void *out,
+                                    int64_t out_batch_stride, int32_t n_batch, int32_t n_heads, int32_t n_tokens,
+                                    int32_t head_dim, int32_t fused, void *stream);
+int duo_int4_stream_compress_batched(void *k_q, void *k_sz, void *v_q, void *v_sz, int64_t pool_batch_stride_rows,
+                                     int64_t pool_token_stride_rows, int64_t pool_head_stride_rows, int32_t n_batch,
+                                     int32_t n_heads, int32_t len, int32_t sink, int32_t recent, int32_t *new_len,
+                                     void *stream);
+int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_stride, int64_t q_head_stride, void *out,
+                                     int64_t out_batch_stride, int64_t out_head_stride, int32_t n_batch, int32_t group,
+                                     const duo_int4_pool *full, const duo_int4_pool *stream_cls, float scale,
+                                     int32_t head_dim, int32_t fused, void *workspace, int64_t workspace_bytes,
+                                     void *stream);
 
 /* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
 int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,
