@@ -67,6 +67,8 @@ def apply_rope_inplace_ref(q: torch.Tensor, k: torch.Tensor, offsets, rope_scale
     bsz = q.shape[0]
     if isinstance(offsets, torch.Tensor):
         offs = (offsets.expand(bsz) if offsets.numel() == 1 else offsets).tolist()
+    elif isinstance(offsets, (list, tuple)):
+        offs = list(offsets)
     else:
         offs = [int(offsets)] * bsz
     for b in range(bsz):

@@ -148,9 +148,12 @@ def fake_attention(Hq, Hkv, D, rope_theta, rope_factor):
     return m
 
 
-def golden_static(name, counts, Hq, Hkv, chunks, decode_steps, sink, recent, theta, factor, seed):
+def golden_static(name, counts, Hq, Hkv, chunks, decode_steps, sink, recent, theta, factor, seed, batch=1, starts=None):
     """Chunked prefill + decode (with the benchmark's evict_last(1)) through the reference's static
-    forward and its real DuoAttentionStaticKVCache, for every layer of a ragged head split."""
+    forward and its real DuoAttentionStaticKVCache, for every layer of a ragged head split.
+    ``batch`` > 1: the reference's batch dimension (static_kv_cache.py:60-99: one counter per layer, all rows at the same
+    length); ``starts[b]`` shifts row b's position ids (a left-padded batch): the forward hands position_ids[:, 0] to the
+    RoPE kernel, one offset per row (llama.py:347-352)."""
     from duo_attn.patch.llama import llama_duo_attention_forward_one_way_reordered_static as fwd
     from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
 
@@ -162,17 +165,20 @@ def golden_static(name, counts, Hq, Hkv, chunks, decode_steps, sink, recent, the
         parameters=lambda: iter([torch.zeros(1, dtype=torch.bfloat16)]),
     )
     total = sum(chunks) + decode_steps + 2
-    cache = DuoAttentionStaticKVCache(model, heads, 1, total, sink, recent)
+    starts = [0] * batch if starts is None else list(starts)
+    cache = DuoAttentionStaticKVCache(model, heads, batch, total, sink, recent)
     attn = fake_attention(Hq, Hkv, D, theta, factor)
     g = torch.Generator().manual_seed(seed)
     out = {"counts": np.array(counts), "dims": np.array([Hq, Hkv, D, sink, recent]),
            "rope": np.array([theta, 1.0 if factor is None else factor], dtype=np.float64),
            "steps": np.array(list(chunks) + [1] * decode_steps), "n_prefill": np.array(len(chunks))}
+    if batch > 1:
+        out["starts"] = np.array(starts)
     pos = 0
     for si, S in enumerate(list(chunks) + [1] * decode_steps):
-        position_ids = torch.arange(pos, pos + S)[None]
+        position_ids = torch.stack([torch.arange(pos + s0, pos + s0 + S) for s0 in starts])
         for l in range(L):
-            h = torch.randn(1, S, Hq * D, generator=g).to(torch.bfloat16)
+            h = torch.randn(batch, S, Hq * D, generator=g).to(torch.bfloat16)
             out[f"h_{si}_{l}"] = bits(h)   # before the call: q aliases h and is rotated in place
             o, _ = fwd(attn, h, position_ids=position_ids, kv_cache=cache, layer_idx=l)
             out[f"o_{si}_{l}"] = bits(o)
@@ -273,5 +279,8 @@ if __name__ == "__main__":
     # MHA with linear rope factor 8 (Llama-2-7B-32K style), shipped sink/recent sizes
     golden_static("static_b.npz", counts=[3, 1], Hq=4, Hkv=4, chunks=(300, 200), decode_steps=2,
                   sink=128, recent=256, theta=10000.0, factor=8.0, seed=2)
+    # the reference's batch dimension, rows starting at different positions (position_ids[:, 0] per row)
+    golden_static("static_c.npz", counts=[2, 0, 3], Hq=8, Hkv=4, chunks=(40, 21), decode_steps=3,
+                  sink=4, recent=12, theta=500000.0, factor=None, seed=4, batch=2, starts=[0, 7])
     golden_tuple("tuple_a.npz", nf=1, Hq=8, Hkv=4, chunks=(20, 9, 1, 1), sink=4, recent=8, theta=10000.0, seed=3)
     print("golden vectors written to", HERE)

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz"])
+@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz", "static_c.npz"])
 def test_hip_hot_path_reproduces_reference_golden(name):
     from duo_attn.patch._duo import duo_static_attention_core
     from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
@@ -29,16 +29,20 @@ def test_hip_hot_path_reproduces_reference_golden(name):
     n_prefill = int(g["n_prefill"])
     total = sum(steps) + 2
     heads = heads_from_counts(counts, Hkv)
-    cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D, device=DEV), heads, 1, total, sink, recent)
-    ref = StaticCacheRef(len(counts), Hkv, D, heads, 1, total, sink, recent)
+    # static_c: the reference's batch dimension (2 rows in ONE batched launch here), rows at different RoPE positions
+    starts = [int(x) for x in g["starts"]] if "starts" in g.files else [0]
+    B = len(starts)
+    cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D, device=DEV), heads, B, total, sink, recent)
+    ref = StaticCacheRef(len(counts), Hkv, D, heads, B, total, sink, recent)
     pos = 0
     for si, S in enumerate(steps):
         for l in range(len(counts)):
             q, k, v = split_hidden(bf16(g[f"h_{si}_{l}"]), Hq, Hkv, D)
-            out = duo_static_attention_core(q.to(DEV), k.to(DEV), v.to(DEV), cache, l, pos, factor, theta)
-            exact, bud = static_forward_ref(q, k, v, ref, l, pos, factor, theta, round_p=False,
+            p0 = pos if B == 1 else [pos + s0 for s0 in starts]
+            out = duo_static_attention_core(q.to(DEV), k.to(DEV), v.to(DEV), cache, l, p0, factor, theta)
+            exact, bud = static_forward_ref(q, k, v, ref, l, p0, factor, theta, round_p=False,
                                             out_dtype=torch.float32, return_budget=True)
-            golden = bf16(g[f"o_{si}_{l}"]).view(1, S, Hq, D).float()
+            golden = bf16(g[f"o_{si}_{l}"]).view(B, S, Hq, D).float()
             # (1) against the exact-P fp32 oracle on the same inputs: the usual bar
             attn_close(out, exact, f"{name} step {si} layer {l}", bud if S > 1 else None)
             # (2) against the reference's own bf16 output: both sides carry one output rounding -> allow ONE more

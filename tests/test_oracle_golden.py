@@ -64,12 +64,13 @@ def _replay_static(g, step_fn):
     counts = [int(c) for c in g["counts"]]
     steps = [int(s) for s in g["steps"]]
     n_prefill = int(g["n_prefill"])
+    starts = [int(x) for x in g["starts"]] if "starts" in g.files else [0]      # batched fixture: per-row position offsets
     pos = 0
     for si, S in enumerate(steps):
         for l in range(len(counts)):
             q, k, v = split_hidden(bf16(g[f"h_{si}_{l}"]), Hq, Hkv, D)
-            out = step_fn(q, k, v, l, pos, factor, theta)
-            ulp_close(out.reshape(1, S, Hq * D), bf16(g[f"o_{si}_{l}"]), f"step {si} layer {l}")
+            out = step_fn(q, k, v, l, pos if len(starts) == 1 else [pos + s0 for s0 in starts], factor, theta)
+            ulp_close(out.reshape(len(starts), S, Hq * D), bf16(g[f"o_{si}_{l}"]), f"step {si} layer {l}")
         if si >= n_prefill:
             yield "evict"
         else:
@@ -87,13 +88,17 @@ def _check_final_cache(g, cache):
         assert torch.equal(cache.streaming_value_states_list[l][:, :m], bf16(g[f"strv_{l}"]))
 
 
-@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz"])
+def _batch_of(g):
+    return len(g["starts"]) if "starts" in g.files else 1
+
+
+@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz", "static_c.npz"])
 def test_oracle_static_forward_reproduces_reference(name):
     g = load(name)
     Hq, Hkv, D, sink, recent = (int(x) for x in g["dims"])
     counts = [int(c) for c in g["counts"]]
     total = int(sum(g["steps"])) + 2
-    ref = StaticCacheRef(len(counts), Hkv, D, heads_from_counts(counts, Hkv), 1, total, sink, recent)
+    ref = StaticCacheRef(len(counts), Hkv, D, heads_from_counts(counts, Hkv), _batch_of(g), total, sink, recent)
 
     def step(q, k, v, l, pos, factor, theta):
         return static_forward_ref(q, k, v, ref, l, pos, factor, theta, round_p=False)
@@ -104,7 +109,7 @@ def test_oracle_static_forward_reproduces_reference(name):
     _check_final_cache(g, ref)
 
 
-@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz"])
+@pytest.mark.parametrize("name", ["static_a.npz", "static_b.npz", "static_c.npz"])
 def test_product_host_path_reproduces_reference(name, oracle_backend):
     """duo_static_attention_core + the product's DuoAttentionStaticKVCache (head-major pools,
     two-segment attention, in-place streaming update), oracle plugged in as the device backend."""
@@ -118,7 +123,7 @@ def test_product_host_path_reproduces_reference(name, oracle_backend):
     Hq, Hkv, D, sink, recent = (int(x) for x in g["dims"])
     counts = [int(c) for c in g["counts"]]
     total = int(sum(g["steps"])) + 2
-    cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D), heads_from_counts(counts, Hkv), 1,
+    cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D), heads_from_counts(counts, Hkv), _batch_of(g),
                                       total, sink, recent)
 
     def step(q, k, v, l, pos, factor, theta):
