@@ -297,8 +297,11 @@ def duo_attention_forward_one_way_reordered(
     be = get_backend()
     attn_output = torch.empty_like(query_states)
     scale = head_dim ** -0.5
+    batched = bsz > 1 and hasattr(be, "attention_batched")      # one launch for all batch rows
     if past_key_value is None or q_len == kv_seq_len:
-        for b in range(bsz):
+        if batched:
+            be.attention_batched(query_states, attn_output, groups, (num_kv, 0, None, (key_states, value_states)), None, scale)
+        for b in range(0 if batched else bsz):
             be.attention(query_states[b], attn_output[b], groups,
                          (num_kv, 0, None, (key_states[b], value_states[b])), None, scale)
         if past_key_value is not None:  # zero-length past: keep the concatenations well-formed
@@ -309,7 +312,12 @@ def duo_attention_forward_one_way_reordered(
     else:
         past_full_KV = past_key_value[0].transpose(1, 2)        # [2B, N, nf, D]
         past_streaming_KV = past_key_value[1].transpose(1, 2)   # [2B, n, ns, D]
-        for b in range(bsz):
+        if batched:     # K rows = the first B entries of the stacked cache, V rows = the last B
+            full = (nf, 0, (past_full_KV[:bsz], past_full_KV[bsz:]), (full_key_states, full_value_states)) if nf > 0 else None
+            stream = (ns, nf * groups, (past_streaming_KV[:bsz], past_streaming_KV[bsz:]),
+                      (streaming_key_states, streaming_value_states)) if ns > 0 else None
+            be.attention_batched(query_states, attn_output, groups, full, stream, scale)
+        for b in range(0 if batched else bsz):
             full = (nf, 0, (past_full_KV[b], past_full_KV[bsz + b]),
                     (full_key_states[b], full_value_states[b])) if nf > 0 else None
             stream = (ns, nf * groups, (past_streaming_KV[b], past_streaming_KV[bsz + b]),

@@ -189,3 +189,40 @@ def test_tuple_full_attention_baseline_matches_hf(family):
         backend._set_backend_for_testing(None)
     assert len(past) == 3 and past[0][0].shape == (1, 2, 420, 128) and past[0][1].shape == (1, 2, 420, 128)
     check_calls_against_oracle(rec.calls, f"{family} full-attention tuple baseline")
+
+
+def test_tuple_model_batch_rows_equal_single_rows():
+    """B = 2 through the tuple-cache patch (every attention call ONE batched launch: K = the first B, V = the last B
+    entries of the stacked [2B, h, N, D] cache) against each prompt run alone: same logits up to bf16 GEMM batching
+    noise, same cache rows bit for bit (data movement)."""
+    from duo_attn.patch import enable_duo_attention_eval
+
+    base = tiny("llama", seed=9)
+    heads = np.array([[0.0, 1.0], [1.0, 0.0], [1.0, 1.0]])
+    sink, recent = 16, 48
+    ids = torch.randint(0, 211, (2, 301), generator=torch.Generator().manual_seed(10)).to(DEV)
+    chunks = (180, 119, 1, 1)
+
+    def run(rows):
+        model = copy.deepcopy(base)
+        enable_duo_attention_eval(model, heads.copy(), sink, recent)
+        past, pos, logits = None, 0, []
+        with torch.no_grad():
+            for c in chunks:
+                o = model(input_ids=ids[rows, pos:pos + c], past_key_values=past, use_cache=True)
+                past = o.past_key_values
+                logits.append(o.logits.float())
+                pos += c
+        return torch.cat(logits, 1), past
+
+    both, past_b = run(slice(0, 2))
+    for b in range(2):
+        solo, past_s = run(slice(b, b + 1))
+        assert _rel(both[b:b + 1], solo) < 2e-2, (b, _rel(both[b:b + 1], solo))
+        # layer 0's caches only depend on the embeddings and layer 0's projections of the row itself (equal up to the
+        # bf16 rounding of a GEMM that may be tiled differently for 2 x 300 rows than for 300)
+        fb, sb = past_b[0]
+        fs, ss = past_s[0]
+        for got, want in ((fb[[b, 2 + b]], fs), (sb[[b, 2 + b]], ss)):
+            assert got.shape == want.shape
+            assert (got.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
