@@ -148,28 +148,40 @@ def run(args, quiet=False):
     return res
 
 
+def _dist_setup():
+    """one process per GPU over RCCL — or, with DUO_BENCH_DEBUG_SHARED_GPU=1, the same code path rehearsed on a ONE-GPU box:
+    every rank computes on cuda:0, gloo group, hand-off and control tensors through host memory (not a measurement mode)"""
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    shared = os.environ.get("DUO_BENCH_DEBUG_SHARED_GPU") == "1"
+    local = 0 if shared else int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if shared:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = f"cuda:{local}"
+    return dist, rank, world, dev, ("cpu" if shared else dev), ("cpu" if shared else None)
+
+
 def run_pp(args):
     """--pp: layer pipeline, one process per GPU (launch with torch.distributed.run).  The model is sharded with
     duo_attn.pipeline.PipelinedCausalLM: chunked prefill streamed through the stages (row blocks with --row_block),
     greedy decode with the token fed back from the last stage.  BASELINE cfg4's entry point:
         python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/benchmark_static.py --pp \
             --max_length 1048576 --prefilling_chunk_size 32000 --row_block 4096"""
-    import torch.distributed as dist
-
     from duo_attn.pipeline import PipelinedCausalLM
     from duo_attn.utils import sparsify_attention_heads
 
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = f"cuda:{local}"
+    dist, rank, world, dev, ctl, handoff = _dist_setup()
     model, config, is_mistral = build_model(args.shape, dev, args.seed)     # same seed: same weights on every rank
     heads = np.random.RandomState(0).rand(config.num_hidden_layers, config.num_key_value_heads)
     heads, sparsity = sparsify_attention_heads(heads, None, args.sparsity)
     mod = __import__("duo_attn.patch." + ("mistral" if is_mistral else "llama"), fromlist=["x"])
     getattr(mod, f"enable_{'mistral' if is_mistral else 'llama'}_duo_attention_static_kv_cache_eval")(model, heads)
-    pl = PipelinedCausalLM(model, heads, dev)
+    pl = PipelinedCausalLM(model, heads, dev, handoff=handoff)
     torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(args.seed)
     input_ids = torch.randint(0, config.vocab_size, (1, args.max_length - 1), generator=g)
@@ -185,7 +197,7 @@ def run_pp(args):
             fn()
         torch.cuda.synchronize()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=dev)
+        t = torch.tensor([time.perf_counter() - t0], device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t) / steps * 1e3
 
@@ -203,11 +215,11 @@ def run_pp(args):
     n = args.decode_steps
     gen_latency = timed(lambda: pl.decode(tok, kv, n), 1, 0) / n
     stage = torch.tensor([pl.pp.first_layer, pl.pp.last_layer, kv.memory_usage // (1 << 20),
-                          int(torch.cuda.max_memory_allocated() // (1 << 20))], device=dev, dtype=torch.int64)
+                          int(torch.cuda.max_memory_allocated() // (1 << 20))], device=ctl, dtype=torch.int64)
     allst = [torch.zeros_like(stage) for _ in range(world)]
     dist.all_gather(allst, stage)
     res = {
-        "mode": f"layer pipeline, {world} ranks (RCCL p2p)", "shape": args.shape, "context_length": args.max_length,
+        "mode": f"layer pipeline, {world} ranks ({dist.get_backend()} p2p" + (", shared-GPU rehearsal" if handoff else "") + ")", "shape": args.shape, "context_length": args.max_length,
         "sparsity": float(sparsity), "prefilling_chunk_size": args.prefilling_chunk_size, "row_block": rb,
         "avg_context_time_ms": ctx_latency, "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3,
         "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
@@ -225,16 +237,10 @@ def run_tp(args):
     """--tp: head-parallel tensor parallelism, one process per GPU (duo_attn.tp: retrieval heads dealt evenly over the
     ranks, column/row-sliced projections, two RCCL all-reduces of [1, S, hidden] per layer).  Same protocol as the
     single-GPU run; every rank executes every layer on its Hkv / tp heads."""
-    import torch.distributed as dist
-
     from duo_attn.tp import shard_model_for_tp
     from duo_attn.utils import sparsify_attention_heads
 
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = f"cuda:{local}"
+    dist, rank, world, dev, ctl, _ = _dist_setup()
     model, config, is_mistral = build_model(args.shape, dev, args.seed)
     L, Hkv, hidden = config.num_hidden_layers, config.num_key_value_heads, config.hidden_size
     heads = np.random.RandomState(0).rand(L, Hkv)
@@ -268,7 +274,7 @@ def run_tp(args):
             fn()
         torch.cuda.synchronize()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=dev)
+        t = torch.tensor([time.perf_counter() - t0], device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t) / steps * 1e3
 
@@ -282,11 +288,11 @@ def run_tp(args):
         kv.evict_last(1)
 
     gen_latency = timed(func2, args.decode_steps, args.decode_warmup)
-    st = torch.tensor([int(mine.sum()), kv.memory_usage // (1 << 20)], device=dev, dtype=torch.int64)
+    st = torch.tensor([int(mine.sum()), kv.memory_usage // (1 << 20)], device=ctl, dtype=torch.int64)
     allst = [torch.zeros_like(st) for _ in range(world)]
     dist.all_gather(allst, st)
     res = {
-        "mode": f"head-parallel TP, {world} ranks (RCCL all-reduce)", "shape": args.shape, "context_length": args.max_length,
+        "mode": f"head-parallel TP, {world} ranks ({dist.get_backend()} all-reduce" + (", shared-GPU rehearsal" if ctl == "cpu" else "") + ")", "shape": args.shape, "context_length": args.max_length,
         "sparsity": float(sparsity), "prefilling_chunk_size": C, "avg_context_time_ms": ctx_latency,
         "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3, "avg_generation_time_ms": gen_latency,
         "decode_tok_s": 1e3 / gen_latency, "all_reduces_per_layer": 2, "all_reduce_bytes_decode": hidden * 2,
