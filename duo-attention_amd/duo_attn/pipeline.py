@@ -11,7 +11,11 @@ Chunk-level pipelining is what makes prefill scale: chunk c on stage s depends o
 from stage s-1 and chunk c-1 on stage s, so with n chunks and P stages the makespan is
 (n + P - 1) chunk-stage slots instead of n*P.  In that (feed-forward) mode the send of item i and the
 receive of item i+1 are issued as ONE ``batch_isend_irecv`` group, so neither waits behind the other on
-the rank's in-order RCCL communicator and a stage computes item i+1 while item i leaves.  Decode at batch 1
+the rank's in-order RCCL communicator and a stage computes item i+1 while item i leaves.  (Where the backend hands back
+one request per operation — gloo — the receive is waited for before computing and the send only before its buffer is
+reused.  RCCL returns ONE request for the coalesced group, so there the wait before item i+1 also covers the send of item
+i: a stage cannot run more than one item ahead of its successor — the depth-1 buffering the double-buffered slots give
+anyway.  This has only ever run over gloo: no RCCL run exists)  Decode at batch 1
 is strictly sequential across stages (latency = sum of stages + hops); sharding it only multiplies KV
 capacity — this is reported as is.
 
