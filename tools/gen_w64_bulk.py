@@ -80,6 +80,15 @@ def add(x, k, h, parity):
     return Op("v_add_f32 {l}, {l}, {e}", [("l", "v", acc, "rw"), ("e", "v", E(x, k, h), "r")])
 
 
+ROWSUM = os.environ.get("W64_GEN_ROWSUM", "add")     # add: one fp32 v_add per score;  dot2: one packed dot per P word (sums the ROUNDED P)
+
+
+def dot2(x, k, parity):
+    # l += p_lo * 1 + p_hi * 1 on the packed word the PV MFMA reads: one instruction for two scores
+    acc = f"lsum[{x}]" if parity == 0 else f"lodd[{x}]"
+    return Op("@DOT2@ {l}, {one}, {pk}", [("l", "v", acc, "rw"), ("one", "s", "w64_ones", "r"), ("pk", "v", f"pk{AB[x]}[{k}]", "r")])
+
+
 def cvt(x, k):
     return Op("@CVT@ {pk}, {e0}, {e1}",
               [("pk", "v", f"pk{AB[x]}[{k}]", "w"), ("e0", "v", E(x, k, 0), "r"), ("e1", "v", E(x, k, 1), "r")])
@@ -200,9 +209,15 @@ FIN_R = 5
 
 def schedule_slices(x, cap, gap0):
     """r -> ops of block x's 16 slices (112 instructions), list-scheduled oldest slice first"""
-    deps = {"F0": [], "F1": [], "X0": ["F0"], "X1": ["F1"], "A0": ["X0"], "C": ["X0", "X1"], "A1": ["X1"]}
-    rank = {"A0": 0, "C": 0, "A1": 0, "X0": 1, "X1": 1, "F0": 2, "F1": 2}
-    pending = [(k, o) for k in range(16) for o in ("F0", "F1", "X0", "X1", "A0", "C", "A1")]
+    if ROWSUM == "dot2":
+        deps = {"F0": [], "F1": [], "X0": ["F0"], "X1": ["F1"], "C": ["X0", "X1"], "D": ["C"]}
+        rank = {"D": 0, "C": 0, "X0": 1, "X1": 1, "F0": 2, "F1": 2}
+        kinds = ("F0", "F1", "X0", "X1", "C", "D")
+    else:
+        deps = {"F0": [], "F1": [], "X0": ["F0"], "X1": ["F1"], "A0": ["X0"], "C": ["X0", "X1"], "A1": ["X1"]}
+        rank = {"A0": 0, "C": 0, "A1": 0, "X0": 1, "X1": 1, "F0": 2, "F1": 2}
+        kinds = ("F0", "F1", "X0", "X1", "A0", "C", "A1")
+    pending = [(k, o) for k in range(16) for o in kinds]
     place, by_r = {}, {}
     for r in sorted(cap):
         picked = []
@@ -222,16 +237,16 @@ def schedule_slices(x, cap, gap0):
             pending.remove((k, o))
             picked.append((k, o))
         # text order inside the statement: fma, then add / cvt, the exps last (an exp of this gap's fma sits behind it)
-        picked.sort(key=lambda ko: {"F": 0, "A": 1, "C": 1, "X": 2}[ko[1][0]])
+        picked.sort(key=lambda ko: {"F": 0, "A": 1, "C": 1, "D": 1, "X": 2}[ko[1][0]])
         parity = (gap0 + r) & 1
         mk = {"F0": lambda k: fma(x, k, 0), "F1": lambda k: fma(x, k, 1), "X0": lambda k: exp(x, k, 0),
               "X1": lambda k: exp(x, k, 1), "A0": lambda k: add(x, k, 0, parity), "A1": lambda k: add(x, k, 1, parity),
-              "C": lambda k: cvt(x, k)}
+              "C": lambda k: cvt(x, k), "D": lambda k: dot2(x, k, parity)}
         by_r[r] = [mk[o](k) for k, o in picked]
     assert not pending, pending
     # the temporaries of slice k are free before slice k + NT starts; P words land two gaps before their MFMA
     for k in range(16 - NT):
-        assert max(place[(k, o)] for o in ("A0", "C", "A1")) < place[(k + NT, "F0")], k
+        assert max(place[(k, o)] for o in kinds if o[0] in "AC") < place[(k + NT, "F0")], k
     need0 = 48 if x == 0 else 80
     for k in range(16):
         assert gap0 + place[(k, "C")] <= need0 + 4 * (k >> 2) - 2, (x, k)
@@ -259,7 +274,7 @@ def build_gaps(variant):
         if "kread" in DROP and t.startswith("ds_read_b128"): return False
         if "vread" in DROP and t.startswith("ds_read_b64_tr"): return False
         if "dma" in DROP and "global_load_lds" in t: return False
-        if "slice" in DROP and t.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "@CVT@"): return False
+        if "slice" in DROP and t.split()[0] in ("v_fma_f32", "v_exp_f32", "v_add_f32", "@CVT@", "@DOT2@"): return False
         if "max" in DROP and t.startswith("v_max3") : return False
         return True
     return [[op for op in g if keep(op)] for g in gaps]
@@ -375,7 +390,7 @@ def emit_stmt(ops, out, prefix=None):
     assert len(outs) + len(ins) <= 30, (len(outs), len(ins))
     out.append("asm volatile(")
     for k, ln in enumerate(lines):
-        ln = ln.replace("@MFMA@", '" W64_MFMA "').replace("@CVT@", '" W64_CVT "')     # element-type mnemonics: macros of the including kernel
+        ln = ln.replace("@MFMA@", '" W64_MFMA "').replace("@CVT@", '" W64_CVT "').replace("@DOT2@", '" W64_DOT2 "')     # element-type mnemonics: macros of the including kernel
         out.append(f'    "{ln}' + ('\\n\\t"' if k + 1 < len(lines) else '"'))
     out.append("    : " + ", ".join(outs))
     out.append("    : " + ", ".join(ins))
