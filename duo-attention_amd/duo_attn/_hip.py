@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
-ABI_VERSION = 2
+ABI_VERSION = 3
 HEAD_DIM = 128
 
 
@@ -91,6 +91,20 @@ _PREFILL_BATCHED = [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_in
                     POINTER(HeadClass), POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p]
 _ROPE_BATCHED = [c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32,
                  c_int32, POINTER(c_int64), c_float, c_float, c_int32, c_void_p]
+
+class LinearSeg(Structure):
+    """duo_linear_seg: one [n, n_in] bf16 weight block of a token-row linear (torch.nn.Linear.weight layout)."""
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("row_stride", c_int64), ("n", c_int32), ("reserved", c_int32)]
+
+
+class TokenLinearArgs(Structure):
+    """duo_token_linear_args (include/duo_attn_hip.h)."""
+    _fields_ = [("x", c_void_p), ("x2", c_void_p), ("x_row_stride", c_int64), ("n_rows", c_int32), ("n_in", c_int32),
+                ("seg", LinearSeg * 3), ("norm_weight", c_void_p), ("norm_eps", c_float), ("reserved", c_int32),
+                ("residual", c_void_p), ("residual_row_stride", c_int64), ("y", c_void_p), ("y_row_stride", c_int64)]
+
+
+TOKEN_LINEAR_MAX_ROWS = 4      # DUO_TOKEN_LINEAR_MAX_ROWS
 
 _SIGNATURES = {
     "duo_abi_version": (ctypes.c_int, []),
@@ -178,6 +192,7 @@ _SIGNATURES = {
          POINTER(HeadClass), c_float, c_int32, c_void_p, c_int64, c_void_p],
     ),
     "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "duo_token_linear_bf16": (ctypes.c_int, [POINTER(TokenLinearArgs), c_void_p]),
     "duo_int4_quantize": (
         ctypes.c_int,
         [c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
@@ -705,6 +720,54 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
         "duo_rmsnorm_bf16",
     )
     return y.view(x.shape)
+
+
+def token_linear_fits(n_rows: int, n_in: int) -> bool:
+    """whether duo_token_linear_bf16 takes ``n_rows`` token rows of ``n_in`` features (rows in LDS, 156 KiB)"""
+    kpad = -(-n_in // 2048) * 2048
+    return 1 <= n_rows <= TOKEN_LINEAR_MAX_ROWS and n_in >= 8 and n_in % 8 == 0 and n_rows * kpad * 2 <= 156 * 1024
+
+
+def token_linear(x: torch.Tensor, blocks, norm=None, x2: Optional[torch.Tensor] = None,
+                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Token-row linear layers of the decode step in ONE launch (duo_token_linear_bf16):
+    ``y = [W0; W1; W2] @ xn + bias (+ residual)`` with ``xn = x``, ``rmsnorm(x; *norm)`` or ``silu(x) * x2``.
+    x [rows, n_in] bf16 (rows <= 4, unit inner stride); blocks: up to three ``(weight [n, n_in], bias or None)``;
+    norm: ``(weight [n_in], eps)``; returns [rows, sum n] bf16."""
+    lib = load_library()
+    _require_gpu_bf16(x, "x")
+    rows, n_in = x.shape
+    if x.stride(1) != 1 or not token_linear_fits(rows, n_in) or not 1 <= len(blocks) <= 3:
+        raise DuoHipError(f"token_linear: unsupported input {tuple(x.shape)} strides {x.stride()} with {len(blocks)} blocks")
+    a = TokenLinearArgs()
+    a.x, a.x_row_stride, a.n_rows, a.n_in = x.data_ptr(), x.stride(0), rows, n_in
+    if x2 is not None:
+        _require_gpu_bf16(x2, "x2")
+        if x2.shape != x.shape or x2.stride() != x.stride():
+            raise DuoHipError("token_linear: x2 must have the shape and strides of x")
+        a.x2 = x2.data_ptr()
+    n_total = 0
+    for i, (w, b) in enumerate(blocks):
+        _require_gpu_bf16(w, "weight")
+        if w.dim() != 2 or w.shape[1] != n_in or w.stride(1) != 1:
+            raise DuoHipError(f"token_linear: weight {tuple(w.shape)} strides {w.stride()} does not match n_in {n_in}")
+        a.seg[i].w, a.seg[i].row_stride, a.seg[i].n = w.data_ptr(), w.stride(0), w.shape[0]
+        if b is not None:
+            _require_gpu_bf16(b, "bias")
+            a.seg[i].bias = b.contiguous().data_ptr()
+        n_total += w.shape[0]
+    if norm is not None:
+        _require_gpu_bf16(norm[0], "norm weight")
+        a.norm_weight, a.norm_eps = norm[0].contiguous().data_ptr(), float(norm[1])
+    y = torch.empty(rows, n_total, dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        _require_gpu_bf16(residual, "residual")
+        if residual.shape != y.shape or residual.stride(1) != 1:
+            raise DuoHipError("token_linear: residual must be [rows, n_total] with unit inner stride")
+        a.residual, a.residual_row_stride = residual.data_ptr(), residual.stride(0)
+    a.y, a.y_row_stride = y.data_ptr(), y.stride(0)
+    _check(lib.duo_token_linear_bf16(byref(a), _stream_ptr()), "duo_token_linear_bf16")
+    return y
 
 
 # ----------------------------------------------------------------------------- INT4 KV pools

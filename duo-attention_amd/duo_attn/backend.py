@@ -97,6 +97,14 @@ class HipBackend:
     def rmsnorm(self, x, weight, eps: float):
         return self._hip.rmsnorm(x, weight, eps)
 
+    # -- the torch.nn.Linear / RMSNorm / SiLU*mul / residual-add modules either side of the attention op at q_len == 1
+    #    (reference llama.py:332-340, :430-432; static_kv_cache.py:482-537): weight rows streamed once, one launch each
+    def token_linear_fits(self, n_rows: int, n_in: int) -> bool:
+        return self._hip.token_linear_fits(n_rows, n_in)
+
+    def token_linear(self, x, blocks, norm=None, x2=None, residual=None):
+        return self._hip.token_linear(x, blocks, norm=norm, x2=x2, residual=residual)
+
 
 _backend = None
 

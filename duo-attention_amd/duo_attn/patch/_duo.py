@@ -6,7 +6,9 @@ implementation is parameterised by the HF module classes and re-exported under
 both names by ``llama.py`` / ``mistral.py``.
 
 Every attention call goes through ``backend.get_backend()`` — the HIP C-ABI
-library.  The projections (``nn.Linear`` -> hipBLASLt) are HF's own.
+library.  The projections (``nn.Linear`` -> hipBLASLt) are HF's own, except at
+q_len == 1 on the static path, where they are matrix-vector products streamed by
+``duo_token_linear_bf16`` (``duo_decode_layer_fused`` below).
 
 Written against transformers 5.x: the attention module no longer has
 ``num_heads`` / ``rotary_emb`` / ``rope_theta`` (reference llama.py:65,68,87,
@@ -15,6 +17,7 @@ computed once per forward by ``model.rotary_emb``.
 """
 from __future__ import annotations
 
+import os
 import types
 from typing import Optional, Tuple
 
@@ -209,6 +212,80 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
     kv_cache.kv_seq_len_list[layer_idx] = cur + 1
     kv_cache.streaming_kv_seq_len_list[layer_idx] = new_len
     return attn_output
+
+
+# =============================================================================
+# decode step of a decoder layer with the token-row linears fused around the attention op
+# =============================================================================
+_FUSED_DECODE_LAYER = os.environ.get("DUO_FUSED_DECODE_LAYER", "1") != "0"     # (0: module by module, for A/B)
+
+
+def _streamable_linear(m) -> bool:
+    w = getattr(m, "weight", None)
+    return (type(m) is torch.nn.Linear and w is not None and w.dtype == torch.bfloat16 and w.is_cuda
+            and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0
+            and (m.bias is None or m.bias.dtype == torch.bfloat16))
+
+
+def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
+    """Whether this decoder layer's decode step can run as the fused form below: one token per batch row after a
+    prefill, bf16 on the GPU, plain ``nn.Linear`` projections (a tensor-parallel shard's o_proj / down_proj reduce
+    across ranks BEFORE the residual add, so sharded layers keep the module-by-module path), SiLU-gated MLP,
+    RMSNorm modules with the patched forward, a backend that has the kernel."""
+    if not _FUSED_DECODE_LAYER or hidden_states.dim() != 3 or hidden_states.shape[1] != 1:
+        return False
+    be = get_backend()
+    if not hasattr(be, "token_linear") or not hidden_states.is_cuda or hidden_states.dtype != torch.bfloat16:
+        return False
+    if not isinstance(kv_cache, DuoAttentionStaticKVCache) or kv_cache.kv_seq_len_list[layer_idx] <= 0:
+        return False
+    attn, mlp = layer.self_attn, getattr(layer, "mlp", None)
+    if mlp is None or type(getattr(mlp, "act_fn", None)).__name__ not in ("SiLUActivation", "SiLU"):
+        return False
+    mods = [getattr(attn, n, None) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + \
+           [getattr(mlp, n, None) for n in ("gate_proj", "up_proj", "down_proj")]
+    if not all(_streamable_linear(m) for m in mods):
+        return False
+    for norm in (layer.input_layernorm, layer.post_attention_layernorm):
+        if not hasattr(norm, "variance_epsilon") or norm.weight.dtype != torch.bfloat16:
+            return False
+    rows = hidden_states.shape[0]
+    return all(be.token_linear_fits(rows, m.in_features) for m in mods)
+
+
+def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None, position_ids=None):
+    """The reference's decoder layer at q_len == 1 (static_kv_cache.py:482-537 around llama.py:309-434) in six launches:
+
+        q|k|v = [Wq; Wk; Wv] . rmsnorm(h)            input_layernorm folded into the projection's prologue
+        attn  = duo_static_attention_core(...)       RoPE + append + split-head attention + streaming update (2 launches)
+        h1    = Wo . attn + h                        first residual add folded into o_proj's epilogue
+        g|u   = [Wg; Wu] . rmsnorm(h1)               post_attention_layernorm folded in
+        h2    = Wd . (silu(g) * u) + h1              SiLU*mul in the prologue, second residual add in the epilogue
+
+    Every value the modules materialise as a bf16 tensor is rounded to bf16 at the same point (csrc/duo_linear.hip);
+    the linears differ from the library GEMM only by the summation order of their fp32 dot products."""
+    be = get_backend()
+    attn, mlp = layer.self_attn, layer.mlp
+    bsz, _, hidden = hidden_states.shape
+    num_heads, num_kv, head_dim, _ = _dims(attn)
+    x = hidden_states.view(bsz, hidden)
+    n_ln, p_ln = layer.input_layernorm, layer.post_attention_layernorm
+    qkv = be.token_linear(x, [(attn.q_proj.weight, attn.q_proj.bias), (attn.k_proj.weight, attn.k_proj.bias),
+                              (attn.v_proj.weight, attn.v_proj.bias)], norm=(n_ln.weight, n_ln.variance_epsilon))
+    nq, nk = num_heads * head_dim, num_kv * head_dim
+    q = qkv[:, :nq].view(bsz, 1, num_heads, head_dim)
+    k = qkv[:, nq:nq + nk].view(bsz, 1, num_kv, head_dim)
+    v = qkv[:, nq + nk:].view(bsz, 1, num_kv, head_dim)
+    rope_scale, rope_theta = rope_scale_and_theta(attn.config)
+    if pos0 is None and position_ids is not None:
+        pos0 = first_positions(position_ids)
+    ao = duo_static_attention_core(q, k, v, kv_cache, layer_idx, pos0, rope_scale, rope_theta)
+    h1 = be.token_linear(ao.view(bsz, nq), [(attn.o_proj.weight, attn.o_proj.bias)], residual=x)
+    gu = be.token_linear(h1, [(mlp.gate_proj.weight, mlp.gate_proj.bias), (mlp.up_proj.weight, mlp.up_proj.bias)],
+                         norm=(p_ln.weight, p_ln.variance_epsilon))
+    inter = mlp.gate_proj.out_features
+    h2 = be.token_linear(gu[:, :inter], [(mlp.down_proj.weight, mlp.down_proj.bias)], x2=gu[:, inter:], residual=h1)
+    return h2.view(bsz, 1, hidden)
 
 
 # =============================================================================

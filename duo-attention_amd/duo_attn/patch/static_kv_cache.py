@@ -374,6 +374,12 @@ def duo_attn_static_kv_cache_decoder_layer_forward(
     use_cache: Optional[bool] = False,
     **kwargs,
 ):
+    if hidden_states.shape[1] == 1 and "row_block" not in kwargs:
+        # decode step: the token-row linears either side of the attention op fused around it (six launches per layer)
+        from ._duo import duo_decode_layer_fused, fused_decode_layer_ok
+
+        if fused_decode_layer_ok(self, hidden_states, kv_cache, layer_idx):
+            return (duo_decode_layer_fused(self, hidden_states, kv_cache, layer_idx, kwargs.get("pos0"), position_ids),)
     residual = hidden_states
     hidden_states = self.input_layernorm(hidden_states)
     hidden_states, _ = self.self_attn(

@@ -33,8 +33,12 @@
  *                             (static_kv_cache.py:60-125; flash_attn_func batches natively):
  *                             the batch row is a grid dimension, one launch for all rows
  *
+ *   duo_token_linear_bf16     the torch.nn.Linear / RMSNorm / SiLU*mul / residual-add modules either side of the
+ *                             attention op at q_len == 1: llama.py:332-340, :430-432; static_kv_cache.py:482-537
+ *
  * ABI version 2 (round 3): duo_kv_seg gained `batch_stride`, the `_batched` entry points were
  * added, duo_int4_dequantize_f16 / duo_attn_decode_int4_f16 take a `fused` flag.
+ * ABI version 3: + duo_token_linear_bf16 (additions only).
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -51,7 +55,7 @@
 extern "C" {
 #endif
 
-#define DUO_ABI_VERSION 2
+#define DUO_ABI_VERSION 3
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
@@ -415,6 +419,45 @@ int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_stride, int6
 /* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
 int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,
                      int32_t hidden, float eps, void *stream);
+
+/* ---- token-row linear layers of the decode step -------------------------------------------------------------------
+ * At q_len == 1 the projections either side of the attention op are matrix-vector products over weights that are read
+ * once per token (HBM-bound streaming): q/k/v_proj and o_proj of the static forward (duo_attn/patch/llama.py:332-340,
+ * :430-432) and the MLP + norms + residual adds of its decoder layer (duo_attn/patch/static_kv_cache.py:482-537).
+ *
+ *   y[b, n] = sum_k W[n, k] * xn[b, k] + bias[n]  (+ residual[b, n])        b < n_rows <= DUO_TOKEN_LINEAR_MAX_ROWS
+ *   xn = x                                   when norm_weight == NULL and x2 == NULL
+ *      = rmsnorm(x; norm_weight, norm_eps)   (flashinfer.norm.rmsnorm: fp32, one rounding to bf16)
+ *      = silu(x) * x2                        (LlamaMLP's act_fn(gate) * up; silu(x) rounded to bf16 first, as the module does)
+ * W: up to three row-major [n, n_in] bf16 blocks (torch.nn.Linear.weight layout) whose outputs are concatenated along n
+ * (q | k | v, gate | up); seg[i].n == 0 ends the list.  fp32 accumulation, one rounding to bf16, then the residual add
+ * with its own rounding — the values a module-by-module run materialises in bf16 are rounded at the same points.
+ * Alignment: x, x2, norm_weight, every W block 16 bytes; strides multiples of 8 elements; n_in a multiple of 8;
+ * n_rows * round_up(n_in, 2048) * 2 bytes must fit one CU's LDS (156 KiB).                                              */
+#define DUO_TOKEN_LINEAR_MAX_ROWS 4
+typedef struct duo_linear_seg {
+    const void *w;          /* [n, n_in] bf16, rows `row_stride` elements apart */
+    const void *bias;       /* [n] bf16 or NULL */
+    int64_t row_stride;
+    int32_t n;
+    int32_t reserved;
+} duo_linear_seg;
+typedef struct duo_token_linear_args {
+    const void *x;                  /* [n_rows, n_in] bf16, rows x_row_stride elements apart */
+    const void *x2;                 /* silu(x) * x2 prologue: same shape and stride as x; else NULL */
+    int64_t x_row_stride;
+    int32_t n_rows;
+    int32_t n_in;
+    duo_linear_seg seg[3];
+    const void *norm_weight;        /* RMSNorm prologue: [n_in] bf16; else NULL */
+    float norm_eps;
+    int32_t reserved;
+    const void *residual;           /* [n_rows, n_total] bf16 added to the rounded product; else NULL */
+    int64_t residual_row_stride;
+    void *y;                        /* [n_rows, n_total] bf16 */
+    int64_t y_row_stride;
+} duo_token_linear_args;
+int duo_token_linear_bf16(const duo_token_linear_args *args, void *stream);
 
 #ifdef __cplusplus
 }

@@ -283,6 +283,35 @@ def rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return y.to(x.dtype)
 
 
+def token_linear_ref(x, blocks, norm=None, x2=None, residual=None, exact=False):
+    """The module sequence either side of the attention op at q_len == 1, written module by module (reference
+    llama.py:332-340 q/k/v_proj, :430-432 o_proj; static_kv_cache.py:482-537 norms, MLP, residual adds; HF LlamaMLP
+    ``down_proj(act_fn(gate_proj(h)) * up_proj(h))``), every intermediate a bf16 tensor as in the modules:
+        xn = x | rmsnorm(x; *norm) | silu(x) * x2;   y = cat_i(xn @ W_i^T + b_i);   y = y + residual
+    x [rows, n_in]; blocks: list of (weight [n, n_in], bias or None).  fp64 accumulation of the products (the check's
+    tolerance is the summation-order noise of an fp32 dot product).  ``exact``: also return the fp64 value of the product
+    before its rounding (for the tolerance)."""
+    dt = x.dtype
+    if norm is not None:
+        xn = rmsnorm_ref(x, norm[0], norm[1])
+    elif x2 is not None:
+        xn = torch.nn.functional.silu(x.float()).to(dt)          # act_fn output: a bf16 tensor
+        xn = (xn.float() * x2.float()).to(dt)                    # times up_proj's output: a bf16 tensor
+    else:
+        xn = x
+    outs = []
+    for w, b in blocks:
+        o = xn.double() @ w.double().t()
+        if b is not None:
+            o = o + b.double()
+        outs.append(o)
+    pre = torch.cat(outs, -1)
+    y = pre.float().to(dt)
+    if residual is not None:
+        y = (residual.float() + y.float()).to(dt)
+    return (y, pre) if exact else y
+
+
 # ----------------------------------------------------------------------------- host-side helpers
 def reorder_rows_ref(weight: torch.Tensor, heads: torch.Tensor, repeat: int, channel: str) -> torch.Tensor:
     """reference patch/utils.py:7-34 (boolean-mask permutation, retrieval heads first)."""

@@ -42,7 +42,8 @@ def test_struct_layout_matches_header(tmp_path):
     from duo_attn import _hip
 
     pairs = {"duo_kv_seg": _hip.KVSeg, "duo_head_class": _hip.HeadClass, "duo_int4_pool": _hip.Int4Pool,
-             "duo_decode_layer_args": _hip.DecodeLayerArgs, "duo_decode_batch": _hip.DecodeBatch}
+             "duo_decode_layer_args": _hip.DecodeLayerArgs, "duo_decode_batch": _hip.DecodeBatch,
+             "duo_linear_seg": _hip.LinearSeg, "duo_token_linear_args": _hip.TokenLinearArgs}
     gcc = shutil.which("gcc")
     assert gcc, "gcc is part of the image"
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
@@ -73,6 +74,9 @@ def test_argument_errors_without_gpu():
     assert rc == -2   # DUO_EHEADDIM
     rc = lib.duo_attn_prefill_bf16(None, 0, 0, None, 0, 0, 4, 4, None, None, 1.0, 128, None)
     assert rc == -1   # DUO_EINVAL (null q)
+    a = _hip.TokenLinearArgs()
+    assert lib.duo_token_linear_bf16(ctypes.byref(a), None) == -1      # null x / y
+    assert _hip.TOKEN_LINEAR_MAX_ROWS == 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -1,0 +1,175 @@
+"""GPU: the token-row linears of the decode step (duo_token_linear_bf16, csrc/duo_linear.hip).
+
+At q_len == 1 the reference's q/k/v_proj, o_proj (llama.py:332-340, :430-432) and its decoder layer's norms, MLP and
+residual adds (static_kv_cache.py:482-537) are matrix-vector products over weights read once per token.  Checked here:
+  * op level — every prologue (none / RMSNorm / SiLU*mul), bias, residual, 1-3 weight blocks with padded row strides,
+    1-4 token rows, feature counts that are / are not multiples of the 2048-element group (incl. the Llama-3-8B and the
+    tensor-parallel half shapes) against ``token_linear_ref`` (fp64 dot products, every intermediate rounded to bf16
+    where the modules round): within one bf16 ulp of the exact value, bit-equal on >= 97 % of the elements;
+  * the RMSNorm prologue feeds the product the very bits duo_rmsnorm_bf16 writes (identity weight block);
+  * layer level — an HF decoder layer's decode step, fused vs module by module, on Llama and Mistral tiny models, and a
+    whole greedy generation with the fused layers against the module-by-module run.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.duo_oracle import rmsnorm_ref, token_linear_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rand(shape, g, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def _close(y, ref, pre, what, residual=None):
+    """y (HIP) vs ref (rounded oracle) with pre = exact fp64 product: one bf16 ulp of the exact value (plus one of the
+    residual sum when there is a second rounding), and mostly bit-equal"""
+    y, ref, pre = y.float().cpu(), ref.float(), pre.float()
+    tol = (2.0 ** -7) * pre.abs() + 1e-4
+    if residual is not None:
+        tol = tol + (2.0 ** -7) * (pre + residual.float()).abs()
+    err = (y - ref).abs()
+    assert (err <= tol).all(), f"{what}: {int((err > tol).sum())} of {err.numel()} beyond one ulp, worst {err.max().item():.3e}"
+    same = (y == ref).float().mean().item()
+    assert same >= 0.97, f"{what}: only {same:.4f} of the elements bit-equal to the oracle"
+
+
+CASES = [
+    # rows, n_in, block sizes, bias, prologue, residual, row padding
+    (1, 4096, (4096, 1024, 1024), False, "norm", False, 0),      # q|k|v of Llama-3-8B
+    (1, 4096, (4096,), False, "none", True, 0),                  # o_proj + residual
+    (1, 4096, (14336, 14336), False, "norm", False, 0),          # gate|up
+    (1, 14336, (4096,), False, "silu", True, 0),                 # down_proj over silu(g)*u + residual
+    (2, 4096, (2048, 512, 512), True, "norm", False, 8),         # a tensor-parallel half, biased (Qwen-style), padded rows
+    (3, 7168, (4096,), True, "silu", True, 0),                   # TP half of down_proj: 14 chunks of 512 (not a multiple of 4)
+    (4, 512, (512, 256, 256), False, "norm", False, 0),          # the tiny test models
+    (4, 1032, (40,), True, "none", True, 16),                    # n_in not a multiple of 512; fewer rows than waves
+    (1, 8, (3,), False, "none", False, 0),                       # smallest
+    (2, 2048, (1000, 7), False, "silu", False, 0),               # two blocks, odd sizes
+    (1, 4096, (32064,), False, "none", False, 0),                # wide output (several rows per wave)
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_token_linear_matches_oracle(case):
+    from duo_attn import _hip
+
+    rows, n_in, sizes, with_bias, pro, with_res, pad = case
+    g = torch.Generator().manual_seed(rows * 1000003 + n_in * 31 + sum(sizes) + pad)
+    x = _rand((rows, n_in), g)
+    x2 = _rand((rows, n_in), g) if pro == "silu" else None
+    blocks = []
+    for n in sizes:
+        w_full = _rand((n, n_in + pad), g, scale=n_in ** -0.5)
+        blocks.append((w_full[:, :n_in], _rand((n,), g) if with_bias else None))
+    norm = (_rand((n_in,), g).abs() + 0.5, 1e-5) if pro == "norm" else None
+    res = _rand((rows, sum(sizes)), g) if with_res else None
+    ref, pre = token_linear_ref(x, blocks, norm=norm, x2=x2, residual=res, exact=True)
+    dev = lambda t: None if t is None else t.to(DEV)
+    # (x and x2 as column slices of one buffer, the way the fused layer hands gate|up to down_proj)
+    if x2 is not None:
+        both = torch.cat([x, x2], 1).to(DEV)
+        xd, x2d = both[:, :n_in], both[:, n_in:]
+    else:
+        xd, x2d = x.to(DEV), None
+    wd = []
+    for (w, b), n in zip(blocks, sizes):
+        wf = torch.empty(n, n_in + pad, dtype=torch.bfloat16, device=DEV)
+        wf[:, :n_in].copy_(w)
+        wd.append((wf[:, :n_in], dev(b)))
+    y = _hip.token_linear(xd, wd, norm=None if norm is None else (norm[0].to(DEV), norm[1]), x2=x2d, residual=dev(res))
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    _close(y, ref, pre, str(case), res)
+
+
+def test_norm_prologue_is_the_rmsnorm_kernel():
+    """identity weight block: the product returns the staged token rows -> the RMSNorm prologue must give the bits of
+    duo_rmsnorm_bf16 (same reduction order at 256 threads per workgroup), which is itself pinned to the oracle"""
+    from duo_attn import _hip
+
+    g = torch.Generator().manual_seed(5)
+    n = 1024
+    x = _rand((3, n), g, scale=3.0).to(DEV)
+    w = (_rand((n,), g).abs() + 0.25).to(DEV)
+    eye = torch.eye(n, dtype=torch.bfloat16, device=DEV)
+    got = _hip.token_linear(x, [(eye, None)], norm=(w, 1e-6))
+    want = _hip.rmsnorm(x, w, 1e-6)
+    assert torch.equal(got, want)
+    ref = rmsnorm_ref(x.cpu(), w.cpu(), 1e-6)
+    assert (got.cpu().float() - ref.float()).abs().max() <= (2.0 ** -7) * ref.float().abs().max()
+
+
+def test_argument_errors():
+    from duo_attn import _hip
+
+    x = torch.zeros(5, 64, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(8, 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_hip.DuoHipError):
+        _hip.token_linear(x, [(w, None)])                        # more than 4 token rows
+    with pytest.raises(_hip.DuoHipError):
+        _hip.token_linear(x[:2, :60], [(w[:, :60], None)])       # n_in not a multiple of 8
+    with pytest.raises(_hip.DuoHipError):
+        _hip.token_linear(x[:2], [(w[:, :32], None)])            # weight does not match n_in
+    assert not _hip.token_linear_fits(4, 32768)                  # rows would not fit LDS
+    assert _hip.token_linear_fits(1, 14336) and _hip.token_linear_fits(4, 14336)
+
+
+def _tiny(family, seed):
+    from test_golden_and_model_gpu import tiny
+    return tiny(family, seed=seed)
+
+
+@pytest.mark.parametrize("family,bsz", [("llama", 1), ("mistral", 1), ("llama", 2)])
+def test_fused_decode_layer_matches_module_by_module(family, bsz):
+    """the same patched model, the same prefill, then decode steps with the fused layer form and module by module:
+    logits within the bf16 noise of three layers, caches written identically up to the projection's rounding"""
+    from duo_attn.patch import _duo
+
+    mod = __import__(f"duo_attn.patch.{family}", fromlist=["x"])
+    enable_static = getattr(mod, f"enable_{family}_duo_attention_static_kv_cache_eval")
+    heads = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    ids = torch.randint(0, 211, (bsz, 90), generator=torch.Generator().manual_seed(11)).to(DEV)
+
+    def run(fused):
+        model = _tiny(family, 7)
+        enable_static(model, heads.copy())
+        cache = mod.DuoAttentionStaticKVCache(model, heads, bsz, 128, 16, 48)
+        old = _duo._FUSED_DECODE_LAYER
+        _duo._FUSED_DECODE_LAYER = fused
+        calls = {"n": 0}
+        be = _duo.get_backend()
+        orig = be.token_linear
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+
+        be.token_linear = counting
+        try:
+            outs = []
+            with torch.no_grad():
+                out = model(input_ids=ids[:, :80], past_key_values=cache, use_cache=True)
+                for t in range(80, 90):
+                    out = model(input_ids=ids[:, t:t + 1], past_key_values=cache, use_cache=True)
+                    outs.append(out.logits.float().cpu())
+        finally:
+            _duo._FUSED_DECODE_LAYER = old
+            del be.token_linear
+        return torch.cat(outs, 1), calls["n"], cache
+
+    l_f, n_f, c_f = run(True)
+    l_m, n_m, c_m = run(False)
+    assert n_f == 10 * 3 * 4 and n_m == 0          # four token-linear launches per layer and step; none module by module
+    rel = ((l_f - l_m).norm() / l_m.norm()).item()
+    assert rel < 2e-2, rel
+    assert (l_f.argmax(-1) == l_m.argmax(-1)).float().mean() >= 0.9
+    assert c_f.kv_seq_len == c_m.kv_seq_len == 90
+    for l in range(3):
+        a, b = c_f.full_value_states_list[l][:, :90].float(), c_m.full_value_states_list[l][:, :90].float()
+        assert ((a - b).norm() / b.norm().clamp_min(1e-6)).item() < 2e-2

@@ -42,7 +42,8 @@ def time_it(fn, reps, warm=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["prefill", "decode", "decode_int4"])
+    ap.add_argument("what", choices=["prefill", "decode", "decode_int4", "linear"])
+    ap.add_argument("--rows", type=int, default=1, help="linear: token rows (batch size of the decode step)")
     ap.add_argument("--nf", type=int, default=4)
     ap.add_argument("--past", type=int, default=65536)
     ap.add_argument("--chunk", type=int, default=16384)
@@ -58,6 +59,44 @@ def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
     G = HQ // HKV
+    if a.what == "linear":
+        # the four token-row linears of a Llama-3-8B decoder layer's decode step (csrc/duo_linear.hip) against the same
+        # modules through torch (hipBLASLt GEMM at M = rows + separate norm / activation / add kernels); 32 distinct
+        # weight sets so that nothing is served from L2 / MALL
+        import torch.nn.functional as F
+        Hd, I, L = 4096, 14336, 32
+        rn = lambda *s_: (torch.randn(*s_, generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+        Ws = [dict(q=rn(4096, Hd), k=rn(1024, Hd), v=rn(1024, Hd), o=rn(Hd, 4096), g=rn(I, Hd), u=rn(I, Hd), d=rn(Hd, I),
+                   n1=rn(Hd).abs() + 1, n2=rn(Hd).abs() + 1) for _ in range(L)]
+        x = rn(a.rows, Hd) * 50
+        ao = rn(a.rows, 4096) * 50
+        cases = {
+            "qkv (rmsnorm prologue)": (lambda w: be.token_linear(x, [(w["q"], None), (w["k"], None), (w["v"], None)], norm=(w["n1"], 1e-5)),
+                                       lambda w: [F.linear(be.rmsnorm(x, w["n1"], 1e-5), w[n]) for n in "qkv"], 6144 * Hd),
+            "o_proj + residual": (lambda w: be.token_linear(ao, [(w["o"], None)], residual=x),
+                                  lambda w: x + F.linear(ao, w["o"]), Hd * 4096),
+            "gate|up (rmsnorm prologue)": (lambda w: be.token_linear(x, [(w["g"], None), (w["u"], None)], norm=(w["n2"], 1e-5)),
+                                           lambda w: [F.linear(be.rmsnorm(x, w["n2"], 1e-5), w[n]) for n in "gu"], 2 * I * Hd),
+        }
+        gu = be.token_linear(x, [(Ws[0]["g"], None), (Ws[0]["u"], None)], norm=(Ws[0]["n2"], 1e-5))
+        cases["down_proj (silu*mul prologue) + residual"] = (
+            lambda w: be.token_linear(gu[:, :I], [(w["d"], None)], x2=gu[:, I:], residual=x),
+            lambda w: x + F.linear(F.silu(gu[:, :I]) * gu[:, I:], w["d"]), Hd * I)
+        tot = {"hip": 0.0, "torch": 0.0}
+        for name, (hip_fn, torch_fn, nelem) in cases.items():
+            res = {}
+            for tag, fn in (("hip", hip_fn), ("torch", torch_fn)):
+                avg, mn, med = time_it(lambda: [fn(w) for w in Ws], a.reps)
+                res[tag] = avg / L * 1e3
+                tot[tag] += avg / L * 1e3
+            print(json.dumps({"case": f"{name} rows={a.rows}", "weight_MB": nelem * 2 / 1e6, "hip_us": round(res["hip"], 2),
+                              "torch_us": round(res["torch"], 2), "hip_TBps": round(nelem * 2 / res["hip"] / 1e6, 3),
+                              "torch_TBps": round(nelem * 2 / res["torch"] / 1e6, 3)}))
+        wbytes = (6144 * Hd + Hd * 4096 + 3 * I * Hd) * 2
+        print(json.dumps({"case": f"layer total rows={a.rows}", "hip_us": round(tot["hip"], 1), "torch_us": round(tot["torch"], 1),
+                          "hip_TBps": round(wbytes / tot["hip"] / 1e6, 3), "torch_TBps": round(wbytes / tot["torch"] / 1e6, 3),
+                          "x32_layers_ms": {k: round(v * 32 / 1e3, 3) for k, v in tot.items()}}))
+        return
     scale = D ** -0.5
     if a.what == "prefill":
         nf, ns, S, past = a.nf, HKV - a.nf, a.chunk, a.past
