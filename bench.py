@@ -630,11 +630,14 @@ def model_level(args):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     a = m.parse(["--max_length", str(args.ctx), "--prefilling_chunk_size", str(args.chunk), "--prefill_steps", "1",
-                 "--prefill_warmup", "1", "--decode_steps", "50", "--decode_warmup", "10", "--graph"])
+                 "--prefill_warmup", "1", "--decode_steps", "50", "--decode_warmup", "10", "--graph", "--also_module_by_module"])
     r = m.run(a, quiet=True)
     return {"prefill_tok_s": r["prefill_tok_s"], "decode_ms_per_token": r["avg_generation_time_ms"],
+            "decode_ms_per_token_module_by_module": r.get("avg_generation_time_module_by_module_ms"),
             "decode_mode": r["decode_mode"], "kv_cache_MB": r["kv_cache_memory_MB"], "sparsity": r["sparsity"],
-            "what": "whole HF Llama-3-8B-shape model, random init, incl. hipBLASLt GEMMs (tools/benchmark_static.py --graph)"}
+            "what": "whole HF Llama-3-8B-shape model, random init (tools/benchmark_static.py --graph): prefill GEMMs are "
+                    "hipBLASLt; the decode step's token-row linears are duo_token_linear_bf16 (module_by_module: the same "
+                    "step through the library GEMMs at M = 1 and separate norm / activation / add kernels)"}
 
 
 def main():

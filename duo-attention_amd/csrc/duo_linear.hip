@@ -24,6 +24,7 @@
 // round-robin to all waves of the grid; a wave keeps two groups of four loads in flight across row boundaries (the next
 // group is issued unconditionally — behind the wave's last group it re-reads that group — so the waits are counted).
 // The grid is chosen so that every wave gets the same number of rows (token_linear_grid below).
+#include <type_traits>
 #include "duo_common.h"
 #include "duo_kv_ops.h"
 
@@ -42,7 +43,7 @@ struct LinSegDev {
 struct TokenLinearParams {
     const bf16_t *x, *x2;
     int64_t x_rs;
-    int32_t K, kpad, gpr;           // gpr: groups of kLinG x 512 elements per weight row (kpad = gpr * kLinG * 512)
+    int32_t K, kpad, gpr;           // gpr: groups of kLinG x 512 elements per weight row, EVEN (kpad = gpr * kLinG * 512)
     LinSegDev seg[3];
     int32_t n_total;
     const bf16_t *norm_w;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
     // group g of this wave's i-th row (cursor clamped to the wave's last row: the loads behind the last group are never
     // consumed); per lane 8 elements at k0, clamped into the row — the staged x is zero there
     auto issue = [&](int i, int g, u32x4 (&buf)[kLinG]) __attribute__((always_inline)) {
-        const int n = gw + min(i, my_rows - 1) * TW;
+        const int n = min(gw + max(min(i, my_rows - 1), 0) * TW, P.n_total - 1);     // (a wave without rows reads a valid row, never consumed)
         const uint64_t wr = row_ptr(n);
 #pragma unroll
         for (int j = 0; j < kLinG; ++j) {
@@ -109,33 +110,72 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
         }
     };
 
-    // the wave's first TWO groups go out before the token rows are staged (for a 4096-feature row that is the whole
-    // row): the prologue below runs under their latency
     u32x4 bufA[kLinG], bufB[kLinG];
     const int T = my_rows * gpr;
     int ii = 0, ig = 0;
     auto adv = [&](int &i, int &g) __attribute__((always_inline)) { if (++g == gpr) { g = 0; ++i; } };
-    if (my_rows > 0) {
-        issue(ii, ig, bufA); adv(ii, ig);
-        issue(ii, ig, bufB); adv(ii, ig);
+
+    // bias and residual of this wave's rows, row i in lane i (raw bf16 bits; used by the epilogue behind the stream):
+    // requested first, so nothing waits for them later
+    uint32_t e_bias = 0u, e_res[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) e_res[b] = 0u;
+    if (lane < my_rows) {
+        const int n = gw + lane * TW;
+        const bf16_t *bias = n < n0 ? P.seg[0].bias : n < n1 ? P.seg[1].bias : P.seg[2].bias;
+        const int nb = n < n0 ? n : n < n1 ? n - n0 : n - n1;
+        if (bias) e_bias = bias[nb];
+        if (P.res) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) e_res[b] = P.res[(int64_t)b * P.res_rs + n];
+        }
     }
 
     // ---- token rows -> LDS (all threads of the workgroup) ---------------------------------------------------------
+    // Order of the requests: token-row chunks (L2 hits), then the wave's first TWO weight groups (for a 4096-feature row
+    // that is the whole row), then wait for the token rows only — the staging arithmetic, the RMSNorm reduction and the
+    // barrier run under the weight loads' latency.  Loads return in order, so this needs the token-row loads outside the
+    // compiler's wait bookkeeping as well; they cover the fast path (at most two chunks per thread and row), the
+    // generic path below re-reads what it needs behind the weight loads.
     {
         const int nchunk = K >> 3, npad = P.kpad >> 3;
-        float rs[B];
-        if constexpr (PRO == PRO_NORM) {
-            float ss[B];
+        constexpr int XI = 2;
+        constexpr int XPER = PRO == PRO_SILU ? 2 : 1;
+        const bool fast = B * XPER <= 4 && npad <= XI * nthr;
+        // one staged chunk: raw x chunk (+ partner / norm weight) -> the packed bf16 the product reads
+        auto xform = [&](u32x4 v, u32x4 v2, u32x4 gw8, float rs_b) __attribute__((always_inline)) -> u32x4 {
+            if constexpr (PRO == PRO_NORM) {
+                float f[8], g[8];
+                unpack8f(v, f);
+                unpack8f(gw8, g);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = f[e] * rs_b * g[e];
+                return pack8f(f);
+            } else if constexpr (PRO == PRO_SILU) {
+                float f[8], u[8];
+                unpack8f(v, f);
+                unpack8f(v2, u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float sv = f[e] / (1.f + expf(-f[e]));                     // silu in fp32 ...
+                    const float sr = __uint_as_float(f32_to_bf16_bits(sv) << 16);    // ... a bf16 tensor in the module
+                    f[e] = sr * u[e];
+                }
+                return pack8f(f);
+            } else {
+                return v;
+            }
+        };
+        auto sumsq = [&](u32x4 v, float acc_) __attribute__((always_inline)) -> float {
+            float f[8];
+            unpack8f(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc_ = fmaf(f[e], f[e], acc_);
+            return acc_;
+        };
+        auto reduce_rs = [&](float (&ss)[B], float (&rs)[B]) __attribute__((always_inline)) {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                ss[b] = 0.f;
-                const bf16_t *xr = P.x + (int64_t)b * P.x_rs;
-                for (int c = tid; c < nchunk; c += nthr) {
-                    float f[8];
-                    unpack8f(*reinterpret_cast<const u32x4 *>(xr + c * 8), f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ss[b] = fmaf(f[e], f[e], ss[b]);
-                }
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) ss[b] += __shfl_xor(ss[b], off);
                 if (lane == 0) red[b][wave] = ss[b];
@@ -145,44 +185,103 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
             for (int b = 0; b < B; ++b) {
                 float tot = 0.f;
                 if (nw == 4) tot = red[b][0] + red[b][1] + red[b][2] + red[b][3];     // (the order of duo_rmsnorm_kernel)
-                else for (int w2 = 0; w2 < nw; ++w2) tot += red[b][w2];
+                else for (int w2_ = 0; w2_ < nw; ++w2_) tot += red[b][w2_];
                 rs[b] = rsqrtf(tot / (float)K + P.eps);
             }
-        }
+        };
+        float rs[B];
 #pragma unroll
-        for (int b = 0; b < B; ++b) {
-            const bf16_t *xr = P.x + (int64_t)b * P.x_rs;
-            u32x4 *dst = reinterpret_cast<u32x4 *>(xs + b * xrow);
-            for (int c = tid; c < npad; c += nthr) {
-                u32x4 v = {0u, 0u, 0u, 0u};
-                if (c < nchunk) {
-                    v = *reinterpret_cast<const u32x4 *>(xr + c * 8);
-                    if constexpr (PRO == PRO_NORM) {
-                        float f[8], g[8];
-                        unpack8f(v, f);
-                        unpack8f(*reinterpret_cast<const u32x4 *>(P.norm_w + c * 8), g);
+        for (int b = 0; b < B; ++b) rs[b] = 1.f;
+        // One straight-line sequence for every wave, whatever its path afterwards: token-row requests, weight requests,
+        // wait for the former.  The loads are asm (outside the compiler's wait bookkeeping), so nothing may touch their
+        // destination registers before the matching wait — in particular no copies at a control-flow merge, hence no
+        // control flow here (tests/test_token_linear_isa.py audits the built code for exactly that).
+        u32x4 xr[B][XI], x2r[B][XI], nwr[XI];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) f[e] = f[e] * rs[b] * g[e];
-                        v = pack8f(f);
-                    } else if constexpr (PRO == PRO_SILU) {
-                        float f[8], u[8];
-                        unpack8f(v, f);
-                        unpack8f(*reinterpret_cast<const u32x4 *>(P.x2 + (int64_t)b * P.x_rs + c * 8), u);
+        for (int it = 0; it < XI; ++it) {
+            const uint32_t voff = (uint32_t)min(tid + it * nthr, nchunk - 1) * 16u;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float s = f[e] / (1.f + expf(-f[e]));                     // silu in fp32 ...
-                            const float sr = __uint_as_float(f32_to_bf16_bits(s) << 16);    // ... a bf16 tensor in the module
-                            f[e] = sr * u[e];
-                        }
-                        v = pack8f(f);
-                    }
+            for (int b = 0; b < B; ++b) {
+                const uint64_t xb = (uint64_t)(P.x + (int64_t)b * P.x_rs);
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xr[b][it]) : "v"(voff), "s"(xb));
+                if constexpr (PRO == PRO_SILU && B * XPER <= 4) {
+                    const uint64_t x2b = (uint64_t)(P.x2 + (int64_t)b * P.x_rs);
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x2r[b][it]) : "v"(voff), "s"(x2b));
                 }
-                dst[c] = v;
+            }
+            if constexpr (PRO == PRO_NORM) {
+                const uint64_t nb_ = (uint64_t)P.norm_w;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(nwr[it]) : "v"(voff), "s"(nb_));
+            }
+        }
+        issue(ii, ig, bufA); adv(ii, ig);
+        issue(ii, ig, bufB); adv(ii, ig);
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr[b][it]) : "n"(2 * kLinG));
+                if constexpr (PRO == PRO_SILU && B * XPER <= 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x2r[b][it]) : "n"(2 * kLinG));
+            }
+            if constexpr (PRO == PRO_NORM) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(nwr[it]) : "n"(2 * kLinG));
+        }
+        if (fast) {
+            if constexpr (PRO == PRO_NORM) {
+                float ss[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    ss[b] = 0.f;
+#pragma unroll
+                    for (int it = 0; it < XI; ++it)
+                        if (tid + it * nthr < nchunk) ss[b] = sumsq(xr[b][it], ss[b]);
+                }
+                reduce_rs(ss, rs);
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                u32x4 *dst = reinterpret_cast<u32x4 *>(xs + b * xrow);
+#pragma unroll
+                for (int it = 0; it < XI; ++it) {
+                    const int c = tid + it * nthr;
+                    u32x4 v2 = {0u, 0u, 0u, 0u}, g8 = {0u, 0u, 0u, 0u};
+                    if constexpr (PRO == PRO_SILU && B * XPER <= 4) v2 = x2r[b][it];
+                    if constexpr (PRO == PRO_NORM) g8 = nwr[it];
+                    if (c < npad) dst[c] = c < nchunk ? xform(xr[b][it], v2, g8, rs[b]) : u32x4{0u, 0u, 0u, 0u};
+                }
+            }
+        } else {
+            if constexpr (PRO == PRO_NORM) {
+                float ss[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    ss[b] = 0.f;
+                    const bf16_t *xr = P.x + (int64_t)b * P.x_rs;
+                    for (int c = tid; c < nchunk; c += nthr) ss[b] = sumsq(*reinterpret_cast<const u32x4 *>(xr + c * 8), ss[b]);
+                }
+                reduce_rs(ss, rs);
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                const bf16_t *xr = P.x + (int64_t)b * P.x_rs;
+                u32x4 *dst = reinterpret_cast<u32x4 *>(xs + b * xrow);
+                for (int c = tid; c < npad; c += nthr) {
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    if (c < nchunk) {
+                        u32x4 v2 = v, g8 = v;
+                        if constexpr (PRO == PRO_SILU) v2 = *reinterpret_cast<const u32x4 *>(P.x2 + (int64_t)b * P.x_rs + c * 8);
+                        if constexpr (PRO == PRO_NORM) g8 = *reinterpret_cast<const u32x4 *>(P.norm_w + c * 8);
+                        v = xform(*reinterpret_cast<const u32x4 *>(xr + c * 8), v2, g8, rs[b]);
+                    }
+                    dst[c] = v;
+                }
             }
         }
     }
     __syncthreads();
-    if (my_rows <= 0) return;
+    if (my_rows <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
 
     // ---- the stream ------------------------------------------------------------------------------------------------
     float acc[B];
@@ -195,24 +294,22 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
     float keep[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) keep[b] = 0.f;
-    auto flush = [&](int i_first, int count) {
-        if (lane < count) {
-            const int n = gw + (i_first + lane) * TW;
-            const bf16_t *bias = n < n0 ? P.seg[0].bias : n < n1 ? P.seg[1].bias : P.seg[2].bias;
-            const int nb = n < n0 ? n : n < n1 ? n - n0 : n - n1;
-            const float bv = bias ? __uint_as_float((uint32_t)bias[nb] << 16) : 0.f;
+    auto flush = [&]() {
+        asm volatile("" : "+v"(e_bias));          // (keeps the conversions — and with them the wait for these loads — here)
+#pragma unroll
+        for (int b = 0; b < B; ++b) asm volatile("" : "+v"(e_res[b]));
+        if (lane < my_rows) {
+            const int n = gw + lane * TW;
+            const float bv = __uint_as_float(e_bias << 16);
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 uint32_t r = f32_to_bf16_bits(keep[b] + bv);
-                if (P.res) {
-                    const float rv = __uint_as_float((uint32_t)P.res[(int64_t)b * P.res_rs + n] << 16);
-                    r = f32_to_bf16_bits(rv + __uint_as_float(r << 16));
-                }
+                if (P.res) r = f32_to_bf16_bits(__uint_as_float(e_res[b] << 16) + __uint_as_float(r << 16));
                 P.y[(int64_t)b * P.y_rs + n] = (bf16_t)r;
             }
         }
     };
-    auto consume = [&](int i, int g, u32x4 (&buf)[kLinG]) __attribute__((always_inline)) {
+    auto consume = [&](int i, int g, u32x4 (&buf)[kLinG], auto may_end_row) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < kLinG; ++j) {
             const int kk = (g * kLinG + j) * 256 + lane * 4;
@@ -226,7 +323,7 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
                 for (int e = 0; e < 8; ++e) acc[b] = fmaf(wf[e], xf[e], acc[b]);
             }
         }
-        if (g == gpr - 1) {                 // the row is complete (wave-uniform)
+        if (decltype(may_end_row)::value && g == gpr - 1) {       // the row is complete (wave-uniform)
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float t = wave_sum(acc[b]);
@@ -236,18 +333,19 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
         }
     };
 
+    // (gpr is even — the launcher pads a row to whole PAIRS of groups — so a row always ends in the B half and the loop
+    //  body has no exit in the middle: one shape for the compiler, and for the audit in tests/test_token_linear_isa.py)
     int ci = 0, cg = 0;
     for (int t = 0; t < T; t += 2) {
         lin_wait<kLinG>(bufA);
-        consume(ci, cg, bufA); adv(ci, cg);
+        consume(ci, cg, bufA, std::false_type{}); adv(ci, cg);
         issue(ii, ig, bufA); adv(ii, ig);
-        if (t + 1 >= T) break;
         lin_wait<kLinG>(bufB);
-        consume(ci, cg, bufB); adv(ci, cg);
+        consume(ci, cg, bufB, std::true_type{}); adv(ci, cg);
         issue(ii, ig, bufB); adv(ii, ig);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the group re-read behind the wave's last one)
-    flush(0, my_rows);          // (the launcher keeps a wave's rows <= 64)
+    flush();          // (the launcher keeps a wave's rows <= 64)
 }
 
 // Workgroups and threads per workgroup.  Rows are dealt round-robin to waves, so the launch ends with the wave that has
@@ -298,7 +396,7 @@ extern "C" int duo_token_linear_bf16(const duo_token_linear_args *a, void *strea
     TokenLinearParams P;
     P.x = (const bf16_t *)a->x; P.x2 = (const bf16_t *)a->x2; P.x_rs = a->x_row_stride;
     P.K = a->n_in;
-    P.gpr = (a->n_in + kLinG * 512 - 1) / (kLinG * 512);
+    P.gpr = 2 * ((a->n_in + 2 * kLinG * 512 - 1) / (2 * kLinG * 512));      // whole pairs of groups (see the stream loop)
     P.kpad = P.gpr * kLinG * 512;
     int64_t n_total = 0;
     for (int s = 0; s < 3; ++s) {

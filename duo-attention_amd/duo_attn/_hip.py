@@ -724,7 +724,7 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
 
 def token_linear_fits(n_rows: int, n_in: int) -> bool:
     """whether duo_token_linear_bf16 takes ``n_rows`` token rows of ``n_in`` features (rows in LDS, 156 KiB)"""
-    kpad = -(-n_in // 2048) * 2048
+    kpad = -(-n_in // 4096) * 4096
     return 1 <= n_rows <= TOKEN_LINEAR_MAX_ROWS and n_in >= 8 and n_in % 8 == 0 and n_rows * kpad * 2 <= 156 * 1024
 
 

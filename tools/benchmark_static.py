@@ -117,24 +117,38 @@ def run(args, quiet=False):
     out = prefill()
     pred = out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
 
-    def func2():
+    def eager_step():
         with torch.no_grad():
             model(input_ids=pred, past_key_values=kv_cache, use_cache=True)
         kv_cache.evict_last(1)
 
-    if args.graph:
+    def decode_fn():
+        if not args.graph:
+            return eager_step
         from duo_attn.graph import DecodeStepGraph
 
         for _ in range(3):      # eager steps first: every kernel and GEMM handle is loaded before the capture
-            func2()
+            eager_step()
 
         def step():
             with torch.no_grad():
                 return model(input_ids=pred, past_key_values=kv_cache, use_cache=True).logits
 
-        graph = DecodeStepGraph(kv_cache, step, evict_after=1)
-        func2 = graph.replay    # noqa: F811 — same protocol: one token, then evict_last(1), inside the graph
-    gen_latency, gen_memory = bench_func(func2, args.decode_steps, args.decode_warmup)
+        return DecodeStepGraph(kv_cache, step, evict_after=1).replay    # same protocol: one token, then evict_last(1), inside the graph
+
+    gen_latency, gen_memory = bench_func(decode_fn(), args.decode_steps, args.decode_warmup)
+    unfused_latency = None
+    if getattr(args, "also_module_by_module", False):
+        # the same decode step with the decoder layer run module by module (library GEMMs at M = 1, separate norm /
+        # activation / add kernels) instead of the fused token-row linears (duo_attn/patch/_duo.py: duo_decode_layer_fused)
+        from duo_attn.patch import _duo
+
+        old = _duo._FUSED_DECODE_LAYER
+        _duo._FUSED_DECODE_LAYER = False
+        try:
+            unfused_latency, _ = bench_func(decode_fn(), args.decode_steps, args.decode_warmup)
+        finally:
+            _duo._FUSED_DECODE_LAYER = old
     res = {
         "shape": args.shape, "context_length": args.max_length, "sparsity": float(sparsity),
         "prefilling_chunk_size": C, "avg_context_time_ms": ctx_latency, "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3,
@@ -143,6 +157,8 @@ def run(args, quiet=False):
         "kv_cache_memory_MB": kv_cache.memory_usage / 1024 / 1024,
         "decode_mode": "hip graph replay" if args.graph else "eager",
     }
+    if unfused_latency is not None:
+        res["avg_generation_time_module_by_module_ms"] = unfused_latency
     del model, kv_cache
     torch.cuda.empty_cache()
     return res
@@ -322,6 +338,8 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--graph", action="store_true",
                     help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
+    ap.add_argument("--also_module_by_module", action="store_true",
+                    help="also time the decode step with the decoder layers run module by module (A/B of the fused layer form)")
     ap.add_argument("--pp", action="store_true", help="layer pipeline over the ranks of torch.distributed.run")
     ap.add_argument("--row_block", type=int, default=0, help="--pp: hand prefill chunks through the stages in row blocks")
     ap.add_argument("--tp", action="store_true", help="head-parallel tensor parallelism over the ranks of torch.distributed.run")
