@@ -193,6 +193,7 @@ _SIGNATURES = {
     ),
     "duo_rmsnorm_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "duo_token_linear_bf16": (ctypes.c_int, [POINTER(TokenLinearArgs), c_void_p]),
+    "duo_silu_mul_bf16": (ctypes.c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_void_p]),
     "duo_int4_quantize": (
         ctypes.c_int,
         [c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
@@ -720,6 +721,24 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
         "duo_rmsnorm_bf16",
     )
     return y.view(x.shape)
+
+
+def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """``silu(gate) * up`` (HF LlamaMLP's activation product) in one pass; [..., n] bf16, unit inner stride."""
+    lib = load_library()
+    _require_gpu_bf16(gate, "gate")
+    _require_gpu_bf16(up, "up")
+    if gate.shape != up.shape or gate.shape[-1] % 8:
+        raise DuoHipError(f"silu_mul: shapes {tuple(gate.shape)} / {tuple(up.shape)}")
+    g2, u2 = gate.reshape(-1, gate.shape[-1]), up.reshape(-1, up.shape[-1])
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    if u2.stride(1) != 1:
+        u2 = u2.contiguous()
+    y = torch.empty(g2.shape, dtype=torch.bfloat16, device=gate.device)
+    _check(lib.duo_silu_mul_bf16(g2.data_ptr(), g2.stride(0), u2.data_ptr(), u2.stride(0), y.data_ptr(), y.stride(0),
+                                 g2.shape[0], g2.shape[1], _stream_ptr()), "duo_silu_mul_bf16")
+    return y.view(gate.shape)
 
 
 def token_linear_fits(n_rows: int, n_in: int) -> bool:

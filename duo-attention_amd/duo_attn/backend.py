@@ -99,6 +99,9 @@ class HipBackend:
 
     # -- the torch.nn.Linear / RMSNorm / SiLU*mul / residual-add modules either side of the attention op at q_len == 1
     #    (reference llama.py:332-340, :430-432; static_kv_cache.py:482-537): weight rows streamed once, one launch each
+    def silu_mul(self, gate, up):
+        return self._hip.silu_mul(gate, up)
+
     def token_linear_fits(self, n_rows: int, n_in: int) -> bool:
         return self._hip.token_linear_fits(n_rows, n_in)
 

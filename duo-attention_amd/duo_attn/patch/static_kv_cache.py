@@ -393,9 +393,23 @@ def duo_attn_static_kv_cache_decoder_layer_forward(
     hidden_states = residual + hidden_states
     residual = hidden_states
     hidden_states = self.post_attention_layernorm(hidden_states)
-    hidden_states = self.mlp(hidden_states)
+    hidden_states = _mlp_forward(self.mlp, hidden_states)
     hidden_states = residual + hidden_states
     return (hidden_states,)
+
+
+def _mlp_forward(mlp, x):
+    """HF LlamaMLP / MistralMLP: ``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` with the activation product as ONE
+    elementwise pass (duo_silu_mul_bf16) instead of a SiLU kernel and a multiply — same roundings; anything that is not a
+    SiLU-gated bf16 MLP on the GPU (or a backend without the kernel) runs the module as it is"""
+    from ..backend import get_backend
+
+    be = get_backend()
+    if (hasattr(be, "silu_mul") and x.is_cuda and x.dtype == torch.bfloat16
+            and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
+            and all(hasattr(mlp, n) for n in ("gate_proj", "up_proj", "down_proj"))):
+        return mlp.down_proj(be.silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
+    return mlp(x)
 
 
 def enable_duo_attention_static_kv_cache(model):

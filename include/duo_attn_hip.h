@@ -33,12 +33,13 @@
  *                             (static_kv_cache.py:60-125; flash_attn_func batches natively):
  *                             the batch row is a grid dimension, one launch for all rows
  *
+ *   duo_silu_mul_bf16         act_fn(gate) * up of HF's LlamaMLP on prefill chunks (<- static_kv_cache.py:528-537)
  *   duo_token_linear_bf16     the torch.nn.Linear / RMSNorm / SiLU*mul / residual-add modules either side of the
  *                             attention op at q_len == 1: llama.py:332-340, :430-432; static_kv_cache.py:482-537
  *
  * ABI version 2 (round 3): duo_kv_seg gained `batch_stride`, the `_batched` entry points were
  * added, duo_int4_dequantize_f16 / duo_attn_decode_int4_f16 take a `fused` flag.
- * ABI version 3: + duo_token_linear_bf16 (additions only).
+ * ABI version 3: + duo_token_linear_bf16, duo_silu_mul_bf16 (additions only).
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -419,6 +420,12 @@ int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_stride, int6
 /* ---- RMSNorm: y = x * rsqrt(mean(x^2) + eps) * w, rows of `hidden` bf16 ---- */
 int duo_rmsnorm_bf16(const void *x, const void *w, void *y, int64_t n_rows,
                      int32_t hidden, float eps, void *stream);
+
+/* ---- SiLU(gate) * up of the SwiGLU MLP on whole chunks (HF LlamaMLP.forward: act_fn(gate_proj(x)) * up_proj(x), called from
+ * the decoder layer at duo_attn/patch/static_kv_cache.py:528-537): one pass, silu(gate) rounded to bf16 before the product
+ * as the module sequence does.  [n_rows, n_cols] bf16, row strides in elements (multiples of 8), 16-byte aligned bases. ---- */
+int duo_silu_mul_bf16(const void *gate, int64_t gate_row_stride, const void *up, int64_t up_row_stride, void *y,
+                      int64_t y_row_stride, int64_t n_rows, int32_t n_cols, void *stream);
 
 /* ---- token-row linear layers of the decode step -------------------------------------------------------------------
  * At q_len == 1 the projections either side of the attention op are matrix-vector products over weights that are read

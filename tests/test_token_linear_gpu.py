@@ -173,3 +173,26 @@ def test_fused_decode_layer_matches_module_by_module(family, bsz):
     for l in range(3):
         a, b = c_f.full_value_states_list[l][:, :90].float(), c_m.full_value_states_list[l][:, :90].float()
         assert ((a - b).norm() / b.norm().clamp_min(1e-6)).item() < 2e-2
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 300, 1024), 0), ((1, 16384, 14336), 0), ((5, 7, 72), 8), ((1, 1, 8), 0)])
+def test_silu_mul_is_the_module_sequence(shape, pad):
+    """duo_silu_mul_bf16 == act_fn(gate) * up of HF's LlamaMLP, intermediate rounding included: bit for bit against torch's
+    own two kernels on the GPU up to the last bit of exp (allowed: one bf16 ulp on <= 0.1 % of the elements), and within one
+    ulp of the fp32 CPU restatement"""
+    from duo_attn import _hip
+
+    g = torch.Generator().manual_seed(sum(shape) + pad)
+    n = shape[-1]
+    gate_full = _rand(shape[:-1] + (n + pad,), g, scale=2.0).to(DEV)
+    up_full = _rand(shape[:-1] + (n + pad,), g).to(DEV)
+    gate, up = gate_full[..., :n], up_full[..., :n]
+    got = _hip.silu_mul(gate, up)
+    want = torch.nn.functional.silu(gate) * up
+    assert got.shape == want.shape
+    diff = (got.float() - want.float()).abs()
+    assert (diff <= (2.0 ** -7) * want.float().abs() + 1e-30).all()
+    assert (got != want).float().mean().item() <= 1e-3
+    if gate.numel() <= 1 << 20:
+        ref = (torch.nn.functional.silu(gate.cpu().float()).to(torch.bfloat16).float() * up.cpu().float()).to(torch.bfloat16)
+        assert ((got.cpu().float() - ref.float()).abs() <= (2.0 ** -7) * ref.float().abs() + 1e-30).all()
