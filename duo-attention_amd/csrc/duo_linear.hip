@@ -21,9 +21,11 @@
 // module-by-module one only by the summation order inside a dot product.
 //
 // Work split: one weight row = one wave (64 lanes x 16 bytes per load instruction = 1 KiB of the row), rows dealt
-// round-robin to all waves of the grid; a wave keeps two groups of four loads in flight across row boundaries (the next
-// group is issued unconditionally — behind the wave's last group it re-reads that group — so the waits are counted).
-// The grid is chosen so that every wave gets the same number of rows (token_linear_grid below).
+// round-robin to the streaming waves of the grid; a wave keeps two groups of four loads in flight across row boundaries
+// (the next group is issued unconditionally — behind the wave's last group it re-reads that group — so the waits are
+// counted).  FOUR streaming waves per CU (one workgroup per CU) when that deals the rows evenly: measured faster than 8,
+// 12 or 16 on every shape (profiles/r3_token_linear.md); token_linear_grid below picks the count.
+#include <stdlib.h>
 #include <type_traits>
 #include "duo_common.h"
 #include "duo_kv_ops.h"
@@ -46,6 +48,7 @@ struct TokenLinearParams {
     int32_t K, kpad, gpr;           // gpr: groups of kLinG x 512 elements per weight row, EVEN (kpad = gpr * kLinG * 512)
     LinSegDev seg[3];
     int32_t n_total;
+    int32_t sw;                     // waves per workgroup that take rows (<= blockDim / 64)
     const bf16_t *norm_w;
     float eps;
     const bf16_t *res;
@@ -69,6 +72,16 @@ __device__ __forceinline__ float wave_sum(float x) {
            (__int_as_float(__builtin_amdgcn_readlane(xi, 32)) + __int_as_float(__builtin_amdgcn_readlane(xi, 48)));
 }
 
+// the token-row chunk in `reg` has landed: the two weight groups issued behind it may still fly — or nothing at all in a
+// wave without rows, which skipped them (has_rows == 0)
+#define LIN_WAIT_X(reg)                                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%1)\n\t"                                                                               \
+                 "s_cmp_eq_u32 %2, 0\n\t"                                                                                 \
+                 "s_cbranch_scc0 2f\n\t"                                                                                  \
+                 "s_waitcnt vmcnt(0)\n"                                                                                   \
+                 "2:"                                                                                                     \
+                 : "+v"(reg) : "n"(2 * kLinG), "s"(has_rows) : "scc")
+
 template <int B, int PRO>
 __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinearParams P) {
     extern __shared__ __attribute__((aligned(16))) uint32_t xs[];      // [B][kpad / 2] packed bf16 pairs
@@ -76,8 +89,17 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
     const int tid = threadIdx.x, lane = tid & 63;
     const int nthr = blockDim.x, nw = nthr >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int TW = gridDim.x * nw, gw = blockIdx.x * nw + wave;
-    const int my_rows = gw < P.n_total ? (P.n_total - gw + TW - 1) / TW : 0;
+    // rows go to the first P.sw waves of a workgroup only: the stream is fastest with FEW waves per CU (measured: 4 per CU
+    // beat 8, 12 and 16 on every shape), while staging long token rows wants many threads — the other waves stage, meet the
+    // barrier and leave
+    const int sw = P.sw;
+    const int TW = gridDim.x * sw, gw = blockIdx.x * sw + wave;
+    const int my_rows = __builtin_amdgcn_readfirstlane(wave < sw && gw < P.n_total ? (P.n_total - gw + TW - 1) / TW : 0);
+    uint32_t has_rows;           // (wave-uniform; the asm puts it in an SGPR whatever unit the compiler computed my_rows on)
+    {
+        const uint32_t hv = my_rows > 0 ? 1u : 0u;
+        asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(has_rows) : "v"(hv));
+    }
     const int gpr = P.gpr, K = P.K;
     const int xrow = P.kpad >> 1;                                       // dwords per staged token row
 
@@ -99,16 +121,25 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
     auto issue = [&](int i, int g, u32x4 (&buf)[kLinG]) __attribute__((always_inline)) {
         const int n = min(gw + max(min(i, my_rows - 1), 0) * TW, P.n_total - 1);     // (a wave without rows reads a valid row, never consumed)
         const uint64_t wr = row_ptr(n);
+        uint32_t off[kLinG];
 #pragma unroll
-        for (int j = 0; j < kLinG; ++j) {
-            const int k0 = ((g * kLinG + j) * 64 + lane) * 8;
-            const uint32_t off = (uint32_t)min(k0, K - 8) * 2u;
-            // (asm: the stream's loads are outside the compiler's wait bookkeeping on purpose — its loop-carried
-            //  analysis put a vmcnt(0) at the loop head, i.e. it let the prefetch drain every second group; the waits
-            //  are the explicit counted ones in lin_wait below)
-            asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(buf[j]) : "v"(off), "s"(wr));
-        }
+        for (int j = 0; j < kLinG; ++j) off[j] = (uint32_t)min(((g * kLinG + j) * 64 + lane) * 8, K - 8) * 2u;
+        // (asm: the stream's loads are outside the compiler's wait bookkeeping on purpose — its loop-carried analysis
+        //  put a vmcnt(0) at the loop head, i.e. it let the prefetch drain every second group; the waits are the
+        //  explicit counted ones in lin_wait below.  A wave without rows branches over them INSIDE the statement:
+        //  to the compiler it is the same straight-line code for every wave.)
+        asm volatile("s_cmp_eq_u32 %[hr], 0\n\t"
+                     "s_cbranch_scc1 1f\n\t"
+                     "global_load_dwordx4 %[d0], %[o0], %[b] nt\n\t"
+                     "global_load_dwordx4 %[d1], %[o1], %[b] nt\n\t"
+                     "global_load_dwordx4 %[d2], %[o2], %[b] nt\n\t"
+                     "global_load_dwordx4 %[d3], %[o3], %[b] nt\n"
+                     "1:"
+                     : [d0] "=&v"(buf[0]), [d1] "=&v"(buf[1]), [d2] "=&v"(buf[2]), [d3] "=&v"(buf[3])
+                     : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [b] "s"(wr), [hr] "s"(has_rows)
+                     : "scc");
     };
+    static_assert(kLinG == 4, "issue() names four loads");
 
     u32x4 bufA[kLinG], bufB[kLinG];
     const int T = my_rows * gpr;
@@ -220,10 +251,10 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
         for (int it = 0; it < XI; ++it) {
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr[b][it]) : "n"(2 * kLinG));
-                if constexpr (PRO == PRO_SILU && B * XPER <= 4) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x2r[b][it]) : "n"(2 * kLinG));
+                LIN_WAIT_X(xr[b][it]);
+                if constexpr (PRO == PRO_SILU && B * XPER <= 4) LIN_WAIT_X(x2r[b][it]);
             }
-            if constexpr (PRO == PRO_NORM) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(nwr[it]) : "n"(2 * kLinG));
+            if constexpr (PRO == PRO_NORM) LIN_WAIT_X(nwr[it]);
         }
         if (fast) {
             if constexpr (PRO == PRO_NORM) {
@@ -348,31 +379,42 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
     flush();          // (the launcher keeps a wave's rows <= 64)
 }
 
-// Workgroups and threads per workgroup.  Rows are dealt round-robin to waves, so the launch ends with the wave that has
-// one row more than the others: pick the wave count (16, 14, 12, 10 or 8 per CU) that deals the rows most evenly.  With
-// 256-thread workgroups every such count is a whole number of workgroups per CU; every workgroup stages the token rows
-// itself, so long rows (down_proj: 14336 features, twice that read for the SiLU prologue) use 1024-thread workgroups —
-// a quarter of the staging work and L2 traffic — when 16 waves per CU deal the rows evenly enough.
-static void token_linear_grid(int n_total, int n_in, int n_rows, size_t lds_bytes, int &blocks, int &threads) {
+// Workgroups, threads per workgroup and streaming waves per workgroup.  Rows are dealt round-robin to the streaming waves,
+// so the launch ends with the wave that has one row more than the others: the count must deal the rows evenly.  Among
+// the counts that do, FEWER streaming waves per CU are faster — measured on every shape of a Llama-3-8B layer (device-side
+// durations, profiles/r3_token_linear.md): o_proj 12.2 / 10.5 / 8.6 us and gate|up 47 / 46 / 41 us at 16 / 8 / 4 waves per
+// CU — so 4 per CU (one workgroup per CU) is preferred and a larger count has to deal the rows at least 2 % better.
+// Staging is the opposite: every workgroup stages the token rows itself, and long rows (down_proj: 14336 features, twice
+// that read for the SiLU prologue) want many threads — those launches use 1024-thread workgroups of which the first four
+// waves stream (29.2 -> 24.7 us against four-wave workgroups).
+static void token_linear_grid(int n_total, int n_in, int n_rows, size_t lds_bytes, int &blocks, int &threads, int &sw) {
     auto eff_of = [&](int tw) { const int r = (n_total + tw - 1) / tw; return (double)n_total / ((double)r * tw); };
-    static const int cand[5] = {16, 14, 12, 10, 8};               // waves per CU (x 256 CUs)
+    static const int cand[6] = {4, 8, 16, 12, 14, 10};            // streaming waves per CU (x 256 CUs), in order of preference
+    static const int forced = [] { const char *e = getenv("DUO_LINEAR_WAVES_PER_CU"); return e ? atoi(e) : 0; }();   // (sweeps)
+    static const int forced_thr = [] { const char *e = getenv("DUO_LINEAR_THREADS"); return e ? atoi(e) : 0; }();
     double best = -1.0;
-    int best_c = 16;
+    int best_c = 4;
     for (int c : cand) {
         const double e = eff_of(256 * c);
-        if (e > best + 1e-9) { best = e; best_c = c; }
+        if (e > best + 0.02) { best = e; best_c = c; }           // (a later candidate has to deal the rows 2 % better)
     }
-    const bool long_rows = (int64_t)n_in * n_rows > 8192;
-    if (lds_bytes > 38 * 1024 || (long_rows && eff_of(4096) >= 0.95 * best)) {
-        threads = lds_bytes > 78 * 1024 || long_rows ? 1024 : 512;
-        blocks = 256 * 16 * 64 / threads;                          // 16 waves per CU
-    } else {
-        threads = 256;
-        blocks = 256 * best_c / 4;
-    }
+    if (forced > 0 && forced <= 16) best_c = forced;
+    // threads per workgroup: 256 stage a 4096-feature row in two chunks each; long rows (down_proj: 14336 features, twice
+    // that read for the SiLU prologue) take 1024
+    const bool long_rows = (int64_t)n_in * n_rows > 8192 || lds_bytes > 38 * 1024;
+    threads = forced_thr == 256 || forced_thr == 512 || forced_thr == 1024 ? forced_thr : long_rows ? 1024 : 256;
+    if (lds_bytes > 78 * 1024) threads = 1024;
     const int wpb = threads / 64;
-    if ((int64_t)blocks * wpb > n_total) blocks = (n_total + wpb - 1) / wpb;     // fewer rows than waves
-    while ((int64_t)blocks * wpb * 64 < n_total) blocks *= 2;                    // a wave parks at most 64 row totals
+    const int per_cu = lds_bytes > 78 * 1024 ? 1 : lds_bytes > 38 * 1024 ? 2 : 4;       // workgroups that fit a CU's LDS
+    // one workgroup per CU carries best_c streaming waves when it can (best_c <= its waves); else several workgroups
+    int wgs_per_cu = 1;
+    sw = best_c;
+    while (sw > wpb && wgs_per_cu < per_cu) { wgs_per_cu *= 2; sw = best_c / wgs_per_cu; }
+    if (sw > wpb) sw = wpb;
+    if (sw < 1) sw = 1;
+    blocks = 256 * wgs_per_cu;
+    if ((int64_t)blocks * sw > n_total) blocks = (n_total + sw - 1) / sw;        // fewer rows than waves
+    while ((int64_t)blocks * sw * 64 < n_total) blocks *= 2;                     // a wave parks at most 64 row totals
 }
 
 template <int B>
@@ -416,7 +458,7 @@ extern "C" int duo_token_linear_bf16(const duo_token_linear_args *a, void *strea
     const size_t lds = (size_t)a->n_rows * P.kpad * 2;
     if (lds > 156 * 1024) return DUO_EINVAL;                        // n_rows * n_in beyond one CU's LDS
     int blocks, threads;
-    token_linear_grid(P.n_total, a->n_in, a->n_rows, lds, blocks, threads);
+    token_linear_grid(P.n_total, a->n_in, a->n_rows, lds, blocks, threads, P.sw);
     const int pro = a->norm_weight ? PRO_NORM : a->x2 ? PRO_SILU : PRO_NONE;
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024) {

@@ -227,6 +227,29 @@ def _streamable_linear(m) -> bool:
             and (m.bias is None or m.bias.dtype == torch.bfloat16))
 
 
+def _layer_modules(layer):
+    attn, mlp = layer.self_attn, getattr(layer, "mlp", None)
+    return [getattr(attn, n, None) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + \
+           [getattr(mlp, n, None) for n in ("gate_proj", "up_proj", "down_proj")]
+
+
+def _layer_static_verdict(layer) -> bool:
+    """the part of the eligibility that depends on the layer's modules only; cached on the layer, keyed by the identity of
+    the modules and of their weight storage (re-sharding or re-loading a layer re-evaluates it)"""
+    mods = _layer_modules(layer)
+    key = tuple((id(m), m.weight.data_ptr() if getattr(m, "weight", None) is not None else 0) for m in mods)
+    cached = getattr(layer, "_duo_fused_decode_verdict", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    mlp = getattr(layer, "mlp", None)
+    ok = (mlp is not None and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
+          and all(_streamable_linear(m) for m in mods)
+          and all(hasattr(n, "variance_epsilon") and n.weight.dtype == torch.bfloat16
+                  for n in (layer.input_layernorm, layer.post_attention_layernorm)))
+    layer._duo_fused_decode_verdict = (key, ok)
+    return ok
+
+
 def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
     """Whether this decoder layer's decode step can run as the fused form below: one token per batch row after a
     prefill, bf16 on the GPU, plain ``nn.Linear`` projections (a tensor-parallel shard's o_proj / down_proj reduce
@@ -239,18 +262,10 @@ def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
         return False
     if not isinstance(kv_cache, DuoAttentionStaticKVCache) or kv_cache.kv_seq_len_list[layer_idx] <= 0:
         return False
-    attn, mlp = layer.self_attn, getattr(layer, "mlp", None)
-    if mlp is None or type(getattr(mlp, "act_fn", None)).__name__ not in ("SiLUActivation", "SiLU"):
+    if not _layer_static_verdict(layer):
         return False
-    mods = [getattr(attn, n, None) for n in ("q_proj", "k_proj", "v_proj", "o_proj")] + \
-           [getattr(mlp, n, None) for n in ("gate_proj", "up_proj", "down_proj")]
-    if not all(_streamable_linear(m) for m in mods):
-        return False
-    for norm in (layer.input_layernorm, layer.post_attention_layernorm):
-        if not hasattr(norm, "variance_epsilon") or norm.weight.dtype != torch.bfloat16:
-            return False
     rows = hidden_states.shape[0]
-    return all(be.token_linear_fits(rows, m.in_features) for m in mods)
+    return all(be.token_linear_fits(rows, m.in_features) for m in _layer_modules(layer))
 
 
 def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None, position_ids=None):

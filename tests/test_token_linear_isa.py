@@ -43,8 +43,10 @@ def _kernels(asm_text):
         yield m.group(1), m.group(2)
 
 
-def _audit(body):
-    """returns (violations, number of asm loads seen)"""
+def _audit(body, has_rows=None):
+    """returns (violations, number of asm loads seen).  ``has_rows``: the kernel's asm statements branch on ONE wave-uniform
+    flag (`s_cmp_eq_u32 flag, 0` + `s_cbranch_scc1 Nf` = taken when the wave has no rows, `s_cbranch_scc0 Nf` = taken when it
+    has); True / False fixes those branches for the whole walk (the two kinds of wave), None explores both ways at each."""
     prog = []          # (kind, text, in_asm)   kind: 'label' | 'ins'
     in_asm = False
     for raw in body.splitlines():
@@ -58,6 +60,9 @@ def _audit(body):
         if not line or line.startswith("."):
             if re.fullmatch(r"\.LBB\d+_\d+:", line or ""):
                 prog.append(("label", line[:-1], False))
+            continue
+        if re.fullmatch(r"\d+:", line):
+            prog.append(("label", f"{line[:-1]}@{len(prog)}", False))      # numeric local label of an asm statement
             continue
         if line.endswith(":"):
             prog.append(("label", line[:-1], False))
@@ -106,11 +111,20 @@ def _audit(body):
                 continue
             if text.startswith("s_endpgm"):
                 break
-            m = re.match(r"(s_branch|s_cbranch\S*)\s+(\.LBB\d+_\d+)", text)
+            m = re.match(r"(s_branch|s_cbranch\S*)\s+(\.LBB\d+_\d+|\d+[fb])", text)
             if m:
-                tgt = labels[m.group(2)]
+                name = m.group(2)
+                if name[0] == ".":
+                    tgt = labels[name]
+                else:       # numeric local label: the next (f) / previous (b) definition of that number
+                    hits = [j for j, (k2, t2, _) in enumerate(prog) if k2 == "label" and t2.split("@")[0] == name[:-1]]
+                    tgt = min(j for j in hits if j > i) if name[-1] == "f" else max(j for j in hits if j < i)
                 if m.group(1) == "s_branch":
                     i = tgt
+                    continue
+                if name[0] != "." and has_rows is not None and m.group(1) in ("s_cbranch_scc1", "s_cbranch_scc0"):
+                    taken = (not has_rows) if m.group(1) == "s_cbranch_scc1" else has_rows
+                    i = tgt if taken else i + 1
                     continue
                 work.append((tgt, queue))
                 i += 1
@@ -129,9 +143,10 @@ def test_no_instruction_touches_a_register_with_an_asm_load_outstanding(tmp_path
     text = open(tmp_path / "duo_linear-hip-amdgcn-amd-amdhsa-gfx950.s").read()
     names = []
     for name, body in _kernels(text):
-        v, n_loads = _audit(body)
-        assert n_loads >= 8, f"{name}: the audit did not see the asm loads ({n_loads})"
-        assert not v, f"{name}:\n  " + "\n  ".join(v[:12])
+        for has_rows in (True, False):          # a wave that streams rows / a wave that only stages the token rows
+            v, n_loads = _audit(body, has_rows)
+            assert n_loads >= (10 if has_rows else 2), f"{name}: the audit did not see the asm loads ({n_loads})"
+            assert not v, f"{name} (has_rows={has_rows}):\n  " + "\n  ".join(v[:12])
         names.append(name)
     assert len(names) == 12, names          # 4 row counts x 3 prologues
 
@@ -160,3 +175,23 @@ def test_audit_catches_a_copy_before_the_wait():
     """
     v, _ = _audit(counted)
     assert len(v) == 1 and "v14" in v[0]
+    # a branch over the loads inside an asm statement is a path of its own: the wait that is enough behind the loads is not
+    # enough for an OLDER load on the path that skipped them
+    skipping = """
+    ;ASMSTART
+    global_load_dwordx4 v[20:23], v1, s[2:3]
+    ;ASMEND
+    ;ASMSTART
+    s_cmp_eq_u32 s9, 0
+    s_cbranch_scc1 1f
+    global_load_dwordx4 v[10:13], v1, s[2:3]
+    1:
+    ;ASMEND
+    ;ASMSTART
+    s_waitcnt vmcnt(1)
+    ;ASMEND
+    v_add_f32 v0, v20, v21
+    """
+    assert _audit(skipping, has_rows=False)[0] and not _audit(skipping, has_rows=True)[0]
+    fixed = skipping.replace("s_waitcnt vmcnt(1)\n", "s_waitcnt vmcnt(1)\n    s_cmp_eq_u32 s9, 0\n    s_cbranch_scc0 2f\n    s_waitcnt vmcnt(0)\n    2:\n")
+    assert not _audit(fixed, has_rows=False)[0] and not _audit(fixed, has_rows=True)[0]
