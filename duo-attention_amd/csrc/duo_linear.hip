@@ -462,15 +462,19 @@ extern "C" int duo_token_linear_bf16(const duo_token_linear_args *a, void *strea
     const int pro = a->norm_weight ? PRO_NORM : a->x2 ? PRO_SILU : PRO_NONE;
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024) {
-        // (above the default dynamic-LDS limit the attribute has to be raised once per instantiation; cheap, idempotent)
-#define DUO_LIN_ATTR(Bv, PROv) (void)hipFuncSetAttribute((const void *)duo_token_linear_kernel<Bv, PROv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        // above the default dynamic-LDS limit the attribute has to be raised on the instantiation that is launched
+        // (idempotent, host-side only; sized to this launch — the static part of the kernel's LDS comes on top)
+        const void *fn = nullptr;
+#define DUO_LIN_FN(Bv) (pro == PRO_NORM ? (const void *)duo_token_linear_kernel<Bv, PRO_NORM> : pro == PRO_SILU ? (const void *)duo_token_linear_kernel<Bv, PRO_SILU> : (const void *)duo_token_linear_kernel<Bv, PRO_NONE>)
         switch (a->n_rows) {
-        case 1: DUO_LIN_ATTR(1, PRO_NONE); DUO_LIN_ATTR(1, PRO_NORM); DUO_LIN_ATTR(1, PRO_SILU); break;
-        case 2: DUO_LIN_ATTR(2, PRO_NONE); DUO_LIN_ATTR(2, PRO_NORM); DUO_LIN_ATTR(2, PRO_SILU); break;
-        case 3: DUO_LIN_ATTR(3, PRO_NONE); DUO_LIN_ATTR(3, PRO_NORM); DUO_LIN_ATTR(3, PRO_SILU); break;
-        default: DUO_LIN_ATTR(4, PRO_NONE); DUO_LIN_ATTR(4, PRO_NORM); DUO_LIN_ATTR(4, PRO_SILU); break;
+        case 1: fn = DUO_LIN_FN(1); break;
+        case 2: fn = DUO_LIN_FN(2); break;
+        case 3: fn = DUO_LIN_FN(3); break;
+        default: fn = DUO_LIN_FN(4); break;
         }
-#undef DUO_LIN_ATTR
+#undef DUO_LIN_FN
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
     }
     switch (a->n_rows) {
     case 1: token_linear_launch<1>(P, pro, dim3(blocks), dim3(threads), lds, s); break;

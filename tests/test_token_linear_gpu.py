@@ -52,6 +52,9 @@ CASES = [
     (1, 8, (3,), False, "none", False, 0),                       # smallest
     (2, 2048, (1000, 7), False, "silu", False, 0),               # two blocks, odd sizes
     (1, 4096, (32064,), False, "none", False, 0),                # wide output (several rows per wave)
+    (4, 14336, (520,), False, "silu", True, 0),                  # 128 KiB of token rows in LDS (above the 64 KiB default limit)
+    (3, 14336, (256, 8), True, "norm", False, 0),                # 96 KiB
+    (1, 4096, (128256,), False, "norm", False, 0),               # lm_head-sized: > 64 rows per wave at the preferred wave count
 ]
 
 
