@@ -451,6 +451,74 @@ def _exact_rows(q_rows, K, V, vis, scale):
     return torch.einsum("ngt,td->ngd", torch.softmax(s_, -1), V.float())
 
 
+def token_linear_leg(device, n_layers=32, reps=20):
+    """The decode step's token-row linears (DESIGN row (g), csrc/duo_linear.hip), driver-timed: the four launches of a
+    Llama-3-8B decoder layer (q|k|v with the RMSNorm prologue, o_proj + residual, gate|up with the RMSNorm prologue,
+    down_proj with the SiLU*mul prologue + residual) over `n_layers` DISTINCT weight sets (436 MB each: nothing is served
+    from L2 / MALL), captured once in a HIP graph and replayed — device time without host launch overhead, the way the
+    model-level decode step runs them.  HBM-bound: algorithmic bytes = the weight bytes.  Live parity of one layer's
+    chain against the same modules through torch (library GEMMs, separate norm / activation / add kernels)."""
+    import torch.nn.functional as F
+    from duo_attn import _hip
+
+    Hd, I, NQ, NKV = HIDDEN, 14336, HQ * D, HKV * D
+    g = torch.Generator(device=device).manual_seed(5)
+    rn = lambda *s_, sc=1.0: (torch.randn(*s_, generator=g, device=device, dtype=torch.float32) * sc).to(torch.bfloat16)
+    Ws = [dict(q=rn(NQ, Hd, sc=Hd ** -0.5), k=rn(NKV, Hd, sc=Hd ** -0.5), v=rn(NKV, Hd, sc=Hd ** -0.5), o=rn(Hd, NQ, sc=NQ ** -0.5),
+               g=rn(I, Hd, sc=Hd ** -0.5), u=rn(I, Hd, sc=Hd ** -0.5), d=rn(Hd, I, sc=I ** -0.5), n1=rn(Hd).abs() + 0.5, n2=rn(Hd).abs() + 0.5)
+          for _ in range(n_layers)]
+    h0, ao = rn(1, Hd), rn(1, NQ)
+    layer_bytes = (NQ + 2 * NKV + NQ + 3 * I) * Hd * 2
+
+    def layer(w, h):
+        _hip.token_linear(h, [(w["q"], None), (w["k"], None), (w["v"], None)], norm=(w["n1"], 1e-5))     # (attention op between: not timed here)
+        h1 = _hip.token_linear(ao, [(w["o"], None)], residual=h)
+        gu = _hip.token_linear(h1, [(w["g"], None), (w["u"], None)], norm=(w["n2"], 1e-5))
+        return _hip.token_linear(gu[:, :I], [(w["d"], None)], x2=gu[:, I:], residual=h1)
+
+    def chain():
+        h = h0
+        for w in Ws:
+            h = layer(w, h)
+        return h
+
+    for _ in range(2):
+        chain()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        chain()
+    for _ in range(3):
+        graph.replay()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        graph.replay()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+    # live parity: one layer through torch's own modules (flashinfer-form RMSNorm = duo_rmsnorm_bf16)
+    w = Ws[0]
+    got = layer(w, h0)
+    xn = _hip.rmsnorm(h0, w["n1"], 1e-5)
+    h1 = h0 + F.linear(ao, w["o"])
+    xn2 = _hip.rmsnorm(h1, w["n2"], 1e-5)
+    want = h1 + F.linear(F.silu(F.linear(xn2, w["g"])) * F.linear(xn2, w["u"]), w["d"])
+    del xn
+    rel = ((got.float() - want.float()).norm() / want.float().norm()).item()
+    gbps = layer_bytes * n_layers / t / 1e9
+    return {"what": "q|k|v, o_proj, gate|up, down_proj of a Llama-3-8B decoder layer at q_len == 1 (duo_token_linear_bf16), "
+                    f"{n_layers} distinct layers in one captured graph",
+            "layers": n_layers, "launches_per_layer": 4, "algorithmic_bytes_per_layer": float(layer_bytes),
+            "us_per_layer": t / n_layers * 1e6, "ms_per_token_32_layers": t / n_layers * 32 * 1e3,
+            "roofline": {"kernel": "duo_token_linear_kernel", "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": gbps * 1e9 / HBM_PEAK, "traffic": None,
+                         "avg_launch_ms": t / n_layers / 4 * 1e3, "algorithmic_bytes_per_launch": layer_bytes / 4.0},
+            "parity_vs_torch_modules_rel_l2": rel}
+
+
 def int4_leg(device, ctx=1048576, reps=5, parity=True, prefill=True):
     """BASELINE configs[4] (INT4 KV pools), driver-timed: (1) `duo_int4_decode_mfma_kernel` — the fused decode attention
     of ONE layer (4 retrieval + 4 streaming kv heads) straight on the packed pools at a 1 M-token context: 136 B per
@@ -806,6 +874,13 @@ def main():
                                 "avg_launch_ms": d["kernel_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"]}
         except Exception as e:      # extra information: never at the price of the bench line
             int4 = {"error": f"{type(e).__name__}: {e}"}
+    tlin = None
+    if world == 1 and not args.no_model_level:
+        try:
+            tlin = token_linear_leg(device)
+            torch.cuda.empty_cache()
+        except Exception as e:      # extra information: never at the price of the bench line
+            tlin = {"error": f"{type(e).__name__}: {e}"}
     if cpu is not None and args.cpu_cfg1_layers > 0:
         try:
             cpu["cfg1_end_to_end"] = cpu_cfg1_end_to_end(args.cpu_cfg1_layers)
@@ -873,6 +948,7 @@ def main():
                             "roofline_decode.whole_step"),
             "parity_live": parity,
             "roofline_int4": int4,
+            "roofline_token_linear": tlin,
             "model_level": mlevel,
             "pipeline": None if world == 1 else {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
