@@ -283,7 +283,7 @@ def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None,
     attn, mlp = layer.self_attn, layer.mlp
     bsz, _, hidden = hidden_states.shape
     num_heads, num_kv, head_dim, _ = _dims(attn)
-    x = hidden_states.view(bsz, hidden)
+    x = hidden_states.reshape(bsz, hidden)
     n_ln, p_ln = layer.input_layernorm, layer.post_attention_layernorm
     qkv = be.token_linear(x, [(attn.q_proj.weight, attn.q_proj.bias), (attn.k_proj.weight, attn.k_proj.bias),
                               (attn.v_proj.weight, attn.v_proj.bias)], norm=(n_ln.weight, n_ln.variance_epsilon))
@@ -295,7 +295,7 @@ def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None,
     if pos0 is None and position_ids is not None:
         pos0 = first_positions(position_ids)
     ao = duo_static_attention_core(q, k, v, kv_cache, layer_idx, pos0, rope_scale, rope_theta)
-    h1 = be.token_linear(ao.view(bsz, nq), [(attn.o_proj.weight, attn.o_proj.bias)], residual=x)
+    h1 = be.token_linear(ao.reshape(bsz, nq), [(attn.o_proj.weight, attn.o_proj.bias)], residual=x)
     gu = be.token_linear(h1, [(mlp.gate_proj.weight, mlp.gate_proj.bias), (mlp.up_proj.weight, mlp.up_proj.bias)],
                          norm=(p_ln.weight, p_ln.variance_epsilon))
     inter = mlp.gate_proj.out_features
