@@ -220,7 +220,14 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
 _FUSED_DECODE_LAYER = os.environ.get("DUO_FUSED_DECODE_LAYER", "1") != "0"     # (0: module by module, for A/B)
 
 
+def _row_parallel(m):
+    """a tensor-parallel shard's o_proj / down_proj (duo_attn/tp.py: RowParallelLinear): the local slice + the group"""
+    return type(m).__name__ == "RowParallelLinear" and hasattr(m, "inner") and hasattr(m, "group")
+
+
 def _streamable_linear(m) -> bool:
+    if _row_parallel(m):
+        m = m.inner
     w = getattr(m, "weight", None)
     return (type(m) is torch.nn.Linear and w is not None and w.dtype == torch.bfloat16 and w.is_cuda
             and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0
@@ -252,9 +259,8 @@ def _layer_static_verdict(layer) -> bool:
 
 def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
     """Whether this decoder layer's decode step can run as the fused form below: one token per batch row after a
-    prefill, bf16 on the GPU, plain ``nn.Linear`` projections (a tensor-parallel shard's o_proj / down_proj reduce
-    across ranks BEFORE the residual add, so sharded layers keep the module-by-module path), SiLU-gated MLP,
-    RMSNorm modules with the patched forward, a backend that has the kernel."""
+    prefill, bf16 on the GPU, ``nn.Linear`` projections (or a tensor-parallel shard's row-parallel o_proj / down_proj),
+    SiLU-gated MLP, RMSNorm modules with the patched forward, a backend that has the kernel."""
     if not _FUSED_DECODE_LAYER or hidden_states.dim() != 3 or hidden_states.shape[1] != 1:
         return False
     be = get_backend()
@@ -265,7 +271,7 @@ def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
     if not _layer_static_verdict(layer):
         return False
     rows = hidden_states.shape[0]
-    return all(be.token_linear_fits(rows, m.in_features) for m in _layer_modules(layer))
+    return all(be.token_linear_fits(rows, (m.inner if _row_parallel(m) else m).in_features) for m in _layer_modules(layer))
 
 
 def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None, position_ids=None):
@@ -278,7 +284,11 @@ def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None,
         h2    = Wd . (silu(g) * u) + h1              SiLU*mul in the prologue, second residual add in the epilogue
 
     Every value the modules materialise as a bf16 tensor is rounded to bf16 at the same point (csrc/duo_linear.hip);
-    the linears differ from the library GEMM only by the summation order of their fp32 dot products."""
+    the linears differ from the library GEMM only by the summation order of their fp32 dot products.
+
+    Tensor-parallel shard (``duo_attn.tp.shard_model_for_tp``): o_proj / down_proj are row-parallel — the local product
+    is all-reduced over the TP group BEFORE the residual add (reference ``tensor_parallel`` semantics, utils.py:206-227),
+    so their residual epilogue becomes a separate add behind the all-reduce; the other two launches are unchanged."""
     be = get_backend()
     attn, mlp = layer.self_attn, layer.mlp
     bsz, _, hidden = hidden_states.shape
@@ -295,12 +305,23 @@ def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None,
     if pos0 is None and position_ids is not None:
         pos0 = first_positions(position_ids)
     ao = duo_static_attention_core(q, k, v, kv_cache, layer_idx, pos0, rope_scale, rope_theta)
-    h1 = be.token_linear(ao.reshape(bsz, nq), [(attn.o_proj.weight, attn.o_proj.bias)], residual=x)
+    h1 = _out_linear(be, attn.o_proj, ao.reshape(bsz, nq), None, x)
     gu = be.token_linear(h1, [(mlp.gate_proj.weight, mlp.gate_proj.bias), (mlp.up_proj.weight, mlp.up_proj.bias)],
                          norm=(p_ln.weight, p_ln.variance_epsilon))
     inter = mlp.gate_proj.out_features
-    h2 = be.token_linear(gu[:, :inter], [(mlp.down_proj.weight, mlp.down_proj.bias)], x2=gu[:, inter:], residual=h1)
+    h2 = _out_linear(be, mlp.down_proj, gu[:, :inter], gu[:, inter:], h1)
     return h2.view(bsz, 1, hidden)
+
+
+def _out_linear(be, proj, x, x2, residual):
+    """o_proj / down_proj of the fused decode layer: ``proj(x [* silu-partner x2]) + residual`` in one launch, or — row
+    parallel — the local product, the all-reduce over the TP group, then the add"""
+    if not _row_parallel(proj):
+        return be.token_linear(x, [(proj.weight, proj.bias)], x2=x2, residual=residual)
+    from ..tp import all_reduce_sum
+
+    y = be.token_linear(x, [(proj.inner.weight, proj.inner.bias)], x2=x2)
+    return residual + all_reduce_sum(y, proj.group)
 
 
 # =============================================================================

@@ -145,11 +145,26 @@ def _tp_worker(rank, world, port, fused, q):
         else:
             heads = TP_HEADS
         rec = _recording_backend(fused)
+        # the decode steps' token-row linears run fused on a shard too: o_proj / down_proj as local product -> all-reduce ->
+        # residual add (duo_attn/patch/_duo.py::_out_linear); count them
+        from duo_attn.patch import _duo
+
+        n_out, orig_out = {"n": 0, "row_parallel": 0}, _duo._out_linear
+
+        def counting_out(be, proj, *a):
+            n_out["n"] += 1
+            n_out["row_parallel"] += int(_duo._row_parallel(proj))
+            return orig_out(be, proj, *a)
+
+        _duo._out_linear = counting_out
         try:
             logits, kv = _run_static(model, heads, TP_CHUNKS, _ids(sum(TP_CHUNKS), 22))
         finally:
             backend._set_backend_for_testing(None)
+            _duo._out_linear = orig_out
         assert rec.calls and kv.kv_seq_len == sum(TP_CHUNKS)
+        assert n_out["n"] == 3 * 3 * 2, n_out                      # 3 decode steps x 3 layers x (o_proj, down_proj)
+        assert n_out["row_parallel"] == (n_out["n"] if world > 1 else 0), n_out
         if not fused:
             assert any(c[0].shape[0] == 1 for c in rec.calls)        # the decode steps went through `attention`
         check_calls_against_oracle(rec.calls, f"tp{world} rank {rank}")
