@@ -352,7 +352,8 @@ def measure_traffic(args):
         for name, mean, cnt in rows:
             key = "duo_prefill" if (("duo_prefill_w64_kernel" in name or "duo_prefill_kernel" in name) and "f16" not in name) else (
                 "duo_decode_scan_kernel" if ("duo_decode_scan_kernel" in name or "duo_decode_split_kernel" in name) else (
-                    "duo_int4_decode_mfma_kernel" if "duo_int4_decode_mfma_kernel" in name else None))
+                    "duo_int4_decode_mfma_kernel" if "duo_int4_decode_mfma_kernel" in name else (
+                        "duo_token_linear_kernel" if "duo_token_linear_kernel" in name else None)))
             if key:
                 tot, c0 = acc.get(key, (0.0, 0))
                 acc[key] = (tot + float(mean) * cnt, c0 + cnt)
@@ -380,6 +381,11 @@ def traffic_probe(args, device):
     hp.free()
     if not args.no_int4:
         int4_leg(device, reps=2, parity=False, prefill=False)     # a few launches of the INT4 decode kernel for FETCH_SIZE
+    # the decode step's token-row linears: the four launches of 4 distinct layers, eager (every launch a dispatch)
+    Ws, h0, _, layer, _, _ = _token_linear_setup(device, 4)
+    for w in Ws:
+        layer(w, h0)
+    torch.cuda.synchronize()
 
 
 def live_parity(device):
@@ -451,14 +457,8 @@ def _exact_rows(q_rows, K, V, vis, scale):
     return torch.einsum("ngt,td->ngd", torch.softmax(s_, -1), V.float())
 
 
-def token_linear_leg(device, n_layers=32, reps=20):
-    """The decode step's token-row linears (DESIGN row (g), csrc/duo_linear.hip), driver-timed: the four launches of a
-    Llama-3-8B decoder layer (q|k|v with the RMSNorm prologue, o_proj + residual, gate|up with the RMSNorm prologue,
-    down_proj with the SiLU*mul prologue + residual) over `n_layers` DISTINCT weight sets (436 MB each: nothing is served
-    from L2 / MALL), captured once in a HIP graph and replayed — device time without host launch overhead, the way the
-    model-level decode step runs them.  HBM-bound: algorithmic bytes = the weight bytes.  Live parity of one layer's
-    chain against the same modules through torch (library GEMMs, separate norm / activation / add kernels)."""
-    import torch.nn.functional as F
+def _token_linear_setup(device, n_layers):
+    """weights of `n_layers` Llama-3-8B decoder layers (random, bf16) and the four token-row linear launches of one layer"""
     from duo_attn import _hip
 
     Hd, I, NQ, NKV = HIDDEN, 14336, HQ * D, HKV * D
@@ -475,6 +475,21 @@ def token_linear_leg(device, n_layers=32, reps=20):
         h1 = _hip.token_linear(ao, [(w["o"], None)], residual=h)
         gu = _hip.token_linear(h1, [(w["g"], None), (w["u"], None)], norm=(w["n2"], 1e-5))
         return _hip.token_linear(gu[:, :I], [(w["d"], None)], x2=gu[:, I:], residual=h1)
+
+    return Ws, h0, ao, layer, layer_bytes, I
+
+
+def token_linear_leg(device, n_layers=32, reps=20):
+    """The decode step's token-row linears (DESIGN row (g), csrc/duo_linear.hip), driver-timed: the four launches of a
+    Llama-3-8B decoder layer (q|k|v with the RMSNorm prologue, o_proj + residual, gate|up with the RMSNorm prologue,
+    down_proj with the SiLU*mul prologue + residual) over `n_layers` DISTINCT weight sets (436 MB each: nothing is served
+    from L2 / MALL), captured once in a HIP graph and replayed — device time without host launch overhead, the way the
+    model-level decode step runs them.  HBM-bound: algorithmic bytes = the weight bytes.  Live parity of one layer's
+    chain against the same modules through torch (library GEMMs, separate norm / activation / add kernels)."""
+    import torch.nn.functional as F
+    from duo_attn import _hip
+
+    Ws, h0, ao, layer, layer_bytes, I = _token_linear_setup(device, n_layers)
 
     def chain():
         h = h0
@@ -502,11 +517,9 @@ def token_linear_leg(device, n_layers=32, reps=20):
     # live parity: one layer through torch's own modules (flashinfer-form RMSNorm = duo_rmsnorm_bf16)
     w = Ws[0]
     got = layer(w, h0)
-    xn = _hip.rmsnorm(h0, w["n1"], 1e-5)
     h1 = h0 + F.linear(ao, w["o"])
     xn2 = _hip.rmsnorm(h1, w["n2"], 1e-5)
     want = h1 + F.linear(F.silu(F.linear(xn2, w["g"])) * F.linear(xn2, w["u"]), w["d"])
-    del xn
     rel = ((got.float() - want.float()).norm() / want.float().norm()).item()
     gbps = layer_bytes * n_layers / t / 1e9
     return {"what": "q|k|v, o_proj, gate|up, down_proj of a Llama-3-8B decoder layer at q_len == 1 (duo_token_linear_bf16), "
@@ -878,6 +891,8 @@ def main():
     if world == 1 and not args.no_model_level:
         try:
             tlin = token_linear_leg(device)
+            tlin["roofline"]["traffic"] = traffic.get("duo_token_linear_kernel")     # mean over the four launch shapes, like algorithmic_bytes_per_launch
+            tlin["roofline"]["traffic_source"] = traffic_source
             torch.cuda.empty_cache()
         except Exception as e:      # extra information: never at the price of the bench line
             tlin = {"error": f"{type(e).__name__}: {e}"}
