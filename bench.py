@@ -740,6 +740,8 @@ def main():
     ap.add_argument("--no-model-level", action="store_true", help="skip the whole-HF-model run (tools/benchmark_static.py)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live parity check")
     ap.add_argument("--no-int4", action="store_true", help="skip the INT4-KV leg (BASELINE configs[4] kernels)")
+    ap.add_argument("--no-token-linear", action="store_true",
+                    help="skip the token-row-linear leg (roofline_token_linear: the decode step's q|k|v, o_proj, gate|up, down_proj)")
     ap.add_argument("--pattern", default="llama3-8b-1048k@0.5", choices=sorted(PATTERNS),
                     help="per-layer retrieval-head counts of the job (default = BASELINE configs[1])")
     ap.add_argument("--cpu-cfg1-layers", type=int, default=1,
@@ -888,7 +890,7 @@ def main():
         except Exception as e:      # extra information: never at the price of the bench line
             int4 = {"error": f"{type(e).__name__}: {e}"}
     tlin = None
-    if world == 1 and not args.no_model_level:
+    if world == 1 and not args.no_token_linear:
         try:
             tlin = token_linear_leg(device)
             tlin["roofline"]["traffic"] = traffic.get("duo_token_linear_kernel")     # mean over the four launch shapes, like algorithmic_bytes_per_launch
