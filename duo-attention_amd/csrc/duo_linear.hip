@@ -5,8 +5,8 @@
 // (duo_attn/patch/static_kv_cache.py:482-537) — are matrix-VECTOR products: every weight byte is read once per token,
 // 33-117 MB per call, nothing to reuse.  They are HBM-bound byte streaming, not GEMM work, and the library GEMM kernels
 // that serve them at M = 1 run at 0.6-4.9 TB/s (profiles/r3_model_level_kernels.md).  This file streams the weight rows
-// once with every wave of the chip holding loads in flight, keeps the token rows in LDS, and folds the element-wise
-// neighbours of each product into it:
+// once (four streaming waves per CU, two groups of loads in flight each), keeps the token rows in LDS, and folds the
+// element-wise neighbours of each product into it:
 //
 //   prologue (while the first weight loads are in flight; the token rows land in LDS as packed bf16)
 //     PRO_NONE   x as given
