@@ -26,13 +26,16 @@
 // counted).  FOUR streaming waves per CU (one workgroup per CU) when that deals the rows evenly: measured faster than 8,
 // 12 or 16 on every shape (profiles/r3_token_linear.md); token_linear_grid below picks the count.
 #include <stdlib.h>
-#include <type_traits>
 #include "duo_common.h"
 #include "duo_kv_ops.h"
 
 namespace {
 
-constexpr int kLinG = 4;            // weight loads per group (1 KiB each per wave)
+#ifndef DUO_LIN_G
+#define DUO_LIN_G 4
+#endif
+constexpr int kLinG = DUO_LIN_G;    // weight loads per group (1 KiB each per wave); two groups in flight per wave
+static_assert(kLinG == 4 || kLinG == 8, "issue() emits the loads four at a time");
 constexpr int kLinMaxRows = 4;      // token rows per call (DUO_TOKEN_LINEAR_MAX_ROWS)
 
 struct LinSegDev {
@@ -45,7 +48,7 @@ struct LinSegDev {
 struct TokenLinearParams {
     const bf16_t *x, *x2;
     int64_t x_rs;
-    int32_t K, kpad, gpr;           // gpr: groups of kLinG x 512 elements per weight row, EVEN (kpad = gpr * kLinG * 512)
+    int32_t K, kpad, gpr;           // gpr: groups of kLinG x 512 elements per weight row (kpad = gpr * kLinG * 512)
     LinSegDev seg[3];
     int32_t n_total;
     int32_t sw;                     // waves per workgroup that take rows (<= blockDim / 64)
@@ -61,8 +64,10 @@ enum { PRO_NONE = 0, PRO_NORM = 1, PRO_SILU = 2 };
 
 // the group's four loads have landed when at most N newer vector-memory operations are outstanding (loads return in order)
 template <int N>
-__device__ __forceinline__ void lin_wait(u32x4 (&buf)[4]) {
-    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(buf[0]), "+v"(buf[1]), "+v"(buf[2]), "+v"(buf[3]) : "n"(N));
+__device__ __forceinline__ void lin_wait(u32x4 (&buf)[kLinG]) {
+#pragma unroll
+    for (int j = 0; j < kLinG; j += 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(buf[j]), "+v"(buf[j + 1]), "+v"(buf[j + 2]), "+v"(buf[j + 3]) : "n"(N));
 }
 
 __device__ __forceinline__ float wave_sum(float x) {
@@ -128,18 +133,20 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
         //  put a vmcnt(0) at the loop head, i.e. it let the prefetch drain every second group; the waits are the
         //  explicit counted ones in lin_wait below.  A wave without rows branches over them INSIDE the statement:
         //  to the compiler it is the same straight-line code for every wave.)
-        asm volatile("s_cmp_eq_u32 %[hr], 0\n\t"
-                     "s_cbranch_scc1 1f\n\t"
-                     "global_load_dwordx4 %[d0], %[o0], %[b] nt\n\t"
-                     "global_load_dwordx4 %[d1], %[o1], %[b] nt\n\t"
-                     "global_load_dwordx4 %[d2], %[o2], %[b] nt\n\t"
-                     "global_load_dwordx4 %[d3], %[o3], %[b] nt\n"
-                     "1:"
-                     : [d0] "=&v"(buf[0]), [d1] "=&v"(buf[1]), [d2] "=&v"(buf[2]), [d3] "=&v"(buf[3])
-                     : [o0] "v"(off[0]), [o1] "v"(off[1]), [o2] "v"(off[2]), [o3] "v"(off[3]), [b] "s"(wr), [hr] "s"(has_rows)
-                     : "scc");
+#pragma unroll
+        for (int j = 0; j < kLinG; j += 4)
+            asm volatile("s_cmp_eq_u32 %[hr], 0\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %[d0], %[o0], %[b] nt\n\t"
+                         "global_load_dwordx4 %[d1], %[o1], %[b] nt\n\t"
+                         "global_load_dwordx4 %[d2], %[o2], %[b] nt\n\t"
+                         "global_load_dwordx4 %[d3], %[o3], %[b] nt\n"
+                         "1:"
+                         : [d0] "=&v"(buf[j]), [d1] "=&v"(buf[j + 1]), [d2] "=&v"(buf[j + 2]), [d3] "=&v"(buf[j + 3])
+                         : [o0] "v"(off[j]), [o1] "v"(off[j + 1]), [o2] "v"(off[j + 2]), [o3] "v"(off[j + 3]), [b] "s"(wr), [hr] "s"(has_rows)
+                         : "scc");
     };
-    static_assert(kLinG == 4, "issue() names four loads");
+
 
     u32x4 bufA[kLinG], bufB[kLinG];
     const int T = my_rows * gpr;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
             }
         }
     };
-    auto consume = [&](int i, int g, u32x4 (&buf)[kLinG], auto may_end_row) __attribute__((always_inline)) {
+    auto consume = [&](int i, int g, u32x4 (&buf)[kLinG]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < kLinG; ++j) {
             const int kk = (g * kLinG + j) * 256 + lane * 4;
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
                 for (int e = 0; e < 8; ++e) acc[b] = fmaf(wf[e], xf[e], acc[b]);
             }
         }
-        if (decltype(may_end_row)::value && g == gpr - 1) {       // the row is complete (wave-uniform)
+        if (g == gpr - 1) {                 // the row is complete (wave-uniform)
 #pragma unroll
             for (int b = 0; b < B; ++b) {
                 const float t = wave_sum(acc[b]);
@@ -364,15 +371,15 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
         }
     };
 
-    // (gpr is even — the launcher pads a row to whole PAIRS of groups — so a row always ends in the B half and the loop
-    //  body has no exit in the middle: one shape for the compiler, and for the audit in tests/test_token_linear_isa.py)
+    // (the loop body has no exit in the middle — with an odd number of groups the last B half is skipped by a forward
+    //  branch over its arithmetic only: one shape for the compiler, and for the audit in tests/test_token_linear_isa.py)
     int ci = 0, cg = 0;
     for (int t = 0; t < T; t += 2) {
         lin_wait<kLinG>(bufA);
-        consume(ci, cg, bufA, std::false_type{}); adv(ci, cg);
+        consume(ci, cg, bufA); adv(ci, cg);
         issue(ii, ig, bufA); adv(ii, ig);
         lin_wait<kLinG>(bufB);
-        consume(ci, cg, bufB, std::true_type{}); adv(ci, cg);
+        if (t + 1 < T) { consume(ci, cg, bufB); adv(ci, cg); }
         issue(ii, ig, bufB); adv(ii, ig);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the group re-read behind the wave's last one)
@@ -438,7 +445,7 @@ extern "C" int duo_token_linear_bf16(const duo_token_linear_args *a, void *strea
     TokenLinearParams P;
     P.x = (const bf16_t *)a->x; P.x2 = (const bf16_t *)a->x2; P.x_rs = a->x_row_stride;
     P.K = a->n_in;
-    P.gpr = 2 * ((a->n_in + 2 * kLinG * 512 - 1) / (2 * kLinG * 512));      // whole pairs of groups (see the stream loop)
+    P.gpr = (a->n_in + kLinG * 512 - 1) / (kLinG * 512);
     P.kpad = P.gpr * kLinG * 512;
     int64_t n_total = 0;
     for (int s = 0; s < 3; ++s) {

@@ -440,7 +440,7 @@ int duo_silu_mul_bf16(const void *gate, int64_t gate_row_stride, const void *up,
  * (q | k | v, gate | up); seg[i].n == 0 ends the list.  fp32 accumulation, one rounding to bf16, then the residual add
  * with its own rounding — the values a module-by-module run materialises in bf16 are rounded at the same points.
  * Alignment: x, x2, norm_weight, every W block 16 bytes; strides multiples of 8 elements; n_in a multiple of 8;
- * n_rows * round_up(n_in, 4096) * 2 bytes must fit one CU's LDS (156 KiB).                                              */
+ * n_rows * round_up(n_in, 2048) * 2 bytes must fit one CU's LDS (156 KiB).                                              */
 #define DUO_TOKEN_LINEAR_MAX_ROWS 4
 typedef struct duo_linear_seg {
     const void *w;          /* [n, n_in] bf16, rows `row_stride` elements apart */
