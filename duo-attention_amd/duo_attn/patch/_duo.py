@@ -249,7 +249,11 @@ def _layer_static_verdict(layer) -> bool:
     if cached is not None and cached[0] == key:
         return cached[1]
     mlp = getattr(layer, "mlp", None)
-    ok = (mlp is not None and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
+    # (the fused form calls duo_static_attention_core itself: only for attention modules that carry THIS module's static
+    #  forward — i.e. went through enable_*_duo_attention_static_kv_cache_eval, weights reordered retrieval-heads-first)
+    attn_fwd = getattr(getattr(layer.self_attn, "forward", None), "__func__", None)
+    ok = (mlp is not None and attn_fwd is duo_attention_forward_one_way_reordered_static
+          and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
           and all(_streamable_linear(m) for m in mods)
           and all(hasattr(n, "variance_epsilon") and n.weight.dtype == torch.bfloat16
                   for n in (layer.input_layernorm, layer.post_attention_layernorm)))
@@ -268,6 +272,8 @@ def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
         return False
     if not isinstance(kv_cache, DuoAttentionStaticKVCache) or kv_cache.kv_seq_len_list[layer_idx] <= 0:
         return False
+    if hidden_states.stride(2) != 1 or hidden_states.stride(0) % 8 or hidden_states.data_ptr() % 16:
+        return False                       # (the kernel's 16-byte row loads)
     if not _layer_static_verdict(layer):
         return False
     rows = hidden_states.shape[0]
