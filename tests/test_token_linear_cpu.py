@@ -51,3 +51,105 @@ def test_exact_returns_the_unrounded_product():
     y, pre = token_linear_ref(x, [(w, None)], exact=True)
     assert pre.dtype == torch.float64 and torch.equal(y, pre.float().to(torch.bfloat16))
     assert torch.allclose(pre, x.double() @ w.double().t())
+
+
+# ----------------------------------------------------------------------------- the fused decoder layer's host logic
+class _FusedOracleBackend:
+    """the oracle backend + ``token_linear`` (the oracle's module-by-module restatement): drives
+    ``duo_decode_layer_fused`` on the CPU — the product itself only takes that path on the GPU"""
+
+    def __init__(self):
+        from oracle.duo_oracle import OracleBackend
+
+        self._inner = OracleBackend(round_p=False)
+        self.calls = 0
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def token_linear_fits(self, n_rows, n_in):
+        return n_rows <= 4 and n_in % 8 == 0
+
+    def token_linear(self, x, blocks, norm=None, x2=None, residual=None):
+        self.calls += 1
+        return token_linear_ref(x, blocks, norm=norm, x2=x2, residual=residual)
+
+
+def _tiny_bf16(family, seed):
+    from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
+
+    torch.manual_seed(seed)
+    kw = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=3, num_attention_heads=4,
+              num_key_value_heads=2, head_dim=128, vocab_size=101, max_position_embeddings=1024,
+              rope_theta=10000.0, attn_implementation="eager", tie_word_embeddings=False)
+    m = LlamaForCausalLM(LlamaConfig(**kw)) if family == "llama" else MistralForCausalLM(MistralConfig(sliding_window=None, **kw))
+    return m.to(torch.bfloat16).eval()
+
+
+def _with_fused_layers(model, _duo):
+    """wrap the patched decoder-layer forwards: q_len == 1 goes through duo_decode_layer_fused (what the product's
+    layer forward does on the GPU when fused_decode_layer_ok says so)"""
+    import types
+
+    for layer in model.model.layers:
+        orig = layer.forward
+
+        def fwd(self, hidden_states, *a, _orig=orig, **kw):
+            if hidden_states.shape[1] == 1 and kw.get("kv_cache") is not None and kw["kv_cache"].kv_seq_len_list[kw["layer_idx"]] > 0:
+                assert _duo._layer_modules(self)[0] is self.self_attn.q_proj
+                return (_duo.duo_decode_layer_fused(self, hidden_states, kw["kv_cache"], kw["layer_idx"], kw.get("pos0"),
+                                                    kw.get("position_ids")),)
+            return _orig(hidden_states, *a, **kw)
+
+        layer.forward = types.MethodType(fwd, layer)
+
+
+import pytest
+
+
+@pytest.mark.parametrize("family,bsz", [("llama", 1), ("mistral", 2)])
+def test_fused_decode_layer_host_logic_matches_module_by_module(family, bsz):
+    """duo_decode_layer_fused (q|k|v with the norm folded in -> the static attention core on views of the fused buffer ->
+    o_proj + residual -> gate|up with the norm folded in -> down_proj over silu(g)*u + residual) against the patched
+    module-by-module layer forward, whole model, on the CPU with the oracle behind both: same tokens, logits within the
+    bf16 noise of a different dot-product summation order; the cache ends in the same state"""
+    import numpy as np
+
+    from duo_attn import backend
+    from duo_attn.patch import _duo
+
+    mod = __import__(f"duo_attn.patch.{family}", fromlist=["x"])
+    enable = getattr(mod, f"enable_{family}_duo_attention_static_kv_cache_eval")
+    heads = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]])
+    ids = torch.randint(0, 101, (bsz, 40), generator=torch.Generator().manual_seed(3))
+    be = _FusedOracleBackend()
+    backend._set_backend_for_testing(be)
+    try:
+        def run(fused):
+            model = _tiny_bf16(family, 5)
+            enable(model, heads.copy())
+            if fused:
+                _with_fused_layers(model, _duo)
+            cache = mod.DuoAttentionStaticKVCache(model, heads, bsz, 64, 4, 12)       # window 16: slides during decode
+            outs = []
+            with torch.no_grad():
+                model(input_ids=ids[:, :30], past_key_values=cache, use_cache=True)
+                for t in range(30, 40):
+                    outs.append(model(input_ids=ids[:, t:t + 1], past_key_values=cache, use_cache=True).logits.float())
+            return torch.cat(outs, 1), cache
+
+        be.calls = 0
+        l_m, c_m = run(False)
+        assert be.calls == 0
+        l_f, c_f = run(True)
+        assert be.calls == 10 * 3 * 4                   # four token-row linears per layer and step
+    finally:
+        backend._set_backend_for_testing(None)
+    rel = ((l_f - l_m).norm() / l_m.norm()).item()
+    assert rel < 2e-2, rel
+    assert (l_f.argmax(-1) == l_m.argmax(-1)).float().mean() >= 0.9
+    assert c_f.kv_seq_len == c_m.kv_seq_len == 40
+    for l in range(3):
+        assert c_f.streaming_kv_seq_len_list[l] == c_m.streaming_kv_seq_len_list[l]
+        a, b = c_f.full_value_states_list[l][:, :40].float(), c_m.full_value_states_list[l][:, :40].float()
+        assert ((a - b).norm() / b.norm().clamp_min(1e-6)).item() < 2e-2

@@ -34,10 +34,12 @@ HEADS = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 0.0, 1.0, 0.0], [0.0, 1.0, 0.0, 1.
 CHUNKS = [23, 17, 1, 1]
 
 
-def _run(model, heads, max_size=64):
+def _run(model, heads, max_size=64, wrap=None):
     from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
 
     enable_llama_duo_attention_static_kv_cache_eval(model, heads.copy())
+    if wrap is not None:
+        wrap(model)
     cache = DuoAttentionStaticKVCache(model, heads, 1, max_size, 4, 8)
     ids = torch.randint(0, 97, (1, sum(CHUNKS)), generator=torch.Generator().manual_seed(1))
     outs, pos = [], 0
@@ -59,6 +61,30 @@ def _worker(rank, world, port, q, mode="explicit"):
 
         backend._set_backend_for_testing(OracleBackend(round_p=False))
         model = _tiny()
+        if mode == "fused":
+            # the decode steps' layers in the fused form (duo_decode_layer_fused): on a shard o_proj / down_proj are the
+            # local product -> all-reduce -> residual add (_out_linear); driven on the CPU through the oracle's token_linear_ref
+            from duo_attn.patch import _duo
+            from test_token_linear_cpu import _FusedOracleBackend, _with_fused_layers
+
+            be = _FusedOracleBackend()
+            backend._set_backend_for_testing(be)
+            local = shard_model_for_tp(model, HEADS)
+            seen = {"row_parallel": 0}
+            orig_out = _duo._out_linear
+
+            def counting(be_, proj, *a):
+                seen["row_parallel"] += int(_duo._row_parallel(proj))
+                return orig_out(be_, proj, *a)
+
+            _duo._out_linear = counting
+            out = _run(model, local, wrap=lambda m: _with_fused_layers(m, _duo))
+            assert seen["row_parallel"] == 2 * 3 * 2, seen         # 2 decode steps x 3 layers x (o_proj, down_proj)
+            assert be.calls == 2 * 3 * 4
+            if rank == 0:
+                q.put(out.numpy())
+            dist.barrier()
+            return
         if mode != "explicit":
             # the reference's call shape (utils.py:206-227) as a drop-in: shard first, then hand the WHOLE-model pattern to
             # the enabler and the cache — they slice it to this rank's heads.  "balanced": the split knows the pattern;
@@ -139,6 +165,31 @@ def test_to_device_enable_tp_is_a_drop_in(mode):
     q = ctx.Queue()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4), np.abs(got - want).max()
+
+
+def test_tp2_fused_decode_layers_equal_single_process():
+    """the fused decode-layer form on tensor-parallel shards (row-parallel o_proj / down_proj: local product -> all-reduce
+    -> residual add) == the single-process module-by-module model, fp32"""
+    _paths()
+    from duo_attn import backend
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend(round_p=False))
+    try:
+        want = _run(_tiny(), HEADS).numpy()
+    finally:
+        backend._set_backend_for_testing(None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "fused")) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
