@@ -156,3 +156,22 @@ def test_xmap_is_a_bijection():
                 heads = blocks(nf, G, nqt)
                 if G == 4 and nqt == 64:
                     assert heads <= 2
+
+
+def test_w64_kernels_own_their_accumulator_file():
+    """tools/debug/audit_w64.sh on the current sources: the 4-wave prefill kernels address the accumulator half of the
+    register file by literal register numbers inside asm statements, so the compiler must not touch it — no
+    compiler-generated instruction may name an AGPR, 256 AGPRs / scratch 0 must be what the kernel descriptor says"""
+    import os
+    import shutil
+    import subprocess
+
+    import pytest
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not present")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "debug", "audit_w64.sh"), root], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("duo_prefill_w64")]
+    assert len(lines) == 2 and all("'NumAgprs': '256'" in l and "'ScratchSize': '0'" in l and l.endswith("AGPRs: 0") for l in lines), lines
