@@ -24,6 +24,8 @@ and then calls the reference's real functions:
       duo_attn.patch.static_kv_cache.DuoAttentionStaticKVCache          (static_kv_cache.py:18-315)
       duo_attn.patch.llama.llama_duo_attention_forward_one_way_reordered_static (llama.py:309-434)
       duo_attn.patch.llama.llama_duo_attention_forward_one_way_reordered        (llama.py:146-306)
+      duo_attn.patch.static_kv_cache.duo_attn_static_kv_cache_llama_decoder_layer_forward (static_kv_cache.py:507-546)
+      duo_attn.patch.flashinfer_utils.flashinfer_rmsnorm_forward                  (flashinfer_utils.py:9-16)
 So the fixtures pin the reference's control flow, cache layout, head split/concat order and mask
 alignment; the only thing they cannot pin is the last-bit behaviour of the CUDA kernels themselves.
 """
@@ -227,6 +229,72 @@ def golden_tuple(name, nf, Hq, Hkv, chunks, sink, recent, theta, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def golden_layer(name, nf, Hq, Hkv, inter, chunks, decode_steps, sink, recent, theta, seed):
+    """A whole DECODER LAYER through the reference's own code: ``duo_attn_static_kv_cache_llama_decoder_layer_forward``
+    (static_kv_cache.py:507-546) around its static attention forward (llama.py:309-434), with real ``nn.Linear``
+    projections, HF's ``LlamaMLP`` and ``LlamaRMSNorm`` modules carrying the reference's ``flashinfer_rmsnorm_forward``
+    (flashinfer_utils.py:9-16; the arithmetic stub above), its real DuoAttentionStaticKVCache, bf16 on the CPU.  Pins the
+    module SEQUENCE either side of the attention op — norm, q/k/v_proj, o_proj, residual, norm, SwiGLU MLP, residual —
+    which this repository runs as fused launches at q_len == 1 (csrc/duo_linear.hip, DESIGN row (g))."""
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaMLP, LlamaRMSNorm
+
+    from duo_attn.patch.flashinfer_utils import flashinfer_rmsnorm_forward
+    from duo_attn.patch.llama import llama_duo_attention_forward_one_way_reordered_static as attn_fwd
+    from duo_attn.patch.static_kv_cache import (DuoAttentionStaticKVCache,
+                                                duo_attn_static_kv_cache_llama_decoder_layer_forward as layer_fwd)
+
+    D, H = 128, Hq * 128
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    heads = [[1.0] * nf + [0.0] * (Hkv - nf)]
+    model = types.SimpleNamespace(
+        config=types.SimpleNamespace(num_hidden_layers=1, num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=H),
+        parameters=lambda: iter([torch.zeros(1, dtype=torch.bfloat16)]),
+    )
+    total = sum(chunks) + decode_steps + 2
+    cache = DuoAttentionStaticKVCache(model, heads, 1, total, sink, recent)
+    attn = fake_attention(Hq, Hkv, D, theta, None)
+    rw = lambda o, i: (torch.randn(o, i, generator=g) * i ** -0.5).to(torch.bfloat16)
+    for nm, o, i in (("q_proj", H, H), ("k_proj", Hkv * D, H), ("v_proj", Hkv * D, H), ("o_proj", H, H)):
+        lin = torch.nn.Linear(i, o, bias=False).to(torch.bfloat16)
+        lin.weight.data.copy_(rw(o, i))
+        setattr(attn, nm, lin)
+    attn.forward = types.MethodType(attn_fwd, attn)
+    layer = torch.nn.Module()
+    layer.self_attn = attn
+    layer.mlp = LlamaMLP(LlamaConfig(hidden_size=H, intermediate_size=inter)).to(torch.bfloat16)
+    for lin in (layer.mlp.gate_proj, layer.mlp.up_proj, layer.mlp.down_proj):
+        lin.weight.data.copy_(rw(*lin.weight.shape))
+    for nm in ("input_layernorm", "post_attention_layernorm"):
+        ln = LlamaRMSNorm(H, eps=1e-5).to(torch.bfloat16)
+        ln.weight.data.copy_((torch.rand(H, generator=g) + 0.5).to(torch.bfloat16))
+        ln.forward = types.MethodType(flashinfer_rmsnorm_forward, ln)
+        setattr(layer, nm, ln)
+    out = {"dims": np.array([Hq, Hkv, D, sink, recent, inter, nf]), "rope": np.array([theta, 1.0], dtype=np.float64),
+           "eps": np.array(1e-5), "steps": np.array(list(chunks) + [1] * decode_steps), "n_prefill": np.array(len(chunks))}
+    for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+        out[f"w_{nm}"] = bits(getattr(attn, nm).weight.data)
+    for nm in ("gate_proj", "up_proj", "down_proj"):
+        out[f"w_{nm}"] = bits(getattr(layer.mlp, nm).weight.data)
+    out["w_input_layernorm"] = bits(layer.input_layernorm.weight.data)
+    out["w_post_attention_layernorm"] = bits(layer.post_attention_layernorm.weight.data)
+    pos = 0
+    with torch.no_grad():
+        for si, S in enumerate(list(chunks) + [1] * decode_steps):
+            position_ids = torch.arange(pos, pos + S)[None]
+            h = torch.randn(1, S, H, generator=g).to(torch.bfloat16)
+            out[f"h_{si}"] = bits(h)
+            o = layer_fwd(layer, h.clone(), position_ids=position_ids, kv_cache=cache, layer_idx=0)[0]
+            out[f"o_{si}"] = bits(o)
+            pos += S              # (no evict_last: the decode steps advance the cache like a generation loop)
+    n, m = cache.kv_seq_len_list[0], cache.streaming_kv_seq_len_list[0]
+    out["len"] = np.array([n, m])
+    out["fullv"] = bits(cache.full_value_states_list[0][:, :n])
+    out["strv"] = bits(cache.streaming_value_states_list[0][:, :m])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def golden_host(name):
     """Host-side pieces: pattern sparsification on the shipped TSVs and the weight reordering."""
     from duo_attn.patch.utils import reorder_full_attn_heads, reorder_linear_weights
@@ -283,4 +351,7 @@ if __name__ == "__main__":
     golden_static("static_c.npz", counts=[2, 0, 3], Hq=8, Hkv=4, chunks=(40, 21), decode_steps=3,
                   sink=4, recent=12, theta=500000.0, factor=None, seed=4, batch=2, starts=[0, 7])
     golden_tuple("tuple_a.npz", nf=1, Hq=8, Hkv=4, chunks=(20, 9, 1, 1), sink=4, recent=8, theta=10000.0, seed=3)
+    # a whole decoder layer (norms, projections, MLP, residual adds around the static attention forward)
+    golden_layer("layer_a.npz", nf=1, Hq=4, Hkv=2, inter=256, chunks=(29, 11), decode_steps=5, sink=4, recent=12,
+                 theta=10000.0, seed=6)
     print("golden vectors written to", HERE)

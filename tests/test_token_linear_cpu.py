@@ -153,3 +153,106 @@ def test_fused_decode_layer_host_logic_matches_module_by_module(family, bsz):
         assert c_f.streaming_kv_seq_len_list[l] == c_m.streaming_kv_seq_len_list[l]
         a, b = c_f.full_value_states_list[l][:, :40].float(), c_m.full_value_states_list[l][:, :40].float()
         assert ((a - b).norm() / b.norm().clamp_min(1e-6)).item() < 2e-2
+
+
+# ----------------------------------------------------------------------------- the reference's own decoder layer
+def _bf16(a):
+    import numpy as np
+
+    return torch.from_numpy(a.view(np.int16).copy()).view(torch.bfloat16)
+
+
+def _layer_from_golden(g, _duo):
+    """the layer of tests/golden/layer_a.npz as the product sees an HF decoder layer: nn.Linear projections, HF's LlamaMLP and
+    LlamaRMSNorm (patched RMSNorm forward), this package's static attention / decoder-layer forwards"""
+    import types
+
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaMLP, LlamaRMSNorm
+
+    from duo_attn.patch.flashinfer_utils import rmsnorm_forward
+    from duo_attn.patch.static_kv_cache import duo_attn_static_kv_cache_decoder_layer_forward
+
+    Hq, Hkv, D, sink, recent, inter, nf = (int(x) for x in g["dims"])
+    H = Hq * D
+    attn = torch.nn.Module()
+    attn.config = types.SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=H, head_dim=D,
+                                        rope_theta=float(g["rope"][0]), rope_scaling=None)
+    attn.head_dim = D
+    for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+        w = _bf16(g[f"w_{nm}"])
+        lin = torch.nn.Linear(w.shape[1], w.shape[0], bias=False).to(torch.bfloat16)
+        lin.weight.data.copy_(w)
+        setattr(attn, nm, lin)
+    attn.forward = types.MethodType(_duo.duo_attention_forward_one_way_reordered_static, attn)
+    layer = torch.nn.Module()
+    layer.self_attn = attn
+    layer.mlp = LlamaMLP(LlamaConfig(hidden_size=H, intermediate_size=inter)).to(torch.bfloat16)
+    for nm in ("gate_proj", "up_proj", "down_proj"):
+        getattr(layer.mlp, nm).weight.data.copy_(_bf16(g[f"w_{nm}"]))
+    for nm in ("input_layernorm", "post_attention_layernorm"):
+        ln = LlamaRMSNorm(H, eps=float(g["eps"])).to(torch.bfloat16)
+        ln.weight.data.copy_(_bf16(g[f"w_{nm}"]))
+        ln.forward = types.MethodType(rmsnorm_forward, ln)
+        setattr(layer, nm, ln)
+    layer.forward = types.MethodType(duo_attn_static_kv_cache_decoder_layer_forward, layer)
+    return layer.eval(), (Hq, Hkv, D, sink, recent, nf)
+
+
+def _layer_close(ours, ref, what):
+    """bf16 layer output vs the reference's: the two sides differ by the attention stub's / the oracle's last bit and —
+    fused form — by the summation order of the dot products; every element within two bf16 ulps of the value (or 2e-3 of
+    the tensor's rms for near-zero outputs), at least 99 % bit-equal (measured on layer_a.npz: every element of every step
+    bit-equal, module by module AND fused)"""
+    o, r = ours.float(), ref.float()
+    assert o.shape == r.shape, (what, o.shape, r.shape)
+    diff = (o - r).abs()
+    tol = torch.clamp(torch.maximum(o.abs(), r.abs()) * 2.0 ** -6, min=2e-3 * float(r.pow(2).mean().sqrt()))
+    assert (diff <= tol).all(), f"{what}: max diff {diff.max():.3e}, {int((diff > tol).sum())} elements beyond the bar"
+    same = (diff == 0).float().mean().item()
+    assert same >= 0.99, f"{what}: only {same:.3f} of the elements bit-equal to the reference"
+    return same
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_decoder_layer_reproduces_the_reference_golden(fused):
+    """tests/golden/layer_a.npz = the reference's OWN decoder-layer forward (static_kv_cache.py:507-546 around llama.py:
+    309-434, flashinfer_utils.py:9-16) run on the CPU by tests/golden/make_golden.py.  This package's decoder layer —
+    module by module, and with the decode steps in the fused form (duo_decode_layer_fused, the oracle's token_linear_ref
+    standing in for the HIP kernel) — must reproduce its hidden states step by step and leave the cache in its state."""
+    import os
+
+    import numpy as np
+
+    from duo_attn import backend
+    from duo_attn.patch import _duo
+    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
+    from helpers import ShapeModel, heads_from_counts
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "layer_a.npz"))
+    be = _FusedOracleBackend()
+    backend._set_backend_for_testing(be)
+    try:
+        layer, (Hq, Hkv, D, sink, recent, nf) = _layer_from_golden(g, _duo)
+        steps, n_pre = [int(x) for x in g["steps"]], int(g["n_prefill"])
+        heads = heads_from_counts([nf], Hkv)
+        cache = DuoAttentionStaticKVCache(ShapeModel(1, Hq, Hkv, D), heads, 1, sum(steps) + 2, sink, recent)
+        pos, worst = 0, 1.0
+        with torch.no_grad():
+            for si, S in enumerate(steps):
+                h = _bf16(g[f"h_{si}"])
+                position_ids = torch.arange(pos, pos + S)[None]
+                if fused and S == 1:
+                    out = _duo.duo_decode_layer_fused(layer, h.clone(), cache, 0, pos, position_ids)
+                else:
+                    out = layer(h.clone(), position_ids=position_ids, kv_cache=cache, layer_idx=0, pos0=pos)[0]
+                worst = min(worst, _layer_close(out, _bf16(g[f"o_{si}"]), f"layer_a step {si} (S={S}, fused={fused})"))
+                pos += S
+        assert be.calls == (4 * (len(steps) - n_pre) if fused else 0)
+        n, m = (int(x) for x in g["len"])
+        assert (cache.kv_seq_len_list[0], cache.streaming_kv_seq_len_list[0]) == (n, m)
+        # V rows are projections of the normalised hidden state: bit-equal module by module, within the bar fused
+        _layer_close(cache.full_value_states_list[0][:, :n], _bf16(g["fullv"]), "full V pool")
+        _layer_close(cache.streaming_value_states_list[0][:, :m], _bf16(g["strv"]), "streaming V pool")
+    finally:
+        backend._set_backend_for_testing(None)
