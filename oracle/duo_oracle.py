@@ -19,6 +19,10 @@ What it restates (torch, CPU, fp32 math on the same bf16 inputs):
                          rotate-half pairs (i, i+D/2), angle = pos / rope_scale * theta^(-2i/D),
                          fp32
   RMSNorm                flashinfer ``norm.rmsnorm``: x * rsqrt(mean(x^2) + eps) * w in fp32
+  decoder layer at       the module sequence either side of the attention op — norms, q/k/v_proj, o_proj, SwiGLU MLP,
+  q_len == 1             residual adds (duo_attn/patch/static_kv_cache.py:507-546 around llama.py:309-434) — as
+                         ``token_linear_ref``: fp64 dot products, every intermediate the modules materialise rounded to
+                         the model dtype; pinned by tests/golden/layer_a.npz (the reference's own layer forward)
 
 Pinning: the reference has no tests or golden vectors.  The oracle is
 pinned against outputs of the REFERENCE'S OWN CODE run in the build container
