@@ -749,6 +749,10 @@ def main():
                          "32 = the whole model (minutes), 0 = skip")
     ap.add_argument("--traffic-probe", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    # stdout carries the ONE JSON line and nothing else: whatever a leg prints on the way (the patch API announces itself
+    # like the reference's does: "Enabling DuoAttention evaluation ...") goes to stderr
+    json_out = sys.stdout
+    sys.stdout = sys.stderr
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -974,7 +978,7 @@ def main():
                             "share_of_prefill_flops": float(t[4]) / sum(layer_cost)} for r, t in enumerate(per_rank)],
             },
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
