@@ -35,3 +35,12 @@ def test_prefill_flops_of_the_job():
     assert abs(tot([8] * 32, 4096) / full - 1) < 1e-9
     for C, want in ((4096, 2.335e15), (16384, 2.545e15), (32000, 2.800e15)):
         assert abs(tot(counts, C) / want - 1) < 2e-3, (C, tot(counts, C))
+
+
+def test_stdout_carries_only_the_json_line():
+    """the driver reads ONE JSON line from stdout: legs that print (the patch API announces itself like the reference's)
+    must not reach it — main() hands stdout to stderr right after argument parsing and prints the line to the saved handle"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("json_out = sys.stdout") < main.index("sys.stdout = sys.stderr") < main.index("torch.cuda.is_available()")
+    assert main.count("print(") == 1 and "print(json.dumps(line), file=json_out, flush=True)" in main
