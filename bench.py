@@ -751,16 +751,31 @@ def main():
     args = ap.parse_args()
     # stdout carries the ONE JSON line and nothing else: whatever a leg prints on the way (the patch API announces itself
     # like the reference's does: "Enabling DuoAttention evaluation ...") goes to stderr
-    json_out = sys.stdout
+    # — at the file-descriptor level too: native libraries write to fd 1 directly (gloo reports its rendezvous there)
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     sys.stdout = sys.stderr
 
+    from duo_attn import launch
+
+    if args.gpus > 1 and not launch.launched_by_torchrun() and not args.traffic_probe:
+        # plain `python bench.py --gpus N`: no rank environment -> start the N ranks here (one per GPU, RCCL; the
+        # driver's own `python -m torch.distributed.run ... bench.py --gpus N` arrives with one and skips this)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        os.dup2(json_out.fileno(), 1)        # the ranks inherit the real stdout; rank 0 prints the line
+        raise SystemExit(launch.self_launch(__file__, sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
+                         f"{args.gpus}, or without any launcher (bench.py then starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if world > 1:
+        launch.check_visible_gpus(world)
     # DUO_BENCH_DEBUG_SHARED_GPU=1: rehearsal of the N > 1 code path on a ONE-GPU box — every rank
     # computes on cuda:0 and the hand-off goes through gloo/host memory.  Not a measurement mode.
     shared = os.environ.get("DUO_BENCH_DEBUG_SHARED_GPU") == "1"

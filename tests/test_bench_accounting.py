@@ -42,5 +42,6 @@ def test_stdout_carries_only_the_json_line():
     must not reach it — main() hands stdout to stderr right after argument parsing and prints the line to the saved handle"""
     src = open(os.path.join(ROOT, "bench.py")).read()
     main = src[src.index("def main():"):]
-    assert main.index("json_out = sys.stdout") < main.index("sys.stdout = sys.stderr") < main.index("torch.cuda.is_available()")
+    assert main.index('json_out = os.fdopen(os.dup(1), "w")') < main.index("os.dup2(2, 1)") < main.index("sys.stdout = sys.stderr") \
+        < main.index("torch.cuda.is_available()")
     assert main.count("print(") == 1 and "print(json.dumps(line), file=json_out, flush=True)" in main

@@ -1,0 +1,125 @@
+"""`python bench.py --gpus N` (and tools/benchmark_static.py --pp/--tp --gpus N) without a launcher start their own ranks.
+
+VERDICT r3 item 1: the driver's N = 1 command shape, `python bench.py --gpus 8`, used to SystemExit because no
+torch.distributed.run environment was present.  CPU legs: the launcher plumbing itself — command line, rendezvous on
+127.0.0.1, a real two-rank gloo job re-executed through ``duo_attn.launch.self_launch``, the GPU-count check.  GPU leg:
+plain ``python bench.py --gpus 2`` on the one-GPU box in the shared-GPU rehearsal mode, JSON line parsed."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_torchrun_command_line():
+    from duo_attn import launch
+
+    cmd = launch.torchrun_command("bench.py", ["--gpus", "4", "--steps", "2"], 4, port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == os.path.abspath("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+
+
+def test_rank_environment_detection_and_gpu_count_check():
+    from duo_attn import launch
+
+    assert not launch.launched_by_torchrun({})
+    assert not launch.launched_by_torchrun({"WORLD_SIZE": "2"})
+    assert launch.launched_by_torchrun({"WORLD_SIZE": "2", "RANK": "1"})
+    launch.check_visible_gpus(2, visible=2, env={})
+    launch.check_visible_gpus(8, visible=1, env={launch.SHARED_GPU_ENV: "1"})
+    with pytest.raises(SystemExit) as e:
+        launch.check_visible_gpus(8, visible=1, env={})
+    assert "--gpus 8 but 1 GPU(s) visible" in str(e.value) and launch.SHARED_GPU_ENV in str(e.value)
+
+
+def test_self_launch_runs_a_two_rank_job(tmp_path):
+    """a script that finds no rank environment re-executes itself as two gloo ranks; rank 0 prints the one result line"""
+    script = tmp_path / "job.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys
+        sys.path.insert(0, {os.path.join(ROOT, "duo-attention_amd")!r})
+        from duo_attn import launch
+        if not launch.launched_by_torchrun():
+            raise SystemExit(launch.self_launch(__file__, sys.argv[1:], 2, visible=2))
+        import torch, torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(dist.get_rank() + 1)])
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({{"world": dist.get_world_size(), "sum": t.item(), "argv": sys.argv[1:],
+                              "master": os.environ["MASTER_ADDR"]}}), flush=True)
+        dist.destroy_process_group()
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), "--flag", "7"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res == {"world": 2, "sum": 3.0, "argv": ["--flag", "7"], "master": "127.0.0.1"}
+    assert "starting 2 ranks" in r.stderr
+
+
+def test_bench_and_benchmark_static_take_the_launcher_path():
+    """both entry points consult duo_attn.launch before they look at WORLD_SIZE"""
+    b = open(os.path.join(ROOT, "bench.py")).read()
+    main = b[b.index("def main():"):]
+    assert main.index("launch.self_launch(__file__, sys.argv[1:], args.gpus)") < main.index('int(os.environ.get("WORLD_SIZE", "1"))')
+    s = open(os.path.join(ROOT, "tools", "benchmark_static.py")).read()
+    assert "launch.self_launch(__file__, sys.argv[1:], n)" in s and "launch.check_visible_gpus(world)" in s
+
+
+def _run_bench(extra_env, *args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+
+
+SMALL = ["--steps", "1", "--warmup", "0", "--ctx", "8192", "--chunk", "4096", "--layers", "4", "--decode-tokens", "4",
+         "--row-block", "2048", "--no-cpu-baseline", "--no-traffic", "--no-model-level", "--no-int4", "--no-token-linear",
+         "--no-parity"]
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher, on the one-GPU box in the shared-GPU rehearsal mode: the two ranks are
+    started by bench.py itself, stdout is the ONE JSON line, and it describes a two-stage pipeline"""
+    r = _run_bench({"DUO_BENCH_DEBUG_SHARED_GPU": "1"}, "--gpus", "2", *SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout
+    line = json.loads(out[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "strong"
+    pipe = line["pipeline"]
+    assert pipe["world_size"] == 2 and pipe["backend"] == "gloo"          # (RCCL: "nccl" when every rank has its own GPU)
+    assert [s["rank"] for s in pipe["stages"]] == [0, 1]
+    assert pipe["stages"][0]["layers"][1] == pipe["stages"][1]["layers"][0] and pipe["stages"][1]["layers"][1] == 4
+    assert line["config"]["parallelism"].startswith("layer-pipeline pp2")
+    assert line["roofline"]["frac"] > 0 and line["full_attention"]["job_tok_s"] > 0
+
+
+@pytest.mark.gpu
+def test_plain_bench_gpus_2_on_one_gpu_is_a_clear_error():
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    r = _run_bench({"DUO_BENCH_DEBUG_SHARED_GPU": "0"}, "--gpus", "2", *SMALL, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2 but 1 GPU(s) visible" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_path_is_unchanged():
+    """N = 1: no launcher involved, one JSON line, no pipeline section"""
+    r = _run_bench({}, "--gpus", "1", *SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert line["n_gpus"] == 1 and line["pipeline"] is None and "starting" not in r.stderr

@@ -171,6 +171,9 @@ def _dist_setup():
 
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     shared = os.environ.get("DUO_BENCH_DEBUG_SHARED_GPU") == "1"
+    from duo_attn import launch
+
+    launch.check_visible_gpus(world)
     local = 0 if shared else int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -186,8 +189,9 @@ def run_pp(args):
     """--pp: layer pipeline, one process per GPU (launch with torch.distributed.run).  The model is sharded with
     duo_attn.pipeline.PipelinedCausalLM: chunked prefill streamed through the stages (row blocks with --row_block),
     greedy decode with the token fed back from the last stage.  BASELINE cfg4's entry point:
-        python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/benchmark_static.py --pp \
-            --max_length 1048576 --prefilling_chunk_size 32000 --row_block 4096"""
+        python tools/benchmark_static.py --pp --gpus 8 --max_length 1048576 --prefilling_chunk_size 32000 --row_block 4096
+    (starts its own ranks; `python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/benchmark_static.py
+    --pp ...` works as well)"""
     from duo_attn.pipeline import PipelinedCausalLM
     from duo_attn.utils import sparsify_attention_heads
 
@@ -343,11 +347,24 @@ def parse(argv=None):
     ap.add_argument("--pp", action="store_true", help="layer pipeline over the ranks of torch.distributed.run")
     ap.add_argument("--row_block", type=int, default=0, help="--pp: hand prefill chunks through the stages in row blocks")
     ap.add_argument("--tp", action="store_true", help="head-parallel tensor parallelism over the ranks of torch.distributed.run")
+    ap.add_argument("--gpus", type=int, default=0,
+                    help="--pp / --tp without a launcher: start this many ranks (one per GPU) under torch.distributed.run; "
+                         "0 = every visible GPU.  Ignored when torch.distributed.run already started the ranks")
     return ap.parse_args(argv)
 
 
 def main():
     args = parse()
+    if args.pp or args.tp:
+        from duo_attn import launch
+
+        if not launch.launched_by_torchrun():
+            # plain `python tools/benchmark_static.py --pp --gpus 8`: start the ranks here (one per GPU, RCCL)
+            n = args.gpus or torch.cuda.device_count()
+            if n < 2:
+                raise SystemExit("--pp / --tp need at least two ranks: pass --gpus N (N GPUs visible, or "
+                                 f"{launch.SHARED_GPU_ENV}=1 for the one-GPU rehearsal)")
+            raise SystemExit(launch.self_launch(__file__, sys.argv[1:], n))
     if args.pp:
         return run_pp(args)
     if args.tp:
