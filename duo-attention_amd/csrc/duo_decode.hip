@@ -70,6 +70,7 @@ struct DecodeParams {
     //      elements apart, the segments carry their own batch strides, every row has its own partial area
     int64_t q_bs, out_bs, app_bs;
     int64_t ws_row_floats;
+    float pos_delta;         // added to the device-side position (dev_state): this batch row's offset from row 0
 };
 
 constexpr int kTicketWords = DUO_DECODE_TICKET_BYTES / 4;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void duo_decode_split_kernel(const DecodeParam
         if (P.dev_state) {   // uniform scalar loads
             app_row = P.dev_state[0];
             C.a.len = ci ? P.dev_state[1] : app_row;
-            pos = (float)P.dev_state[2];
+            pos = (float)P.dev_state[2] + P.pos_delta;
         }
     }
     const int splits = ci ? P.splits[1] : P.splits[0];
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void duo_decode_scan_kernel(const bf16_t *__re
         if (dev_state) {   // captured step: lengths / position live in device memory (uniform scalar loads)
             st_full = dev_state[0];
             st_str = dev_state[1];
-            pos = (float)dev_state[2];
+            pos = (float)dev_state[2] + P.pos_delta;
             app_row = st_full;
             have_state = true;
         }
@@ -917,6 +918,7 @@ static int decode_plan(const void *q, int64_t q_head_stride, void *out, int64_t 
     P.one_launch = 0;
     P.tickets = nullptr;
     P.dev_state = nullptr;
+    P.pos_delta = 0.f;
     P.scale_log2e = scale * 1.4426950408889634f;
     const int n_q_heads = (P.cls[0].n_kv_heads + P.cls[1].n_kv_heads) * group;
     D.nblk = 0;
@@ -1084,7 +1086,7 @@ static int attn_decode_impl(const void *q, int64_t q_batch_stride, int64_t q_hea
 // merge + streaming-pool update.  See include/duo_attn_hip.h.
 static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream_len, const int32_t *dev_state,
                              void *workspace, int64_t workspace_bytes, void *tickets, void *stream,
-                             const duo_decode_batch *B = nullptr) {
+                             const duo_decode_batch *B = nullptr, int64_t pos_delta = 0) {
     if (!a) return DUO_EINVAL;
     if (a->head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
     const int n_batch = B ? B->n_batch : 1;
@@ -1106,13 +1108,17 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
                 if (a->full_k) { r.full_k = (bf16_t *)a->full_k + b * B->full_batch_stride; r.full_v = (bf16_t *)a->full_v + b * B->full_batch_stride; }
                 if (a->str_k) { r.str_k = (bf16_t *)a->str_k + b * B->str_batch_stride; r.str_v = (bf16_t *)a->str_v + b * B->str_batch_stride; }
                 r.pos = B->pos[b];
-                const int rc = decode_layer_impl(&r, new_stream_len, dev_state, workspace, workspace_bytes, nullptr, stream);
+                // (device-side lengths: the row runs at dev_state->pos plus its fixed offset from args->pos, the host's
+                //  view of that counter)
+                const int rc = decode_layer_impl(&r, new_stream_len, dev_state, workspace, workspace_bytes, nullptr, stream,
+                                                 nullptr, dev_state ? B->pos[b] - a->pos : 0);
                 if (rc) return rc;
             }
             return 0;
         }
     }
     const int64_t pos_all = (B && B->pos) ? B->pos[0] : a->pos;
+    if (dev_state && B && B->pos && n_batch > 1) pos_delta = B->pos[0] - a->pos;      // all rows at one offset from the counter
     const bool batched = n_batch > 1;
     const int nf = a->n_full, nkv = a->n_kv_heads, ns = nkv - nf;
     if (!a->q || !a->k || !a->v || !a->out || nkv <= 0 || nf < 0 || ns < 0 || a->n_q_heads % nkv != 0)
@@ -1162,6 +1168,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
     D.P.app_bs = batched ? B->full_batch_stride : 0;
     D.P.pos = (float)pos_all;
     D.P.dev_state = dev_state;
+    D.P.pos_delta = (float)pos_delta;
     memcpy(D.P.inv_freq, inv_freq, sizeof(inv_freq));
     // ---- streaming-pool update parameters (launch 2, or folded into launch 1) -----------------------
     CompressParams C{};
@@ -1176,6 +1183,7 @@ static int decode_layer_impl(const duo_decode_layer_args *a, int32_t *new_stream
                            (const bf16_t *)a->v + (int64_t)nf * a->kv_head_stride, 0, a->kv_head_stride,
                            ns, a->str_len, 1, a->sink, a->recent, 1, (float)pos_all, {}, dev_state};
         memcpy(C.inv_freq, inv_freq, sizeof(inv_freq));
+        C.pos_delta = (float)pos_delta;
         C.p_bs = batched ? B->str_batch_stride : 0;
         C.n_bs = batched ? B->kv_batch_stride : 0;
         n_compress = 2 * ns;
@@ -1237,6 +1245,19 @@ extern "C" int duo_decode_layer_dev_bf16(const duo_decode_layer_args *a, const d
     if (plan.str_len < 1) plan.str_len = 1;
     return decode_layer_impl(&plan, nullptr, reinterpret_cast<const int32_t *>(dev_state), workspace, workspace_bytes,
                              nullptr, stream);
+}
+
+// The batched step with device-side lengths (include/duo_attn_hip.h): one duo_decode_state for all rows of the layer.
+extern "C" int duo_decode_layer_batched_dev_bf16(const duo_decode_layer_args *a, const duo_decode_batch *batch,
+                                                 const duo_decode_state *dev_state, void *workspace,
+                                                 int64_t workspace_bytes, void *stream) {
+    if (!a || !batch || !dev_state) return DUO_EINVAL;
+    duo_decode_layer_args plan = *a;
+    if (plan.full_len < 1) plan.full_len = 1;
+    if (plan.n_full > 0 && plan.full_len + 1 > plan.full_capacity) plan.full_len = plan.full_capacity - 1;
+    if (plan.str_len < 1) plan.str_len = 1;
+    return decode_layer_impl(&plan, nullptr, reinterpret_cast<const int32_t *>(dev_state), workspace, workspace_bytes,
+                             nullptr, stream, batch);
 }
 
 // The whole step in ONE launch: the split-KV scan as above, and behind an arrival ticket per kv head the last

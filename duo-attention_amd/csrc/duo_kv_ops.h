@@ -56,6 +56,7 @@ struct CompressParams {
     float inv_freq[64];
     const int32_t *dev_state;   // {full_len, str_len, pos, _}: overrides cur / pos when set (captured decode step)
     int64_t p_bs, n_bs;         // batched launches: elements between the batch rows of the pool / of the new rows
+    float pos_delta;            // added to the device-side position (a batch row's fixed offset from row 0)
 };
 
 constexpr int CMP_ROWS = 64;   // destination rows per batch: 64 rows x 16 chunks / 256 thr = 4 chunks each
@@ -65,7 +66,7 @@ __device__ __forceinline__ void duo_stream_compress_block(const CompressParams &
     float pos = P.pos;
     if (P.dev_state) {
         cur = P.dev_state[1];
-        pos = (float)P.dev_state[2];
+        pos = (float)P.dev_state[2] + P.pos_delta;
     }
     const int h = blk >> 1;
     const bool is_v = blk & 1;

@@ -36,6 +36,7 @@ namespace {
 #endif
 constexpr int kLinG = DUO_LIN_G;    // weight loads per group (1 KiB each per wave); two groups in flight per wave
 static_assert(kLinG == 4 || kLinG == 8, "issue() emits the loads four at a time");
+static_assert(DUO_LIN_G != 4 || kLinG * 512 == DUO_TOKEN_LINEAR_PAD, "the header's LDS padding rule is the default build's");
 constexpr int kLinMaxRows = 4;      // token rows per call (DUO_TOKEN_LINEAR_MAX_ROWS)
 
 struct LinSegDev {
@@ -54,6 +55,7 @@ struct TokenLinearParams {
     int32_t sw;                     // waves per workgroup that take rows (<= blockDim / 64)
     const bf16_t *norm_w;
     float eps;
+    int32_t norm_hf;                // DUO_LINEAR_NORM_HF: normalised x rounded to bf16 before the weight multiply (HF *RMSNorm)
     const bf16_t *res;
     int64_t res_rs;
     bf16_t *y;
@@ -187,7 +189,14 @@ __global__ __launch_bounds__(1024) void duo_token_linear_kernel(const TokenLinea
                 unpack8f(v, f);
                 unpack8f(gw8, g);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = f[e] * rs_b * g[e];
+                for (int e = 0; e < 8; ++e) {
+                    // flashinfer form: one rounding of x * rs * w.  HuggingFace's LlamaRMSNorm / MistralRMSNorm (the tuple
+                    // path's norm): `weight * (x * rsqrt(var + eps)).to(bf16)` — two roundings.  A select, not a branch:
+                    // weight loads are in flight here (see the note on control flow below)
+                    const float t = f[e] * rs_b;
+                    const float tr = __uint_as_float(f32_to_bf16_bits(t) << 16);
+                    f[e] = (P.norm_hf ? tr : t) * g[e];
+                }
                 return pack8f(f);
             } else if constexpr (PRO == PRO_SILU) {
                 float f[8], u[8];
@@ -460,6 +469,8 @@ extern "C" int duo_token_linear_bf16(const duo_token_linear_args *a, void *strea
     if (n_total > (1 << 30)) return DUO_EINVAL;
     P.n_total = (int32_t)n_total;
     P.norm_w = (const bf16_t *)a->norm_weight; P.eps = a->norm_eps;
+    if (a->flags & ~DUO_LINEAR_NORM_HF) return DUO_EINVAL;         // unknown flag bits
+    P.norm_hf = (a->flags & DUO_LINEAR_NORM_HF) ? 1 : 0;
     P.res = (const bf16_t *)a->residual; P.res_rs = a->residual_row_stride;
     P.y = (bf16_t *)a->y; P.y_rs = a->y_row_stride;
     const size_t lds = (size_t)a->n_rows * P.kpad * 2;

@@ -16,7 +16,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
-ABI_VERSION = 3
+ABI_VERSION = 4
 HEAD_DIM = 128
 
 
@@ -100,11 +100,30 @@ class LinearSeg(Structure):
 class TokenLinearArgs(Structure):
     """duo_token_linear_args (include/duo_attn_hip.h)."""
     _fields_ = [("x", c_void_p), ("x2", c_void_p), ("x_row_stride", c_int64), ("n_rows", c_int32), ("n_in", c_int32),
-                ("seg", LinearSeg * 3), ("norm_weight", c_void_p), ("norm_eps", c_float), ("reserved", c_int32),
+                ("seg", LinearSeg * 3), ("norm_weight", c_void_p), ("norm_eps", c_float), ("flags", c_int32),
                 ("residual", c_void_p), ("residual_row_stride", c_int64), ("y", c_void_p), ("y_row_stride", c_int64)]
 
 
 TOKEN_LINEAR_MAX_ROWS = 4      # DUO_TOKEN_LINEAR_MAX_ROWS
+TOKEN_LINEAR_PAD = 2048        # DUO_TOKEN_LINEAR_PAD: token rows are staged in LDS padded to a multiple of this
+LINEAR_NORM_HF = 1             # DUO_LINEAR_NORM_HF
+
+
+class TupleDecodeArgs(Structure):
+    """``duo_tuple_decode_args``"""
+
+    _fields_ = [
+        ("q", c_void_p), ("q_head_stride", c_int64), ("n_q_heads", c_int32), ("n_kv_heads", c_int32),
+        ("k", c_void_p), ("v", c_void_p), ("kv_head_stride", c_int64),
+        ("cos_row", c_void_p), ("sin_row", c_void_p),
+        ("n_full", c_int32), ("head_dim", c_int32),
+        ("full_k", c_void_p), ("full_v", c_void_p), ("full_token_stride", c_int64), ("full_head_stride", c_int64),
+        ("full_len", c_int32), ("full_capacity", c_int32),
+        ("str_k_src", c_void_p), ("str_v_src", c_void_p), ("src_token_stride", c_int64), ("src_head_stride", c_int64),
+        ("str_k_dst", c_void_p), ("str_v_dst", c_void_p), ("dst_token_stride", c_int64), ("dst_head_stride", c_int64),
+        ("str_len", c_int32), ("sink", c_int32), ("recent", c_int32), ("_pad", c_int32),
+    ]
+
 
 _SIGNATURES = {
     "duo_abi_version": (ctypes.c_int, []),
@@ -148,6 +167,10 @@ _SIGNATURES = {
         ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "duo_decode_state_add": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "duo_decode_layer_batched_dev_bf16": (
+        ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(DecodeBatch), c_void_p, c_void_p, c_int64, c_void_p],
+    ),
+    "duo_tuple_decode_prep_bf16": (ctypes.c_int, [POINTER(TupleDecodeArgs), POINTER(c_int32), c_void_p]),
     "duo_attn_prefill_bf16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
@@ -274,6 +297,10 @@ def _check(code: int, what: str):
         raise DuoHipError(f"{what} failed: [{code}] {msg}")
 
 
+_cuda_get_device = torch._C._cuda_getDevice                        # (torch.cuda.current_device() minus its lazy-init checks:
+_cuda_raw_stream = torch._C._cuda_getCurrentRawStream              #  these two are called tens of times per decode step)
+
+
 def _require_gpu_bf16(t: torch.Tensor, name: str, dtype=torch.bfloat16):
     if not t.is_cuda:
         raise DuoHipError(
@@ -284,16 +311,19 @@ def _require_gpu_bf16(t: torch.Tensor, name: str, dtype=torch.bfloat16):
         raise DuoHipError(f"{name} must be {dtype}, got {t.dtype}")
     if t.stride(-1) != 1:
         raise DuoHipError(f"{name}: last (head_dim) dimension must be contiguous")
-    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+    if t.get_device() != _cuda_get_device():
         raise DuoHipError(
             f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: launches go to "
-            "the current device's stream — wrap the call in `with torch.cuda.device(tensor.device):`")
+            "the current device's stream — wrap the call in `with torch.cuda.device(tensor.device):` (to_device / "
+            "shard_model_for_pp / shard_model_for_tp select the rank's device themselves)")
 
 
 def _stream_ptr(device=None) -> int:
     """the stream the launch goes to = the current stream of the CURRENT device.  Every wrapper below launches on the
     device its tensors live on only if that is the current device (the workspaces are keyed the same way), which
     ``_require_gpu_bf16`` enforces — a process that drives several GPUs switches with ``torch.cuda.device(...)``."""
+    if device is None:
+        return _cuda_raw_stream(_cuda_get_device())
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -456,8 +486,8 @@ _tickets = {}
 
 
 def _stream_key(device: torch.device):
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    return (idx, torch.cuda.current_stream(idx).cuda_stream)
+    idx = device.index if device.index is not None else _cuda_get_device()
+    return (idx, _cuda_raw_stream(idx))
 
 
 def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
@@ -532,6 +562,47 @@ def attn_decode(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[H
         ),
         "duo_attn_decode_bf16",
     )
+
+
+def attn_decode_tuple(q, out, group: int, n_full: int, arena, full_len: int, str_src, k, v, scale: float):
+    """The two flash_attn_func calls of the tuple-cache forward at q_len == 1 (reference llama.py:225-262) as ONE split-KV
+    decode launch pair, straight over the tuple format: retrieval heads over rows [0, full_len) of ``arena`` ([2, nf, cap, D]:
+    K then V) ++ the new row, streaming heads over ``str_src`` ([2, ns, n, D]) ++ the new row; ``k`` / ``v`` [Hkv, D] are the
+    new (rotated) rows, ``q`` / ``out`` [Hq, D].  Same kernel and arithmetic as ``attn_decode`` — this form only spares the
+    host the dozen tensor views per layer and token that describing the segments as tensors costs."""
+    lib = load_library()
+    for t, n in ((q, "q"), (out, "out"), (k, "k"), (v, "v")):
+        _require_gpu_bf16(t, n)
+    Hq, D = q.shape
+    Hkv = k.shape[0]
+    ns = Hkv - n_full
+    khs = k.stride(0)
+    assert v.stride(0) == khs and out.shape == q.shape
+    fc = sc = None
+    if n_full > 0:
+        _require_gpu_bf16(arena, "arena")
+        fc = HeadClass()
+        fc.n_kv_heads, fc.q_head_offset = n_full, 0
+        a, b = fc.segA, fc.segB
+        if full_len > 0:
+            a.k, a.v = arena.data_ptr(), arena.data_ptr() + 2 * arena.stride(0)
+            a.token_stride, a.head_stride, a.len = arena.stride(2), arena.stride(1), int(full_len)
+        b.k, b.v, b.token_stride, b.head_stride, b.len = k.data_ptr(), v.data_ptr(), 0, khs, 1
+    if ns > 0:
+        sc = HeadClass()
+        sc.n_kv_heads, sc.q_head_offset = ns, n_full * int(group)
+        a, b = sc.segA, sc.segB
+        n = str_src.shape[2]
+        if n > 0:
+            _require_gpu_bf16(str_src, "streaming cache")
+            a.k, a.v = str_src.data_ptr(), str_src.data_ptr() + 2 * str_src.stride(0)
+            a.token_stride, a.head_stride, a.len = str_src.stride(2), str_src.stride(1), n
+        off = 2 * n_full * khs
+        b.k, b.v, b.token_stride, b.head_stride, b.len = k.data_ptr() + off, v.data_ptr() + off, 0, khs, 1
+    ws = decode_workspace(q.device, Hq)
+    _check(lib.duo_attn_decode_bf16(q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), int(group),
+                                    byref(fc) if fc is not None else None, byref(sc) if sc is not None else None,
+                                    float(scale), D, ws.data_ptr(), ws.numel() * 4, _stream_ptr()), "duo_attn_decode_bf16")
 
 
 def _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
@@ -708,6 +779,35 @@ def decode_layer_batched(q, k, v, out, n_full, full_k, full_v, full_len, str_k, 
     return int(new_len.value)
 
 
+def decode_layer_batched_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink, recent,
+                             pos, rope_scale, rope_theta, scale, dev_state: torch.Tensor) -> None:
+    """``decode_layer_batched`` with the lengths / position read from ``dev_state`` (int32 [4] on the GPU) — graph-capturable
+    for B > 1.  ``pos``: one int, or one per row: row b runs at ``dev_state.pos + (pos[b] - plan_full_len)`` (the device
+    counter starts as the cache length; a row's offset from it is fixed for the life of a sequence); the ``plan_*`` values
+    only size the grid."""
+    lib = load_library()
+    assert dev_state.is_cuda and dev_state.dtype == torch.int32 and dev_state.numel() >= 4 and dev_state.is_contiguous()
+    B = q.shape[0]
+    ns = k.shape[1] - n_full
+    # args.pos = the host's view of the device-side position counter (= the cache length, sync_device_state)
+    a = _decode_layer_args(q[0], k[0], v[0], out[0], n_full, full_k[0] if n_full > 0 else None,
+                           full_v[0] if n_full > 0 else None, plan_full_len, str_k[0] if ns > 0 else None,
+                           str_v[0] if ns > 0 else None, plan_str_len, sink, recent,
+                           plan_full_len, rope_scale, rope_theta, scale)
+    rows = [int(pos)] * B if not isinstance(pos, (list, tuple)) else [int(p) for p in pos]
+    arr = (c_int64 * B)(*rows)
+    bt = DecodeBatch()
+    bt.n_batch = B
+    bt.q_batch_stride, bt.kv_batch_stride, bt.out_batch_stride = q.stride(0), k.stride(0), out.stride(0)
+    assert v.stride(0) == k.stride(0)
+    bt.full_batch_stride = full_k.stride(0) if n_full > 0 else 0
+    bt.str_batch_stride = str_k.stride(0) if ns > 0 else 0
+    bt.pos = arr
+    ws = decode_workspace(q.device, q.shape[1])
+    _check(lib.duo_decode_layer_batched_dev_bf16(byref(a), byref(bt), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                 _stream_ptr()), "duo_decode_layer_batched_dev_bf16")
+
+
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """flashinfer.norm.rmsnorm semantics on [rows, hidden] bf16."""
     lib = load_library()
@@ -743,16 +843,18 @@ def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
 
 def token_linear_fits(n_rows: int, n_in: int) -> bool:
     """whether duo_token_linear_bf16 takes ``n_rows`` token rows of ``n_in`` features (rows in LDS, 156 KiB)"""
-    kpad = -(-n_in // 4096) * 4096
+    kpad = -(-n_in // TOKEN_LINEAR_PAD) * TOKEN_LINEAR_PAD
     return 1 <= n_rows <= TOKEN_LINEAR_MAX_ROWS and n_in >= 8 and n_in % 8 == 0 and n_rows * kpad * 2 <= 156 * 1024
 
 
 def token_linear(x: torch.Tensor, blocks, norm=None, x2: Optional[torch.Tensor] = None,
-                 residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 residual: Optional[torch.Tensor] = None, norm_hf: bool = False) -> torch.Tensor:
     """Token-row linear layers of the decode step in ONE launch (duo_token_linear_bf16):
     ``y = [W0; W1; W2] @ xn + bias (+ residual)`` with ``xn = x``, ``rmsnorm(x; *norm)`` or ``silu(x) * x2``.
     x [rows, n_in] bf16 (rows <= 4, unit inner stride); blocks: up to three ``(weight [n, n_in], bias or None)``;
-    norm: ``(weight [n_in], eps)``; returns [rows, sum n] bf16."""
+    norm: ``(weight [n_in], eps)`` — the flashinfer form (one rounding; the static path's norm), or with ``norm_hf`` the
+    HuggingFace ``*RMSNorm.forward`` form (normalised x rounded to bf16 before the weight multiply; the tuple path's);
+    returns [rows, sum n] bf16."""
     lib = load_library()
     _require_gpu_bf16(x, "x")
     rows, n_in = x.shape
@@ -766,6 +868,8 @@ def token_linear(x: torch.Tensor, blocks, norm=None, x2: Optional[torch.Tensor] 
             raise DuoHipError("token_linear: x2 must have the shape and strides of x")
         a.x2 = x2.data_ptr()
     n_total = 0
+    keep = []       # contiguous copies of bias / norm weight stay referenced until the launch is enqueued: a temporary freed
+    #                 before `y` is allocated could be handed to `y` by the caching allocator (or a graph's private pool)
     for i, (w, b) in enumerate(blocks):
         _require_gpu_bf16(w, "weight")
         if w.dim() != 2 or w.shape[1] != n_in or w.stride(1) != 1:
@@ -773,11 +877,16 @@ def token_linear(x: torch.Tensor, blocks, norm=None, x2: Optional[torch.Tensor] 
         a.seg[i].w, a.seg[i].row_stride, a.seg[i].n = w.data_ptr(), w.stride(0), w.shape[0]
         if b is not None:
             _require_gpu_bf16(b, "bias")
-            a.seg[i].bias = b.contiguous().data_ptr()
+            bc = b if b.is_contiguous() else b.contiguous()
+            keep.append(bc)
+            a.seg[i].bias = bc.data_ptr()
         n_total += w.shape[0]
     if norm is not None:
         _require_gpu_bf16(norm[0], "norm weight")
-        a.norm_weight, a.norm_eps = norm[0].contiguous().data_ptr(), float(norm[1])
+        nw = norm[0] if norm[0].is_contiguous() else norm[0].contiguous()
+        keep.append(nw)
+        a.norm_weight, a.norm_eps = nw.data_ptr(), float(norm[1])
+        a.flags = LINEAR_NORM_HF if norm_hf else 0
     y = torch.empty(rows, n_total, dtype=torch.bfloat16, device=x.device)
     if residual is not None:
         _require_gpu_bf16(residual, "residual")
@@ -786,7 +895,52 @@ def token_linear(x: torch.Tensor, blocks, norm=None, x2: Optional[torch.Tensor] 
         a.residual, a.residual_row_stride = residual.data_ptr(), residual.stride(0)
     a.y, a.y_row_stride = y.data_ptr(), y.stride(0)
     _check(lib.duo_token_linear_bf16(byref(a), _stream_ptr()), "duo_token_linear_bf16")
+    del keep
     return y
+
+
+def tuple_decode_prep(q, k, v, cos_row, sin_row, n_full: int, arena, full_len: int, str_src, sink: int, recent: int):
+    """The tuple-cache decode step's data movement in ONE launch (duo_tuple_decode_prep_bf16; reference llama.py:177-184,
+    :202-223, :273-301 at q_len == 1, one batch row): q [Hq, D] and k [Hkv, D] are rotated IN PLACE with HF's rotary in
+    torch's bf16 arithmetic (cos_row / sin_row: [D] bf16); the retrieval heads' new rows land at row ``full_len`` of
+    ``arena`` ([2, nf, cap, D]: K then V); the streaming cache ``str_src`` ([2, ns, n, D]) ++ new row, truncated to
+    sink + recent, is written to a NEW tensor, which is returned ([2, ns, min(n + 1, sink + recent), D], head-major)."""
+    lib = load_library()
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (cos_row, "cos"), (sin_row, "sin")):
+        _require_gpu_bf16(t, n)
+    Hq, D = q.shape
+    Hkv = k.shape[0]
+    ns = Hkv - n_full
+    assert k.stride(0) == v.stride(0) and cos_row.numel() == D and sin_row.numel() == D
+    a = TupleDecodeArgs()
+    a.q, a.q_head_stride, a.n_q_heads, a.n_kv_heads = q.data_ptr(), q.stride(0), Hq, Hkv
+    a.k, a.v, a.kv_head_stride = k.data_ptr(), v.data_ptr(), k.stride(0)
+    a.cos_row, a.sin_row = cos_row.data_ptr(), sin_row.data_ptr()
+    a.n_full, a.head_dim = int(n_full), D
+    if n_full > 0:
+        _require_gpu_bf16(arena, "arena")
+        assert arena.dim() == 4 and arena.shape[0] == 2 and arena.shape[1] == n_full and arena.stride(3) == 1
+        a.full_k, a.full_v = arena[0].data_ptr(), arena[1].data_ptr()
+        a.full_token_stride, a.full_head_stride = arena.stride(2), arena.stride(1)
+        a.full_capacity = arena.shape[2]
+    a.full_len = int(full_len)
+    n = int(str_src.shape[2])
+    out_len = min(n + 1, sink + recent)
+    dst = torch.empty(2, ns, out_len, D, dtype=torch.bfloat16, device=q.device)
+    if ns > 0:
+        if n > 0:
+            _require_gpu_bf16(str_src, "streaming cache")
+            assert str_src.shape[0] == 2 and str_src.shape[1] == ns
+            a.str_k_src, a.str_v_src = str_src[0].data_ptr(), str_src[1].data_ptr()
+            a.src_token_stride, a.src_head_stride = str_src.stride(2), str_src.stride(1)
+        if out_len > 0:
+            a.str_k_dst, a.str_v_dst = dst[0].data_ptr(), dst[1].data_ptr()
+            a.dst_token_stride, a.dst_head_stride = dst.stride(2), dst.stride(1)
+    a.str_len, a.sink, a.recent = n, int(sink), int(recent)
+    new_len = c_int32(0)
+    _check(lib.duo_tuple_decode_prep_bf16(byref(a), byref(new_len), _stream_ptr()), "duo_tuple_decode_prep_bf16")
+    assert new_len.value == out_len
+    return dst
 
 
 # ----------------------------------------------------------------------------- INT4 KV pools

@@ -105,8 +105,21 @@ class HipBackend:
     def token_linear_fits(self, n_rows: int, n_in: int) -> bool:
         return self._hip.token_linear_fits(n_rows, n_in)
 
-    def token_linear(self, x, blocks, norm=None, x2=None, residual=None):
-        return self._hip.token_linear(x, blocks, norm=norm, x2=x2, residual=residual)
+    def token_linear(self, x, blocks, norm=None, x2=None, residual=None, norm_hf=False):
+        return self._hip.token_linear(x, blocks, norm=norm, x2=x2, residual=residual, norm_hf=norm_hf)
+
+    # -- the tuple-cache forward's data movement at q_len == 1 (reference llama.py:177-184, :202-223, :273-301): HF rotary in
+    #    place, retrieval rows appended to the arena, the new (truncated) streaming cache written out of place — one launch
+    def tuple_decode_prep(self, q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent):
+        return self._hip.tuple_decode_prep(q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent)
+
+    # -- ... and its two flash_attn_func calls (llama.py:225-262) over the tuple format, segments described by strides
+    #    (same kernel as `attention` at q_len == 1; no tensor views on the host)
+    def tuple_decode_attention(self, q, out, group, n_full, arena, full_len, str_src, k, v, scale):
+        self._hip.attn_decode_tuple(q, out, group, n_full, arena, full_len, str_src, k, v, scale)
+
+    def decode_layer_batched_dev(self, *args, **kw) -> None:
+        return self._hip.decode_layer_batched_dev(*args, **kw)
 
 
 _backend = None

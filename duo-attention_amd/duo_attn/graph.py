@@ -5,16 +5,37 @@ layer from Python every token, with the cache lengths as Python ints baked into 
 (``static_kv_cache.py:44-45``) — at 128K the attention is long enough to hide that, at <=32K or with the
 whole HF model around it the step is host-bound.  Here the lengths also live in HBM
 (``DuoAttentionStaticKVCache.device_state``), the fused decode kernels read them on the device, and the
-whole step — every layer's GEMMs, norms, the two attention launches per layer, the counter update and
+whole step — every layer's token-row linears, the two attention launches per layer, the counter update and
 (for the benchmark protocol) ``evict_last`` — is captured ONCE in a HIP graph and replayed per token.
 The captured split-KV grid keeps working as the context grows: its balanced partition deals the *current*
 number of 64-token units to the captured number of workgroups.
+
+Two ways in:
+
+* ``DecodeStepGraph(kv_cache, step_fn, evict_after)`` — explicit (``tools/benchmark_static.py --graph``, tests);
+* ``auto_decode_step`` — what the patched ``*ForCausalLM.forward`` does by itself when the call is the reference loop's
+  decode call (one token, implicit positions, a static cache on this GPU, no gradients): the reference's harness runs
+  UNCHANGED and its steps are graph replays after two eager ones.  ``DUO_AUTO_DECODE_GRAPH=0`` keeps every step eager.
+
+Which counters the device copy currently equals is tracked on the cache (``kv_cache._device_counters``): anything that
+moves the host counters without going through a graph — ``clear()``, an eager prefill, an eager decode step — makes the
+next replay re-upload them (one small H2D copy outside the graph); ``evict_last`` between two replays is mirrored with
+one tiny launch instead, so the reference's step-then-evict loop never synchronises the stream.
 """
 from __future__ import annotations
 
+import os
+import warnings
 from typing import Callable
 
 import torch
+
+AUTO_DECODE_GRAPH = os.environ.get("DUO_AUTO_DECODE_GRAPH", "1") != "0"
+_AUTO_WARM_STEPS = 2        # eligible eager decode steps before the capture (kernels, GEMM handles and workspaces exist by then)
+
+
+def _host_counters(c):
+    return (tuple(c.kv_seq_len_list), tuple(c.streaming_kv_seq_len_list))
 
 
 class DecodeStepGraph:
@@ -24,28 +45,26 @@ class DecodeStepGraph:
 
     ``evict_after``: tokens evicted after every step inside the graph (1 = the reference's benchmark
     protocol ``kv_cache.evict_last(1)``; 0 = real generation, the cache grows by one row per replay).
+    Batch rows: every row of the cache shares the layer's counters (reference static_kv_cache.py:44-45), so a batched
+    step is captured the same way (``duo_decode_layer_batched_dev_bf16``).
     """
 
     def __init__(self, kv_cache, step_fn: Callable[[], object], evict_after: int = 0):
-        if kv_cache.batch_size != 1:
-            raise ValueError("DecodeStepGraph supports batch size 1")
         if kv_cache.kv_seq_len < 1:
             raise ValueError("capture the decode step after the prefill (empty cache)")
         self.cache, self.step_fn, self.evict_after = kv_cache, step_fn, int(evict_after)
         kv_cache.enable_device_state()
         host = (list(kv_cache.kv_seq_len_list), list(kv_cache.streaming_kv_seq_len_list))
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.output = self._body()
-        # capture records launches without running them: device state and pools are untouched, only the
-        # host mirror moved while the Python code ran
-        kv_cache.kv_seq_len_list[:], kv_cache.streaming_kv_seq_len_list[:] = host
+        try:
+            with torch.cuda.graph(self.graph):
+                self.output = self._body()
+        finally:
+            # capture records launches without running them: device state and pools are untouched, only the
+            # host mirror moved while the Python code ran
+            kv_cache.kv_seq_len_list[:], kv_cache.streaming_kv_seq_len_list[:] = host
+            kv_cache.use_device_state = False
         kv_cache.sync_device_state()
-        self._expected = self._host_counters()
-
-    def _host_counters(self):
-        c = self.cache
-        return (tuple(c.kv_seq_len_list), tuple(c.streaming_kv_seq_len_list))
 
     def _body(self):
         c = self.cache
@@ -63,12 +82,12 @@ class DecodeStepGraph:
         """one decode step; returns the (static) output of ``step_fn`` captured at construction.
 
         The kernels of the captured step read the cache lengths from HBM.  Anything that moved the HOST counters
-        since the last replay without going through the graph — ``clear()``, ``evict_last()``, an eager prefill of
+        since they were last known to agree without going through a graph — ``clear()``, an eager prefill of
         the next prompt (``put_full_kv`` / ``update_streaming_kv``) — leaves that device copy stale, so the host
-        counters are compared with what the last replay left and re-uploaded when they differ (one small H2D
+        counters are compared with ``kv_cache._device_counters`` and re-uploaded when they differ (one small H2D
         copy, outside the graph).  The same graph therefore serves prompt after prompt."""
         c = self.cache
-        if self._host_counters() != self._expected:
+        if _host_counters(c) != c._device_counters:
             c.sync_device_state()
         if max(c.kv_seq_len_list) + 1 > c.max_size:
             raise ValueError(
@@ -80,6 +99,92 @@ class DecodeStepGraph:
             c.kv_seq_len_list[i] += 1
             c.streaming_kv_seq_len_list[i] = min(c.streaming_kv_seq_len_list[i] + 1, W)
         if self.evict_after:
-            c.evict_last(self.evict_after)
-        self._expected = self._host_counters()
+            hook, c._decode_graph = c._decode_graph, None       # (the graph rewound the device copy itself)
+            try:
+                c.evict_last(self.evict_after)
+            finally:
+                c._decode_graph = hook
+        c._device_counters = _host_counters(c)
         return self.output
+
+    def host_evicted(self, before, n) -> None:
+        """``kv_cache.evict_last(n)`` ran on the host between two replays (the reference's benchmark loop does after
+        every step, benchmark_static.py:104).  When the device counters agreed with the host's before it, one tiny launch
+        rewinds them too — the next replay then needs no host-to-device copy, which would synchronise the stream once
+        per token."""
+        c = self.cache
+        if c._device_counters is not None and before == c._device_counters:
+            c.device_state_add(-n, -n, -n)
+            c._device_counters = _host_counters(c)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# automatic capture for the reference's UNCHANGED decode loop
+# ------------------------------------------------------------------------------------------------------------------
+def _model_signature(model):
+    """what the captured launches depend on besides the cache: the layers' forwards and weight storage, and the switches
+    that select kernels — a change of any of them retires the captured step"""
+    from . import _hip
+    from .patch import _duo
+
+    sig = [id(model), _duo._FUSED_DECODE_LAYER, int(_hip.load_library().duo_get_debug_flags())]
+    for layer in model.model.layers:
+        a = layer.self_attn
+        sig.append((id(getattr(layer.forward, "__func__", None)), id(getattr(a.forward, "__func__", None)),
+                    a.q_proj.weight.data_ptr(), layer.mlp.down_proj.weight.data_ptr()))
+    return tuple(sig)
+
+
+def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs_embeds, labels, kwargs) -> bool:
+    """The reference's decode call ``model(input_ids=pred, past_key_values=kv_cache, use_cache=True)``
+    (eval/efficiency/benchmark_static.py:98-102): one token, one batch row, implicit positions, a non-empty static cache on
+    this GPU, no gradients, a single-process model on the HIP backend."""
+    from .backend import get_backend
+
+    if not AUTO_DECODE_GRAPH or input_ids is None or inputs_embeds is not None or labels is not None or position_ids is not None:
+        return False
+    if kwargs or input_ids.shape != (1, 1) or not input_ids.is_cuda or torch.is_grad_enabled() or model.training:
+        return False
+    kv = past_key_values
+    if kv is None or not hasattr(kv, "enable_device_state") or getattr(kv, "batch_size", 0) != 1 or kv.kv_seq_len < 1:
+        return False
+    if getattr(model, "_duo_pp", None) is not None or getattr(model, "_duo_tp", None) is not None:
+        return False
+    if getattr(kv, "_auto_graph_failed", False) or kv.device.type != "cuda" or input_ids.device != kv.device:
+        return False
+    if kv.device.index is not None and kv.device.index != torch.cuda.current_device():
+        return False
+    if torch.cuda.is_current_stream_capturing():
+        return False        # somebody else's capture (DecodeStepGraph, a user's graph): this step is part of theirs
+    return getattr(get_backend(), "name", "") == "hip"
+
+
+def auto_decode_step(model, eager_forward, input_ids, kv):
+    """One decode step of the unchanged reference loop through a HIP graph captured on the way: the first eligible steps
+    after a change run eagerly, then the step is captured ONCE per (model, cache) and replayed — the cache lengths live in
+    HBM (``kv.device_state``), ``kv.evict_last`` rewinds them with a launch, an eager prefill in between re-uploads them.
+    Returns the logits (a fresh tensor per call), or None when this call should run eagerly."""
+    st = getattr(kv, "_auto_graph", None)
+    sig = _model_signature(model)
+    if st is None or st["sig"] != sig:
+        st = {"sig": sig, "calls": 0, "graph": None, "tok": None}
+        kv._auto_graph = st
+        kv._decode_graph = None
+    if st["graph"] is None:
+        st["calls"] += 1
+        if st["calls"] <= _AUTO_WARM_STEPS:
+            return None
+        tok = torch.zeros(1, 1, dtype=torch.long, device=kv.device)
+        tok.copy_(input_ids)
+        try:
+            g = DecodeStepGraph(kv, lambda: eager_forward(tok).logits, evict_after=0)
+        except Exception as e:      # a layer that cannot be captured (host read-backs, foreign modules): stay eager, say so once
+            kv._auto_graph_failed = True
+            warnings.warn(f"DuoAttention: automatic decode-step capture failed ({type(e).__name__}: {e}); decoding eagerly. "
+                          "DUO_AUTO_DECODE_GRAPH=0 disables the attempt.")
+            return None
+        st["graph"], st["tok"] = g, tok
+        kv._decode_graph = g
+    else:
+        st["tok"].copy_(input_ids)
+    return st["graph"].replay().clone()

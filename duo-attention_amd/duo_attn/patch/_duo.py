@@ -155,15 +155,23 @@ def duo_static_attention_row_block(query_states, key_states, value_states, kv_ca
     scale = head_dim ** -0.5
     pk, pv = kv_cache.full_key_states_list[layer_idx], kv_cache.full_value_states_list[layer_idx]
     ck, cv = kv_cache.get_streaming_kv(layer_idx)           # unchanged until the chunk's last block
-    for b in range(bsz):
+    batched = bsz > 1 and hasattr(be, "attention_batched")      # one launch for all batch rows, as in the whole-chunk path
+
+    def classes(sel):
+        """the two head classes of batch row(s) ``sel`` (an index, or slice(None) for the batched launch)"""
         if past_l == 0:     # first chunk: every head causal over the chunk's own rows (:364-372)
-            full = (nf, 0, None, (pk[b, :r1], pv[b, :r1])) if nf > 0 else None
-            stream = (ns, nf * groups, None, (stage_k[b, :r1], stage_v[b, :r1])) if ns > 0 else None
+            full = (nf, 0, None, (pk[sel, :r1], pv[sel, :r1])) if nf > 0 else None
+            stream = (ns, nf * groups, None, (stage_k[sel, :r1], stage_v[sel, :r1])) if ns > 0 else None
         else:
-            full = (nf, 0, (pk[b, :past_l], pv[b, :past_l]),
-                    (pk[b, past_l:past_l + r1], pv[b, past_l:past_l + r1])) if nf > 0 else None
-            stream = (ns, nf * groups, (ck[b], cv[b]), (stage_k[b, :r1], stage_v[b, :r1])) if ns > 0 else None
-        be.attention(query_states[b], attn_output[b], groups, full, stream, scale)
+            full = (nf, 0, (pk[sel, :past_l], pv[sel, :past_l]),
+                    (pk[sel, past_l:past_l + r1], pv[sel, past_l:past_l + r1])) if nf > 0 else None
+            stream = (ns, nf * groups, (ck[sel], cv[sel]), (stage_k[sel, :r1], stage_v[sel, :r1])) if ns > 0 else None
+        return full, stream
+
+    if batched:
+        be.attention_batched(query_states, attn_output, groups, *classes(slice(None)), scale)
+    for b in range(0 if batched else bsz):
+        be.attention(query_states[b], attn_output[b], groups, *classes(b), scale)
     st["next_row"] = r1
     if r1 == chunk_len:
         kv_cache.update_streaming_kv(layer_idx, stage_k[:, :chunk_len], stage_v[:, :chunk_len])
@@ -193,11 +201,17 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
     if getattr(kv_cache, "use_device_state", False):
         # graph-capturable form: the kernels read full_len / str_len / pos from the layer's device state;
         # the host values passed here only size the split-KV grid
-        if bsz != 1:
-            raise ValueError("device-side decode state supports batch size 1")
-        be.decode_layer_dev(query_states[0, 0], key_states[0, 0], value_states[0, 0], attn_output[0, 0], nf,
-                            pk[0], pv[0], cur, sk[0], sv[0], str_len, kv_cache.sink_size, kv_cache.recent_size,
-                            pos_rows[0], rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
+        if bsz == 1:
+            be.decode_layer_dev(query_states[0, 0], key_states[0, 0], value_states[0, 0], attn_output[0, 0], nf,
+                                pk[0], pv[0], cur, sk[0], sv[0], str_len, kv_cache.sink_size, kv_cache.recent_size,
+                                pos_rows[0], rope_scale, rope_theta, head_dim ** -0.5, kv_cache.device_state[layer_idx])
+        else:
+            # all batch rows share the layer's counters (reference static_kv_cache.py:44-45); a row that started at another
+            # position keeps its fixed offset from row 0 (pos_rows[b] - pos_rows[0]) on top of the device-side position
+            be.decode_layer_batched_dev(query_states[:, 0], key_states[:, 0], value_states[:, 0], attn_output[:, 0], nf,
+                                        pk, pv, cur, sk, sv, str_len, kv_cache.sink_size, kv_cache.recent_size,
+                                        pos_rows, rope_scale, rope_theta, head_dim ** -0.5,
+                                        kv_cache.device_state[layer_idx])
     elif bsz > 1 and hasattr(be, "decode_layer_batched"):
         # every batch row in ONE launch pair (grid-level batch rows; rows at different positions fall back to a launch
         # pair per row inside the library)
@@ -231,7 +245,7 @@ def _streamable_linear(m) -> bool:
     w = getattr(m, "weight", None)
     return (type(m) is torch.nn.Linear and w is not None and w.dtype == torch.bfloat16 and w.is_cuda
             and w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0
-            and (m.bias is None or m.bias.dtype == torch.bfloat16))
+            and (m.bias is None or (m.bias.dtype == torch.bfloat16 and m.bias.is_contiguous())))
 
 
 def _layer_modules(layer):
@@ -240,31 +254,117 @@ def _layer_modules(layer):
            [getattr(mlp, n, None) for n in ("gate_proj", "up_proj", "down_proj")]
 
 
-def _layer_static_verdict(layer) -> bool:
-    """the part of the eligibility that depends on the layer's modules only; cached on the layer, keyed by the identity of
-    the modules and of their weight storage (re-sharding or re-loading a layer re-evaluates it)"""
+def _norm_form(norm):
+    """which arithmetic an RMSNorm module's forward performs: "flashinfer" (one rounding: the static path's patched forward,
+    flashinfer_utils.rmsnorm_forward), "hf" (HuggingFace's own LlamaRMSNorm / MistralRMSNorm forward, two roundings — what
+    the tuple path runs, the reference's enable_duo_attention_eval leaves the norms alone), or None (anything else)"""
+    from .flashinfer_utils import rmsnorm_forward
+
+    w = getattr(norm, "weight", None)
+    if not hasattr(norm, "variance_epsilon") or w is None or w.dtype != torch.bfloat16 or not w.is_contiguous():
+        return None
+    fwd = getattr(norm.forward, "__func__", None)
+    if fwd is rmsnorm_forward:
+        return "flashinfer"
+    if type(norm).__name__ in ("LlamaRMSNorm", "MistralRMSNorm") and fwd is type(norm).forward:
+        return "hf"
+    return None
+
+
+class _FusedRefs:
+    """What the fused decode layer reads from a decoder layer, looked up ONCE: torch.nn.Module attribute access goes through
+    ``__getattr__`` (a dict walk per access, ~70 of them per layer and token otherwise).  Parameters are held as objects —
+    their ``.data`` may be swapped (weight reorder), the launch reads ``data_ptr()`` at call time."""
+
+    __slots__ = ("key", "ok", "attn", "qkv", "o", "gu", "down", "n_w", "n_eps", "n_hf", "p_w", "p_eps", "p_hf", "dims", "inter",
+                 "in_feats", "fits")
+
+
+
+def _out_linear(be, proj, x, x2, residual):
+    """o_proj / down_proj of the fused decode layer: ``proj(x [* silu-partner x2]) + residual`` in one launch, or — row
+    parallel (a tensor-parallel shard, duo_attn.tp) — the local product, the all-reduce over the TP group, then the add"""
+    if not _row_parallel(proj):
+        return be.token_linear(x, [(proj.weight, proj.bias)], x2=x2, residual=residual)
+    from ..tp import all_reduce_sum
+
+    y = be.token_linear(x, [(proj.inner.weight, proj.inner.bias)], x2=x2)
+    return residual + all_reduce_sum(y, proj.group)
+
+
+def _refs_key(layer, want_fwd):
+    attn = layer.self_attn
+    return (attn.q_proj.weight.data_ptr(), layer.mlp.down_proj.weight.data_ptr(),
+            getattr(attn.forward, "__func__", None) is want_fwd,
+            id(getattr(layer.input_layernorm.forward, "__func__", None)),
+            id(getattr(layer.post_attention_layernorm.forward, "__func__", None)))
+
+
+def _fused_refs(layer, want_fwd=None, tag="static"):
+    """the layer's ``_FusedRefs`` for the attention forward ``want_fwd`` (default: this module's static forward), cached on
+    the layer and keyed by the storage of its first and last projection and the identity of the forwards involved — the
+    enablers, a weight reload (``.to()``, ``load_state_dict`` into new storage) or a re-shard re-evaluate it.  ``.ok`` says
+    whether the layer's modules allow the fused form at all: attention carrying THIS module's forward (i.e. it went through
+    the matching enabler, weights reordered retrieval-heads-first), bf16 ``nn.Linear`` projections on the GPU (or a TP
+    shard's row-parallel o_proj / down_proj), SiLU-gated MLP, RMSNorm modules in a known form."""
+    if want_fwd is None:
+        want_fwd = duo_attention_forward_one_way_reordered_static
+    cache = layer.__dict__.get("_duo_fused_refs")
+    if cache is None:
+        cache = layer.__dict__["_duo_fused_refs"] = {}
+    hit = cache.get(tag)
+    try:
+        key = _refs_key(layer, want_fwd)
+    except AttributeError:          # not a Llama-style decoder layer
+        key = None
+    if hit is not None and hit.key == key and key is not None:
+        return hit
+    r = _FusedRefs()
+    r.key, r.ok = key, False
+    cache[tag] = r
+    if key is None:
+        return r
     mods = _layer_modules(layer)
-    key = tuple((id(m), m.weight.data_ptr() if getattr(m, "weight", None) is not None else 0) for m in mods)
-    cached = getattr(layer, "_duo_fused_decode_verdict", None)
-    if cached is not None and cached[0] == key:
-        return cached[1]
-    mlp = getattr(layer, "mlp", None)
-    # (the fused form calls duo_static_attention_core itself: only for attention modules that carry THIS module's static
-    #  forward — i.e. went through enable_*_duo_attention_static_kv_cache_eval, weights reordered retrieval-heads-first)
-    attn_fwd = getattr(getattr(layer.self_attn, "forward", None), "__func__", None)
-    ok = (mlp is not None and attn_fwd is duo_attention_forward_one_way_reordered_static
-          and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
-          and all(_streamable_linear(m) for m in mods)
-          and all(hasattr(n, "variance_epsilon") and n.weight.dtype == torch.bfloat16
-                  for n in (layer.input_layernorm, layer.post_attention_layernorm)))
-    layer._duo_fused_decode_verdict = (key, ok)
+    mlp, attn = layer.mlp, layer.self_attn
+    n_ln, p_ln = layer.input_layernorm, layer.post_attention_layernorm
+    if any(m is None or getattr(m, "weight", None) is None for m in mods) or not hasattr(n_ln, "variance_epsilon") \
+            or not hasattr(p_ln, "variance_epsilon"):
+        return r
+    # (the references are filled in whenever the layer has the shape of a Llama / Mistral decoder layer — the CPU test-suite
+    #  drives the fused form's host logic through them with the oracle as backend; `ok` is the product's own gate)
+    forms = (_norm_form(n_ln), _norm_form(p_ln))
+    lin = lambda m: (m.inner if _row_parallel(m) else m)
+    wb = lambda m: (lin(m).weight, lin(m).bias)
+    r.attn = attn
+    r.qkv = [wb(attn.q_proj), wb(attn.k_proj), wb(attn.v_proj)]
+    r.gu = [wb(mlp.gate_proj), wb(mlp.up_proj)]
+    r.o, r.down = attn.o_proj, mlp.down_proj            # (modules: _out_linear decides plain / row-parallel)
+    r.n_w, r.n_eps, r.n_hf = n_ln.weight, n_ln.variance_epsilon, forms[0] == "hf"
+    r.p_w, r.p_eps, r.p_hf = p_ln.weight, p_ln.variance_epsilon, forms[1] == "hf"
+    r.dims = _dims(attn)
+    r.inter = lin(mlp.gate_proj).out_features
+    r.in_feats = sorted({lin(m).in_features for m in mods})
+    r.fits = {}
+    r.ok = (key[2] and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
+            and all(_streamable_linear(m) for m in mods) and None not in forms)
+    return r
+
+
+def _layer_static_verdict(layer, want_fwd=None, key_tag="static") -> bool:
+    return _fused_refs(layer, want_fwd, key_tag).ok
+
+
+def _rows_fit(be, refs, rows) -> bool:
+    ok = refs.fits.get(rows)
+    if ok is None:
+        ok = refs.fits[rows] = all(be.token_linear_fits(rows, n) for n in refs.in_feats)
     return ok
 
 
 def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
     """Whether this decoder layer's decode step can run as the fused form below: one token per batch row after a
     prefill, bf16 on the GPU, ``nn.Linear`` projections (or a tensor-parallel shard's row-parallel o_proj / down_proj),
-    SiLU-gated MLP, RMSNorm modules with the patched forward, a backend that has the kernel."""
+    SiLU-gated MLP, RMSNorm modules with a known forward, a backend that has the kernel."""
     if not _FUSED_DECODE_LAYER or hidden_states.dim() != 3 or hidden_states.shape[1] != 1:
         return False
     be = get_backend()
@@ -274,10 +374,13 @@ def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
         return False
     if hidden_states.stride(2) != 1 or hidden_states.stride(0) % 8 or hidden_states.data_ptr() % 16:
         return False                       # (the kernel's 16-byte row loads)
-    if not _layer_static_verdict(layer):
-        return False
-    rows = hidden_states.shape[0]
-    return all(be.token_linear_fits(rows, (m.inner if _row_parallel(m) else m).in_features) for m in _layer_modules(layer))
+    refs = _fused_refs(layer)
+    return refs.ok and _rows_fit(be, refs, hidden_states.shape[0])
+
+
+def _norm_kw(hf: bool):
+    """``norm_hf=True`` for a norm module that runs HuggingFace's own two-rounding forward (``_norm_form``)"""
+    return {"norm_hf": True} if hf else {}
 
 
 def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None, position_ids=None):
@@ -296,38 +399,124 @@ def duo_decode_layer_fused(layer, hidden_states, kv_cache, layer_idx, pos0=None,
     is all-reduced over the TP group BEFORE the residual add (reference ``tensor_parallel`` semantics, utils.py:206-227),
     so their residual epilogue becomes a separate add behind the all-reduce; the other two launches are unchanged."""
     be = get_backend()
-    attn, mlp = layer.self_attn, layer.mlp
+    r = _fused_refs(layer)
     bsz, _, hidden = hidden_states.shape
-    num_heads, num_kv, head_dim, _ = _dims(attn)
+    num_heads, num_kv, head_dim, _ = r.dims
     x = hidden_states.reshape(bsz, hidden)
-    n_ln, p_ln = layer.input_layernorm, layer.post_attention_layernorm
-    qkv = be.token_linear(x, [(attn.q_proj.weight, attn.q_proj.bias), (attn.k_proj.weight, attn.k_proj.bias),
-                              (attn.v_proj.weight, attn.v_proj.bias)], norm=(n_ln.weight, n_ln.variance_epsilon))
+    qkv = be.token_linear(x, r.qkv, norm=(r.n_w, r.n_eps), **_norm_kw(r.n_hf))
     nq, nk = num_heads * head_dim, num_kv * head_dim
     q = qkv[:, :nq].view(bsz, 1, num_heads, head_dim)
     k = qkv[:, nq:nq + nk].view(bsz, 1, num_kv, head_dim)
     v = qkv[:, nq + nk:].view(bsz, 1, num_kv, head_dim)
-    rope_scale, rope_theta = rope_scale_and_theta(attn.config)
+    rope = r.attn.__dict__.get("_duo_rope")
+    if rope is None:
+        rope = r.attn.__dict__["_duo_rope"] = rope_scale_and_theta(r.attn.config)
     if pos0 is None and position_ids is not None:
         pos0 = first_positions(position_ids)
-    ao = duo_static_attention_core(q, k, v, kv_cache, layer_idx, pos0, rope_scale, rope_theta)
-    h1 = _out_linear(be, attn.o_proj, ao.reshape(bsz, nq), None, x)
-    gu = be.token_linear(h1, [(mlp.gate_proj.weight, mlp.gate_proj.bias), (mlp.up_proj.weight, mlp.up_proj.bias)],
-                         norm=(p_ln.weight, p_ln.variance_epsilon))
-    inter = mlp.gate_proj.out_features
-    h2 = _out_linear(be, mlp.down_proj, gu[:, :inter], gu[:, inter:], h1)
+    ao = duo_static_attention_core(q, k, v, kv_cache, layer_idx, pos0, rope[0], rope[1])
+    h1 = _out_linear(be, r.o, ao.reshape(bsz, nq), None, x)
+    gu = be.token_linear(h1, r.gu, norm=(r.p_w, r.p_eps), **_norm_kw(r.p_hf))
+    h2 = _out_linear(be, r.down, gu[:, :r.inter], gu[:, r.inter:], h1)
     return h2.view(bsz, 1, hidden)
 
 
-def _out_linear(be, proj, x, x2, residual):
-    """o_proj / down_proj of the fused decode layer: ``proj(x [* silu-partner x2]) + residual`` in one launch, or — row
-    parallel — the local product, the all-reduce over the TP group, then the add"""
-    if not _row_parallel(proj):
-        return be.token_linear(x, [(proj.weight, proj.bias)], x2=x2, residual=residual)
-    from ..tp import all_reduce_sum
+# =============================================================================
+# decode step of a decoder layer on the TUPLE cache (enable_duo_attention_eval), fused the same way
+# =============================================================================
+def tuple_fused_decode_ok(layer, hidden_states, past_key_value, position_embeddings, use_cache) -> bool:
+    """Whether this decoder layer's decode step on the tuple cache can run as ``duo_tuple_decode_layer_fused``: one token,
+    one batch row, a non-empty past in the tuple format, bf16 on the GPU, ``nn.Linear`` projections, SiLU-gated MLP, RMSNorm
+    modules in a known form, HF rotary cos / sin for this position, a backend that has the kernels."""
+    if not _FUSED_DECODE_LAYER or not use_cache or hidden_states.dim() != 3 or hidden_states.shape[:2] != (1, 1):
+        return False
+    if past_key_value is None or position_embeddings is None or len(past_key_value) != 2:
+        return False
+    be = get_backend()
+    if not (hasattr(be, "token_linear") and hasattr(be, "tuple_decode_prep")):
+        return False
+    if not hidden_states.is_cuda or hidden_states.dtype != torch.bfloat16:
+        return False
+    if hidden_states.stride(2) != 1 or hidden_states.data_ptr() % 16:
+        return False
+    refs = _fused_refs(layer, duo_attention_forward_one_way_reordered, "tuple")
+    if not refs.ok or not _rows_fit(be, refs, 1):
+        return False
+    pf, ps = past_key_value
+    if not (torch.is_tensor(pf) and torch.is_tensor(ps) and pf.dim() == 4 and ps.dim() == 4 and pf.shape[0] == 2
+            and ps.shape[0] == 2 and pf.shape[2] > 0 and pf.dtype == torch.bfloat16 and ps.dtype == torch.bfloat16
+            and pf.device == hidden_states.device and ps.device == hidden_states.device):
+        return False
+    if ps.numel() and (ps.stride(3) != 1 or ps.data_ptr() % 16 or any(st % 8 for st in ps.stride()[:3])):
+        return False
+    attn = refs.attn
+    if not hasattr(attn, "full_attention_heads") or "sink_size" not in attn.__dict__:
+        return False
+    _, num_kv, head_dim, _ = refs.dims
+    if head_dim != 128 or pf.shape[3] != head_dim or pf.shape[1] + ps.shape[1] != num_kv:
+        return False
+    for t in position_embeddings:
+        if not (torch.is_tensor(t) and t.dtype == torch.bfloat16 and t.is_cuda and t.numel() == head_dim
+                and t.is_contiguous() and t.data_ptr() % 16 == 0):
+            return False
+    return True
 
-    y = be.token_linear(x, [(proj.inner.weight, proj.inner.bias)], x2=x2)
-    return residual + all_reduce_sum(y, proj.group)
+
+def tuple_decode_attention_by_views(be, q, out, groups, nf, arena, N, past_stream, k, v, scale):
+    """the fused tuple step's attention through the generic ``attention`` backend call (segments as tensor views): what
+    ``tuple_decode_attention`` computes, for backends without it (the oracle) and for tests that record every call"""
+    ns = k.shape[0] - nf
+    full = (nf, 0, (arena[0, :, :N].transpose(0, 1), arena[1, :, :N].transpose(0, 1)),
+            (k[:nf].unsqueeze(0), v[:nf].unsqueeze(0))) if nf > 0 else None
+    stream = (ns, nf * groups,
+              (past_stream[0].transpose(0, 1), past_stream[1].transpose(0, 1)) if past_stream.shape[2] > 0 else None,
+              (k[nf:].unsqueeze(0), v[nf:].unsqueeze(0))) if ns > 0 else None
+    be.attention(q.unsqueeze(0), out.unsqueeze(0), groups, full, stream, scale)
+
+
+def duo_tuple_decode_layer_fused(layer, hidden_states, past_key_value, position_embeddings):
+    """The tuple-cache decoder layer at q_len == 1 (reference tuple_kv_cache.py:431-490 around llama.py:146-306) in seven
+    launches instead of ~45 torch kernels:
+
+        q|k|v = [Wq; Wk; Wv] . rmsnorm(h)          input_layernorm in the projection's prologue (HF's two-rounding form)
+        prep                                        HF rotary on q, k in place; retrieval rows appended to the arena;
+                                                    the new streaming cache = truncate(old ++ new row), out of place
+        attn  = decode attention                    retrieval heads over arena[:N] ++ new row, streaming heads over
+                                                    old cache ++ new row (scan + merge launch)
+        h1    = Wo . attn + h ;  g|u = [Wg; Wu] . rmsnorm(h1) ;  h2 = Wd . (silu(g) * u) + h1
+
+    Returns ``(hidden_states, (full_KV, streaming_KV))`` with the tuple format's shapes: ``[2, nf, N + 1, D]`` — a view of
+    the module-owned arena, as ``_tuple_full_kv_append`` hands out — and ``[2, ns, min(n + 1, sink + recent), D]`` (new)."""
+    be = get_backend()
+    r = _fused_refs(layer, duo_attention_forward_one_way_reordered, "tuple")
+    attn = r.attn
+    hidden = hidden_states.shape[2]
+    num_heads, num_kv, head_dim, groups = r.dims
+    x = hidden_states.reshape(1, hidden)
+    qkv = be.token_linear(x, r.qkv, norm=(r.n_w, r.n_eps), **_norm_kw(r.n_hf))
+    nq, nk = num_heads * head_dim, num_kv * head_dim
+    q = qkv[0, :nq].view(num_heads, head_dim)
+    k = qkv[0, nq:nq + nk].view(num_kv, head_dim)
+    v = qkv[0, nq + nk:].view(num_kv, head_dim)
+    ad = attn.__dict__
+    if ad.get("full_attn_head_mask") is None:
+        _tuple_head_split(attn, num_heads, num_kv, groups)
+    nf, ns = ad["num_full_attn_head"], ad["num_streaming_attn_head"]
+    past_full, past_stream = past_key_value
+    arena, N = _tuple_arena_for(attn, past_full, 1, 1, nf, head_dim, hidden_states.device, hidden_states.dtype)
+    buf = arena["buf"]
+    cos, sin = position_embeddings
+    new_stream = be.tuple_decode_prep(q, k, v, cos.view(-1), sin.view(-1), nf, buf, N, past_stream,
+                                      ad["sink_size"], ad["recent_size"])
+    arena["len"] = N + 1
+    out = torch.empty(num_heads, head_dim, dtype=hidden_states.dtype, device=hidden_states.device)
+    if hasattr(be, "tuple_decode_attention"):
+        be.tuple_decode_attention(q, out, groups, nf, buf, N, past_stream, k, v, head_dim ** -0.5)
+    else:
+        tuple_decode_attention_by_views(be, q, out, groups, nf, buf, N, past_stream, k, v, head_dim ** -0.5)
+    h1 = _out_linear(be, r.o, out.view(1, nq), None, x)
+    gu = be.token_linear(h1, r.gu, norm=(r.p_w, r.p_eps), **_norm_kw(r.p_hf))
+    h2 = _out_linear(be, r.down, gu[:, :r.inter], gu[:, r.inter:], h1)
+    return h2.view(1, 1, hidden), (buf[:, :, :N + 1], new_stream)
 
 
 # =============================================================================
@@ -401,11 +590,7 @@ def duo_attention_forward_one_way_reordered(
     query_states, key_states = hf_apply_rotary_pos_emb(query_states, key_states, cos, sin, unsqueeze_dim=2)
 
     if not hasattr(self, "full_attn_head_mask") or self.full_attn_head_mask is None:
-        self.full_attn_head_mask = self.full_attention_heads > 0.5
-        self.num_full_attn_head = int(self.full_attn_head_mask.sum().item())
-        self.num_streaming_attn_head = num_kv - self.num_full_attn_head
-        self.num_full_query_head = self.num_full_attn_head * groups
-        self.num_streaming_query_head = num_heads - self.num_full_query_head
+        _tuple_head_split(self, num_heads, num_kv, groups)
     nf, ns = self.num_full_attn_head, self.num_streaming_attn_head
 
     full_key_states = key_states[:, :, :nf, :]
@@ -484,6 +669,16 @@ def duo_attention_forward_one_way_reordered(
     return attn_output, None, past_key_value
 
 
+def _tuple_head_split(module, num_heads, num_kv, groups):
+    """head counts of the two classes from the registered pattern, computed once (reference llama.py:186-195; one
+    device read-back)"""
+    module.full_attn_head_mask = module.full_attention_heads > 0.5
+    module.num_full_attn_head = int(module.full_attn_head_mask.sum().item())
+    module.num_streaming_attn_head = num_kv - module.num_full_attn_head
+    module.num_full_query_head = module.num_full_attn_head * groups
+    module.num_streaming_query_head = num_heads - module.num_full_query_head
+
+
 def release_tuple_arena(module_or_model):
     """Free the retrieval-head arena(s) of the tuple path (up to 1.5x a layer's full KV each).  The arena lives on
     the attention module between calls so that linear generation appends in place; call this (on a module or on
@@ -505,26 +700,34 @@ def _tuple_full_kv_append(module, past_full, new_k, new_v):
     caller that alternates two sequences on one model makes every call copy (the arena follows the last
     sequence).  ``release_tuple_arena`` frees it."""
     bsz, q, nf, D = new_k.shape
+    arena, N = _tuple_arena_for(module, past_full, bsz, q, nf, D, new_k.device, new_k.dtype)
+    buf = arena["buf"]
+    buf[:bsz, :, N:N + q].copy_(new_k.transpose(1, 2))
+    buf[bsz:, :, N:N + q].copy_(new_v.transpose(1, 2))
+    arena["len"] = N + q
+    return buf[:, :, :N + q]
+
+
+def _tuple_arena_for(module, past_full, bsz, q, nf, D, device, dtype):
+    """the module's arena with room for ``q`` more rows behind ``past_full`` (None or ``[2B, nf, N, D]``): the current one
+    when ``past_full`` IS its current view, else a fresh one holding a copy of ``past_full``.  Returns (arena, N); the
+    caller writes rows [N, N + q) and sets ``arena["len"]``."""
     N = 0 if past_full is None else past_full.shape[2]
     arena = getattr(module, "_duo_full_kv_arena", None)
     fits = (
         arena is not None and past_full is not None and arena["len"] == N
         and past_full.data_ptr() == arena["buf"].data_ptr() and past_full.shape[:2] == arena["buf"].shape[:2]
         and past_full.stride() == arena["buf"].stride() and N + q <= arena["buf"].shape[2]
-        and past_full.dtype == new_k.dtype
+        and past_full.dtype == dtype
     )
     if not fits:
         cap = N + q + max(1024, (N + q) // 2)       # 1.5x growth: amortised O(1) copies per appended row
-        buf = torch.empty(2 * bsz, nf, cap, D, device=new_k.device, dtype=new_k.dtype)
+        buf = torch.empty(2 * bsz, nf, cap, D, device=device, dtype=dtype)
         if N > 0:
             buf[:, :, :N].copy_(past_full)
         arena = {"buf": buf, "len": N}
         module._duo_full_kv_arena = arena
-    buf = arena["buf"]
-    buf[:bsz, :, N:N + q].copy_(new_k.transpose(1, 2))
-    buf[bsz:, :, N:N + q].copy_(new_v.transpose(1, 2))
-    arena["len"] = N + q
-    return buf[:, :, :N + q]
+    return arena, N
 
 
 # =============================================================================
@@ -533,6 +736,13 @@ def _tuple_full_kv_append(module, past_full, new_k, new_v):
 def _reorder_layer(module, layer_full_attention_heads):
     """q/k/v rows and o_proj columns permuted so retrieval heads come first (reference llama.py:523-546)."""
     _, _, head_dim, groups = _dims(module)
+    # which original kv head sits at which position now (a later head-parallel split of the ALREADY reordered model —
+    # reference harness order: enabler, then to_device(enable_tp=True), eval/needle/needle_in_haystack.py:195-214 —
+    # has to translate a whole-model pattern given in the original head order): current position -> original head id
+    mask = (torch.as_tensor(layer_full_attention_heads).float() > 0.5).tolist()
+    perm = [h for h, m in enumerate(mask) if m] + [h for h, m in enumerate(mask) if not m]
+    prev = module.__dict__.get("_duo_head_order")
+    module._duo_head_order = [prev[p] for p in perm] if prev else perm
     module.q_proj = reorder_linear_weights(module.q_proj, layer_full_attention_heads, groups * head_dim, "out")
     module.k_proj = reorder_linear_weights(module.k_proj, layer_full_attention_heads, head_dim, "out")
     module.v_proj = reorder_linear_weights(module.v_proj, layer_full_attention_heads, head_dim, "out")

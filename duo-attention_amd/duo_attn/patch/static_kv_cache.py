@@ -130,7 +130,12 @@ class DuoAttentionStaticKVCache:
         if kp.shape[2] > 0:
             # the input may alias the pool (the reference passes views of a fresh cat, never the
             # pool itself); treat it as an independent tensor: pool := compress(input)
-            for b in range(streaming_key_states.shape[0]):
+            nb = streaming_key_states.shape[0]
+            if nb > 1 and hasattr(be, "stream_compress_batched"):      # all batch rows in one launch
+                be.stream_compress_batched(kp, vp, streaming_key_states, streaming_value_states, 0, self.sink_size,
+                                           self.recent_size)
+                nb = 0
+            for b in range(nb):
                 be.stream_compress(kp[b], vp[b], streaming_key_states[b], streaming_value_states[b], 0,
                                    self.sink_size, self.recent_size)
         self.streaming_kv_seq_len_list[layer_idx] = min(incoming, W)
@@ -183,15 +188,21 @@ class DuoAttentionStaticKVCache:
         for i in range(self.num_layers):
             self.kv_seq_len_list[i] = 0
             self.streaming_kv_seq_len_list[i] = 0
-        be = get_backend()
-        if getattr(getattr(be, "_hip", None), "_one_launch_used", False) and self.device.type == "cuda":
+        from .. import backend as _backend_mod
+
+        be = _backend_mod._backend       # (plain bookkeeping: never instantiates the backend / loads the library)
+        if be is not None and getattr(getattr(be, "_hip", None), "_one_launch_used", False) and self.device.type == "cuda":
             # the opt-in single-launch decode step: a sequence boundary is where its arrival tickets get audited
             be._hip.check_decode_tickets(self.device)
 
     def evict_last(self, num_tokens):
+        g = self._decode_graph
+        before = (tuple(self.kv_seq_len_list), tuple(self.streaming_kv_seq_len_list)) if g is not None else None
         for i in range(self.num_layers):
             self.kv_seq_len_list[i] = max(0, self.kv_seq_len_list[i] - num_tokens)
             self.streaming_kv_seq_len_list[i] = max(0, self.streaming_kv_seq_len_list[i] - num_tokens)
+        if g is not None:       # an automatically captured decode step: its device-side counters follow with one launch
+            g.host_evicted(before, num_tokens)
 
     # ---- a prefill chunk processed in row blocks (duo_static_attention_row_block) ------------------
     def begin_chunk(self, layer_idx, chunk_len):
@@ -224,6 +235,8 @@ class DuoAttentionStaticKVCache:
     # The Python ints stay the host's view (planning, capacity checks, every non-captured path).
     device_state = None
     use_device_state = False
+    _decode_graph = None        # the automatically captured decode step of this cache, if any (duo_attn/graph.py)
+    _device_counters = None     # the host counters the device copy is known to equal (None: unknown / never uploaded)
 
     def enable_device_state(self):
         if self.device_state is None:
@@ -236,6 +249,7 @@ class DuoAttentionStaticKVCache:
         rows = [[self.kv_seq_len_list[i], self.streaming_kv_seq_len_list[i], self.kv_seq_len_list[i], 0]
                 for i in range(self.num_layers)]
         self.device_state.copy_(torch.tensor(rows, dtype=torch.int32), non_blocking=False)
+        self._device_counters = (tuple(self.kv_seq_len_list), tuple(self.streaming_kv_seq_len_list))
 
     def device_state_add(self, d_full, d_str, d_pos):
         from ..backend import get_backend
@@ -269,6 +283,19 @@ def duo_attn_static_kv_cache_for_causal_lm_forward(
     return_dict: Optional[bool] = None,
     **kwargs,
 ):
+    # The reference's decode loop (eval/efficiency/benchmark_static.py:96-105) calls this once per token from Python; the
+    # step is ~230 launches.  When the call is exactly that loop's — one token, implicit positions, a static cache on this
+    # GPU, no gradients — it is served by a HIP graph captured on the way (duo_attn/graph.py: auto_decode_step); every
+    # other call, and DUO_AUTO_DECODE_GRAPH=0, runs the body below as it is.
+    from ..graph import auto_decode_eligible, auto_decode_step
+
+    if auto_decode_eligible(self, input_ids, position_ids, past_key_values, inputs_embeds, labels, kwargs):
+        eager = lambda tok: duo_attn_static_kv_cache_for_causal_lm_forward(
+            self, input_ids=tok, past_key_values=past_key_values, use_cache=use_cache, _duo_no_auto_graph=True)
+        logits = auto_decode_step(self, eager, input_ids, past_key_values)
+        if logits is not None:
+            return CausalLMOutputWithPast(loss=None, logits=logits, past_key_values=past_key_values)
+    kwargs.pop("_duo_no_auto_graph", None)
     outputs = self.model(
         input_ids=input_ids,
         attention_mask=attention_mask,

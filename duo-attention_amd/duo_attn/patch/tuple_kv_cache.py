@@ -185,6 +185,13 @@ def tuple_decoder_layer_forward(
     position_embeddings=None,
     **kwargs,
 ):
+    if hidden_states.shape[1] == 1 and past_key_value is not None:
+        # decode step: the token-row linears fused around the attention op, the cache updates in one launch
+        # (duo_attn/patch/_duo.py: duo_tuple_decode_layer_fused; anything it does not cover takes the module sequence below)
+        from ._duo import duo_tuple_decode_layer_fused, tuple_fused_decode_ok
+
+        if tuple_fused_decode_ok(self, hidden_states, past_key_value, position_embeddings, use_cache):
+            return duo_tuple_decode_layer_fused(self, hidden_states, past_key_value, position_embeddings)
     residual = hidden_states
     hidden_states = self.input_layernorm(hidden_states)
     hidden_states, _, present = self.self_attn(

@@ -234,6 +234,11 @@ def shard_model_for_pp(model, device, group=None, layer_costs=None, handoff=None
     the enablers, ``DuoAttentionStaticKVCache`` and the static model forwards all honour ``model._duo_pp``."""
     if getattr(model, "_duo_pp", None) is not None:
         return model._duo_pp
+    if torch.device(device).type == "cuda":
+        # one process per GPU: this rank's launches go to the CURRENT device's stream (duo_attn/_hip.py refuses tensors
+        # of another device) — the reference's single-process accelerate hooks never had to choose; do it here so that
+        # reference-style callers (to_device(model, devices, enable_pp=True) and nothing else) work on every rank
+        torch.cuda.set_device(torch.device(device))
     inner = model.model
     n_layers = len(inner.layers)
     pipe = LayerPipeline(n_layers, group=group, layer_costs=layer_costs)

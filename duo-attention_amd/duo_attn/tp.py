@@ -126,14 +126,19 @@ def shard_model_for_tp(model, full_attention_heads, rank: Optional[int] = None, 
     D = getattr(cfg, "head_dim", None) or cfg.hidden_size // Hq
     G = Hq // Hkv
     heads = np.asarray(full_attention_heads, dtype=float)
-    assign = balanced_head_assignment(heads, tp)
+    # A model that already went through a DuoAttention enabler has its kv heads REORDERED (retrieval heads first, per
+    # layer; `_duo_head_order`: position -> original head id).  The split works on positions; `heads` is in the original
+    # head order, so it is taken through each layer's order first.
+    perms = [list(layer.self_attn.__dict__.get("_duo_head_order") or range(Hkv)) for layer in model.model.layers]
+    cur = np.stack([heads[l][perms[l]] for l in range(len(perms))]) if len(perms) else heads
+    assign = balanced_head_assignment(cur, tp)
     inter = cfg.intermediate_size
     if inter % tp != 0:
         raise ValueError(f"intermediate_size {inter} does not divide over {tp} ranks")
     local = np.zeros((len(assign), Hkv // tp))
     for l, layer in enumerate(model.model.layers):
         kv_ids = assign[l][rank]
-        local[l] = [1.0 if heads[l, h] > 0.5 else 0.0 for h in kv_ids]
+        local[l] = [1.0 if cur[l, h] > 0.5 else 0.0 for h in kv_ids]
         attn = layer.self_attn
         dev = attn.q_proj.weight.device
         kv_rows = torch.tensor([h * D + d for h in kv_ids for d in range(D)], device=dev)
@@ -145,6 +150,12 @@ def shard_model_for_tp(model, full_attention_heads, rank: Optional[int] = None, 
         for name in ("num_heads", "num_key_value_heads", "num_key_value_groups"):
             if hasattr(attn, name) and name != "num_key_value_groups":
                 setattr(attn, name, getattr(attn, name) // tp)
+        if "full_attention_heads" in attn._buffers:
+            # tuple-path patch already applied (enable_duo_attention_eval): the registered pattern follows the heads
+            buf = attn._buffers["full_attention_heads"]
+            attn._buffers["full_attention_heads"] = buf[torch.tensor(kv_ids, device=buf.device)].clone()
+            attn.full_attn_head_mask = None
+        attn.__dict__["_duo_head_order"] = None     # (positions are the rank's local ones from here on)
         mlp = layer.mlp
         cols = torch.arange(rank * inter // tp, (rank + 1) * inter // tp, device=dev)
         mlp.gate_proj = _slice_rows(mlp.gate_proj, cols)
@@ -155,8 +166,10 @@ def shard_model_for_tp(model, full_attention_heads, rank: Optional[int] = None, 
     cfg.num_attention_heads = Hq // tp
     cfg.num_key_value_heads = Hkv // tp
     cfg.intermediate_size = inter // tp
-    # what the TP-aware head accessors (duo_attn.patch.get/set/map_full_attention_heads) need
-    model._duo_tp = {"assign": assign, "rank": rank, "tp": tp, "group": group, "num_kv_heads": Hkv}
+    # what the TP-aware head accessors (duo_attn.patch.get/set/map_full_attention_heads) need.  `assign` indexes the head
+    # order the model had WHEN IT WAS SHARDED (the original order, or an enabler's reordered one: `perm` maps those
+    # positions back to original head ids)
+    model._duo_tp = {"assign": assign, "rank": rank, "tp": tp, "group": group, "num_kv_heads": Hkv, "perm": perms}
     return local
 
 
@@ -175,13 +188,16 @@ def tp_local_rows(model, full_attention_heads):
         return full_attention_heads
     if len(rows) != len(info["assign"]):
         raise ValueError(f"{len(rows)} pattern rows for {len(info['assign'])} layers")
-    return np.stack([rows[l][info["assign"][l][info["rank"]]] for l in range(len(rows))])
+    perm = info.get("perm") or [list(range(info["num_kv_heads"]))] * len(rows)
+    return np.stack([rows[l][[perm[l][c] for c in info["assign"][l][info["rank"]]]] for l in range(len(rows))])
 
 
 def gather_full_attention_heads(model, local_heads):
     """``local_heads``: this rank's per-layer buffers ``[Hkv / tp]`` (rank-local order, retrieval heads first).
-    Returns the whole model's per-layer ``[Hkv]`` tensors in the ORIGINAL kv-head order, identical on every rank —
-    what the reference's TP branch assembles by concatenating its shards (llama.py:601-620)."""
+    Returns the whole model's per-layer ``[Hkv]`` tensors in the head order the model had when it was sharded (the original
+    order; for a model sharded AFTER an enabler, the enabler's reordered one — exactly what the unsharded patched model's
+    buffers hold), identical on every rank — what the reference's TP branch assembles by concatenating its shards
+    (llama.py:601-620)."""
     info = model._duo_tp
     tp, group = info["tp"], info["group"]
     out = []

@@ -159,10 +159,11 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
         if enable_tp:
             # Reference utils.py:206-227 shards with the third-party `tensor_parallel` package inside one process; here it
             # is one process per GPU (launch with torch.distributed.run): this rank keeps Hkv / tp kv heads of every layer
-            # (duo_attn.tp.shard_model_for_tp).  Call it BEFORE enable_*_duo_attention*_eval — the enablers and the KV cache
-            # then take the WHOLE-model pattern and slice it to this rank's heads themselves.  `full_attention_heads`
-            # (optional, the pattern the model will run with) lets the split deal the retrieval heads evenly over the
-            # ranks; without it rank d takes the d-th contiguous block of kv heads, as the reference's split does.
+            # (duo_attn.tp.shard_model_for_tp).  Either order works: BEFORE enable_*_duo_attention*_eval — the enablers and
+            # the KV cache then take the WHOLE-model pattern and slice it to this rank's heads themselves — or AFTER it, as
+            # the reference's NIAH / LongBench harnesses do (the reordered weights and the registered pattern are sharded).
+            # `full_attention_heads` (optional, the pattern in the ORIGINAL head order) lets the split deal the retrieval
+            # heads evenly over the ranks when the model does not carry the pattern itself.
             import torch.distributed as dist
 
             if not dist.is_initialized():
@@ -172,16 +173,29 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
                 )
             if dist.get_world_size() != len(device):
                 raise ValueError(f"{len(device)} devices for {dist.get_world_size()} ranks")
-            if any(hasattr(l.self_attn, "full_attention_heads") for l in model.model.layers):
-                raise ValueError("to_device(enable_tp=True) must run BEFORE the DuoAttention enabler (the shard keeps "
-                                 "whole kv heads in their original order; the enabler then reorders this rank's heads)")
             from .tp import shard_model_for_tp
 
             dev = device[dist.get_rank()]
-            model.to(dev if isinstance(dev, str) else f"cuda:{dev}")
+            dev = dev if isinstance(dev, str) else f"cuda:{dev}"
+            if dev.startswith("cuda"):
+                torch.cuda.set_device(dev)       # launches go to the CURRENT device's stream (duo_attn/_hip.py)
+            model.to(dev)
             cfg = model.config
-            heads = full_attention_heads if full_attention_heads is not None else \
-                np.zeros((cfg.num_hidden_layers, cfg.num_key_value_heads))
+            heads = full_attention_heads
+            if heads is None:
+                # the reference's harness order (eval/needle/needle_in_haystack.py:195-214, eval/LongBench/pred.py:243):
+                # enable_duo_attention_eval FIRST, then to_device(enable_tp=True) — the pattern is on the modules then
+                # (reordered: retrieval heads first), and the split deals THOSE heads evenly.  Unpatched model, no
+                # pattern: rank d takes the d-th contiguous block of kv heads, as the reference's split does.
+                layers = model.model.layers
+                if all("full_attention_heads" in l.self_attn._buffers for l in layers):
+                    Hkv = cfg.num_key_value_heads
+                    heads = np.zeros((len(layers), Hkv))
+                    for li, l in enumerate(layers):
+                        order = l.self_attn.__dict__.get("_duo_head_order") or list(range(Hkv))
+                        heads[li, order] = l.self_attn._buffers["full_attention_heads"].detach().float().cpu().numpy()
+                else:
+                    heads = np.zeros((cfg.num_hidden_layers, cfg.num_key_value_heads))
             shard_model_for_tp(model, heads)
             return model
         if enable_pp:

@@ -36,10 +36,16 @@
  *   duo_silu_mul_bf16         act_fn(gate) * up of HF's LlamaMLP on prefill chunks (<- static_kv_cache.py:528-537)
  *   duo_token_linear_bf16     the torch.nn.Linear / RMSNorm / SiLU*mul / residual-add modules either side of the
  *                             attention op at q_len == 1: llama.py:332-340, :430-432; static_kv_cache.py:482-537
+ *   duo_tuple_decode_prep_bf16  the data movement of the TUPLE-cache forward at q_len == 1 (llama.py:146-306): HF rotary
+ *                             on q / k (:177-184), the torch.cat of the new row onto the retrieval cache (:202-223) as
+ *                             an in-place append, the streaming cache's cat + sink/recent truncation (:273-301)
  *
  * ABI version 2 (round 3): duo_kv_seg gained `batch_stride`, the `_batched` entry points were
  * added, duo_int4_dequantize_f16 / duo_attn_decode_int4_f16 take a `fused` flag.
  * ABI version 3: + duo_token_linear_bf16, duo_silu_mul_bf16 (additions only).
+ * ABI version 4 (round 4, additions only; a v3 caller that zeroed `reserved` is unaffected):
+ *   duo_token_linear_args.reserved became `flags` (DUO_LINEAR_NORM_HF), + duo_tuple_decode_prep_bf16 (the tuple-cache
+ *   decode step), + duo_decode_layer_batched_dev_bf16 (batched decode step with device-side lengths).
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -56,7 +62,7 @@
 extern "C" {
 #endif
 
-#define DUO_ABI_VERSION 3
+#define DUO_ABI_VERSION 4
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
@@ -287,6 +293,14 @@ int duo_decode_layer_dev_bf16(const duo_decode_layer_args *args, const duo_decod
                               void *workspace, int64_t workspace_bytes, void *stream);
 int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t d_full, int32_t d_str,
                          int32_t d_pos, int32_t str_cap, void *stream);
+/* the batched step (duo_decode_layer_batched_bf16) with device-side lengths: every batch row shares the layer's
+ * duo_decode_state (the reference keeps ONE counter per layer, static_kv_cache.py:44-45).  args->pos is the HOST's view
+ * of dev_state->pos at the time of the call (the cache length); batch row b runs at dev_state->pos + (batch->pos[b] -
+ * args->pos) — left-padded batches: a row's offset from the counter is fixed for the life of the sequence, so a captured
+ * launch stays valid.  One launch pair when every row has the same offset, one pair per row otherwise.               */
+int duo_decode_layer_batched_dev_bf16(const duo_decode_layer_args *args, const duo_decode_batch *batch,
+                                      const duo_decode_state *dev_state, void *workspace, int64_t workspace_bytes,
+                                      void *stream);
 
 /* ---- the same step in ONE launch ------------------------------------------------------------------
  * duo_decode_layer_bf16 / _dev_bf16 issue two launches (scan — which also updates the pool of every streaming head it scans with one workgroup — then the merge).  Here both
@@ -434,14 +448,19 @@ int duo_silu_mul_bf16(const void *gate, int64_t gate_row_stride, const void *up,
  *
  *   y[b, n] = sum_k W[n, k] * xn[b, k] + bias[n]  (+ residual[b, n])        b < n_rows <= DUO_TOKEN_LINEAR_MAX_ROWS
  *   xn = x                                   when norm_weight == NULL and x2 == NULL
- *      = rmsnorm(x; norm_weight, norm_eps)   (flashinfer.norm.rmsnorm: fp32, one rounding to bf16)
+ *      = rmsnorm(x; norm_weight, norm_eps)   (flashinfer.norm.rmsnorm: fp32, one rounding to bf16 — the static path's norm,
+ *                                            flashinfer_utils.py:9-26; with DUO_LINEAR_NORM_HF in `flags` the HuggingFace
+ *                                            LlamaRMSNorm / MistralRMSNorm form the TUPLE path keeps: the normalised x is
+ *                                            rounded to bf16 BEFORE the multiplication by the weight, which rounds again)
  *      = silu(x) * x2                        (LlamaMLP's act_fn(gate) * up; silu(x) rounded to bf16 first, as the module does)
  * W: up to three row-major [n, n_in] bf16 blocks (torch.nn.Linear.weight layout) whose outputs are concatenated along n
  * (q | k | v, gate | up); seg[i].n == 0 ends the list.  fp32 accumulation, one rounding to bf16, then the residual add
  * with its own rounding — the values a module-by-module run materialises in bf16 are rounded at the same points.
  * Alignment: x, x2, norm_weight, every W block 16 bytes; strides multiples of 8 elements; n_in a multiple of 8;
- * n_rows * round_up(n_in, 2048) * 2 bytes must fit one CU's LDS (156 KiB).                                              */
+ * n_rows * round_up(n_in, DUO_TOKEN_LINEAR_PAD) * 2 bytes must fit one CU's LDS (156 KiB).                              */
 #define DUO_TOKEN_LINEAR_MAX_ROWS 4
+#define DUO_TOKEN_LINEAR_PAD 2048     /* token rows are staged in LDS padded to a multiple of this many elements */
+#define DUO_LINEAR_NORM_HF 1          /* duo_token_linear_args.flags: RMSNorm prologue in the HuggingFace two-rounding form */
 typedef struct duo_linear_seg {
     const void *w;          /* [n, n_in] bf16, rows `row_stride` elements apart */
     const void *bias;       /* [n] bf16 or NULL */
@@ -458,13 +477,42 @@ typedef struct duo_token_linear_args {
     duo_linear_seg seg[3];
     const void *norm_weight;        /* RMSNorm prologue: [n_in] bf16; else NULL */
     float norm_eps;
-    int32_t reserved;
+    int32_t flags;                  /* DUO_LINEAR_* bits; 0 = ABI v3 behaviour */
     const void *residual;           /* [n_rows, n_total] bf16 added to the rounded product; else NULL */
     int64_t residual_row_stride;
     void *y;                        /* [n_rows, n_total] bf16 */
     int64_t y_row_stride;
 } duo_token_linear_args;
 int duo_token_linear_bf16(const duo_token_linear_args *args, void *stream);
+
+/* ---- the tuple-cache decode step's data movement (one launch, one batch row) --------------------------------------------
+ * Reference llama_duo_attention_forward_one_way_reordered (duo_attn/patch/llama.py:146-306) at q_len == 1, everything
+ * except the two flash_attn_func calls (duo_attn_decode_bf16 does those, over the arena and the OLD streaming cache as
+ * segment A and the rotated new row as segment B) and the projections:
+ *   1. HF rotary (transformers apply_rotary_pos_emb, llama.py:177-184) on q [n_q_heads, 128] and k [n_kv_heads, 128] IN
+ *      PLACE, in the bf16 arithmetic torch performs: x' = bf16(bf16(x * cos) + bf16(rotate_half(x) * sin)), cos / sin the
+ *      [128] bf16 rows model.rotary_emb produced for this position;
+ *   2. retrieval heads (the first n_full kv heads): rotated k row and v row appended at row `full_len` of the arena
+ *      (reference: torch.cat of the whole cache, :202-223) — full_len + 1 <= full_capacity;
+ *   3. streaming heads: a NEW cache tensor = truncate(old ++ new row) (:273-301): all str_len + 1 rows when that is
+ *      <= sink + recent, else the first `sink` old rows, the last recent - 1 old rows, the new row.  Written out of place
+ *      (dst != src): tuples handed to the caller earlier stay intact.  *new_stream_len = rows written.
+ * Strides in elements, multiples of 8; k / v rows kv_head_stride apart; head_dim == 128.                              */
+typedef struct duo_tuple_decode_args {
+    void *q; int64_t q_head_stride; int32_t n_q_heads; int32_t n_kv_heads;
+    void *k; const void *v; int64_t kv_head_stride;
+    const void *cos_row, *sin_row;          /* [128] bf16 each */
+    int32_t n_full; int32_t head_dim;
+    void *full_k, *full_v;                  /* arena: (row t, head h) at base + t*full_token_stride + h*full_head_stride */
+    int64_t full_token_stride, full_head_stride;
+    int32_t full_len, full_capacity;
+    const void *str_k_src, *str_v_src;      /* old streaming cache, str_len rows */
+    int64_t src_token_stride, src_head_stride;
+    void *str_k_dst, *str_v_dst;            /* new streaming cache, min(str_len + 1, sink + recent) rows */
+    int64_t dst_token_stride, dst_head_stride;
+    int32_t str_len, sink, recent, _pad;
+} duo_tuple_decode_args;
+int duo_tuple_decode_prep_bf16(const duo_tuple_decode_args *args, int32_t *new_stream_len, void *stream);
 
 #ifdef __cplusplus
 }

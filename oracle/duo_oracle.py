@@ -23,6 +23,10 @@ What it restates (torch, CPU, fp32 math on the same bf16 inputs):
   q_len == 1             residual adds (duo_attn/patch/static_kv_cache.py:507-546 around llama.py:309-434) — as
                          ``token_linear_ref``: fp64 dot products, every intermediate the modules materialise rounded to
                          the model dtype; pinned by tests/golden/layer_a.npz (the reference's own layer forward)
+  tuple-cache decode     ``tuple_decode_prep_ref``: HF rotary in torch's bf16 arithmetic (transformers
+  step, data movement    apply_rotary_pos_emb as called at llama.py:177-184), the cache ++ new row concatenations and the
+                         sink/recent truncation (llama.py:202-223, :273-301) written with the reference's own torch ops;
+                         ``rmsnorm_hf_ref``: HuggingFace's LlamaRMSNorm.forward (the tuple path keeps HF's norms)
 
 Pinning: the reference has no tests or golden vectors.  The oracle is
 pinned against outputs of the REFERENCE'S OWN CODE run in the build container
@@ -287,7 +291,39 @@ def rmsnorm_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return y.to(x.dtype)
 
 
-def token_linear_ref(x, blocks, norm=None, x2=None, residual=None, exact=False):
+def rmsnorm_hf_ref(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
+    """transformers LlamaRMSNorm / MistralRMSNorm.forward (what the tuple path's decoder layer runs, reference
+    tuple_kv_cache.py:431-490 leaves the norm modules alone): the normalised activations are rounded to the input dtype
+    BEFORE the multiplication by the weight, which rounds again."""
+    xf = x.float()
+    xf = xf * torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)
+    return w * xf.to(x.dtype)
+
+
+def tuple_decode_prep_ref(q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent):
+    """The data movement of llama_duo_attention_forward_one_way_reordered at q_len == 1, one batch row (reference
+    llama.py:177-184 rotary, :202-223 concatenations, :273-301 truncation + K-on-V stacks) with the reference's torch ops.
+    q [Hq, D], k / v [Hkv, D]: q and k are rotated IN PLACE; ``arena`` [2, nf, cap, D] receives the retrieval heads' rows at
+    row ``full_len``; returns the new streaming cache [2, ns, min(n + 1, sink + recent), D] built from ``str_src``
+    [2, ns, n, D] — same contract as the product's ``tuple_decode_prep`` backend call."""
+    def rot(x):                      # transformers rotate_half + apply_rotary_pos_emb, dtype arithmetic of x
+        x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+        return (x * cos_row) + (torch.cat((-x2, x1), dim=-1) * sin_row)
+
+    q.copy_(rot(q))
+    k.copy_(rot(k))
+    if n_full > 0:
+        arena[0, :, full_len].copy_(k[:n_full])
+        arena[1, :, full_len].copy_(v[:n_full])
+    sk = torch.cat([str_src[0].transpose(0, 1), k[n_full:].unsqueeze(0)], dim=0)      # [n + 1, ns, D]
+    sv = torch.cat([str_src[1].transpose(0, 1), v[n_full:].unsqueeze(0)], dim=0)
+    if sk.shape[0] > sink + recent:
+        sk = torch.cat([sk[:sink], sk[sk.shape[0] - recent:]], dim=0)[: sink + recent]
+        sv = torch.cat([sv[:sink], sv[sv.shape[0] - recent:]], dim=0)[: sink + recent]
+    return torch.stack([sk, sv], dim=0).transpose(1, 2).contiguous()
+
+
+def token_linear_ref(x, blocks, norm=None, x2=None, residual=None, exact=False, norm_hf=False):
     """The module sequence either side of the attention op at q_len == 1, written module by module (reference
     llama.py:332-340 q/k/v_proj, :430-432 o_proj; static_kv_cache.py:482-537 norms, MLP, residual adds; HF LlamaMLP
     ``down_proj(act_fn(gate_proj(h)) * up_proj(h))``), every intermediate a bf16 tensor as in the modules:
@@ -297,7 +333,7 @@ def token_linear_ref(x, blocks, norm=None, x2=None, residual=None, exact=False):
     before its rounding (for the tolerance)."""
     dt = x.dtype
     if norm is not None:
-        xn = rmsnorm_ref(x, norm[0], norm[1])
+        xn = (rmsnorm_hf_ref if norm_hf else rmsnorm_ref)(x, norm[0], norm[1])
     elif x2 is not None:
         xn = torch.nn.functional.silu(x.float()).to(dt)          # act_fn output: a bf16 tensor
         xn = (xn.float() * x2.float()).to(dt)                    # times up_proj's output: a bf16 tensor
@@ -387,3 +423,6 @@ class OracleBackend:
 
     def rmsnorm(self, x, weight, eps):
         return rmsnorm_ref(x, weight, eps)
+
+    def tuple_decode_prep(self, q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent):
+        return tuple_decode_prep_ref(q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent)

@@ -214,16 +214,35 @@ def _pp_worker(rank, world, port, mode, q):
                         tok = out.logits[:, -1, :].argmax(-1, keepdim=True)
                         toks.append(int(tok))
             else:
+                # "row_blocks_b2": two prompts as ONE batch through the row-block wavefront (every attention call one
+                # batched launch, duo_static_attention_row_block) — the reference's batch dimension, static_kv_cache.py:60-167
+                B = 2 if mode == "row_blocks_b2" else 1
+                if B == 2:
+                    ids = torch.cat([ids, _ids(PP_PROMPT, 35)], 0)
                 enable_llama_duo_attention_static_kv_cache_eval(model, np.array(PP_HEADS))
                 pl = PipelinedCausalLM(model, PP_HEADS, DEV, handoff="cpu" if world > 1 else None)
-                kv = pl.make_kv_cache(1, PP_PROMPT + PP_NEW + 2, SINK, RECENT)
+                kv = pl.make_kv_cache(B, PP_PROMPT + PP_NEW + 2, SINK, RECENT)
                 logits = pl.prefill(ids, kv, PP_CHUNK, row_block=PP_ROWS)
                 if world > 1:
-                    logits = pl.pp.broadcast_from_last(logits, (1, 1, VOCAB), torch.bfloat16)
+                    logits = pl.pp.broadcast_from_last(logits, (B, 1, VOCAB), torch.bfloat16)
                 tok = logits[:, -1, :].argmax(-1, keepdim=True)
                 out = pl.decode(tok, kv, PP_NEW)
-                toks = [int(t) for t in out[0]]
+                toks = [[int(t) for t in row] for row in out] if B == 2 else [int(t) for t in out[0]]
                 assert kv.kv_seq_len == PP_PROMPT + PP_NEW
+                if B == 2 and world == 1:
+                    # each batch row == that prompt run alone through the same code: pools bit for bit, same greedy tokens
+                    for b in range(2):
+                        solo = pl.make_kv_cache(1, PP_PROMPT + PP_NEW + 2, SINK, RECENT)
+                        lg = pl.prefill(ids[b:b + 1], solo, PP_CHUNK, row_block=PP_ROWS)
+                        assert _rel(lg, logits[b:b + 1]) < 1e-2
+                        st = pl.decode(lg[:, -1, :].argmax(-1, keepdim=True), solo, PP_NEW)
+                        assert [int(t) for t in st[0]] == toks[b], (b, st, toks)
+                        for l in range(len(model.model.layers)):
+                            if kv.full_value_states_list[l].shape[2] == 0:
+                                continue            # (no retrieval head in this layer)
+                            # prefill rows: the same projections (GEMMs over 2 x S rows instead of S: tiling may differ)
+                            assert _rel(kv.full_value_states_list[l][b, :PP_PROMPT],
+                                        solo.full_value_states_list[l][0, :PP_PROMPT]) < 1e-2
         finally:
             backend._set_backend_for_testing(None)
         n_local = len(model.model.layers)
@@ -277,10 +296,10 @@ def test_tp2_on_hip_equals_single_process_hip(fused):
     assert got.shape == want.shape == (1, len(TP_CHUNKS), VOCAB)
     for i in range(len(TP_CHUNKS)):
         r = _rel(torch.from_numpy(got[:, i]), torch.from_numpy(want[:, i]))
-        assert r < 2e-2, (i, r)
+        assert r < 1e-2, (i, r)
 
 
-@pytest.mark.parametrize("world,mode", [(2, "row_blocks"), (3, "row_blocks"), (2, "drop_in")])
+@pytest.mark.parametrize("world,mode", [(2, "row_blocks"), (3, "row_blocks"), (2, "drop_in"), (2, "row_blocks_b2")])
 def test_pipelined_model_on_hip_equals_single_process_hip(world, mode):
     """Layer pipeline on the HIP kernels: `PipelinedCausalLM.prefill(..., row_block=32)` + `decode`, and the reference
     harness's own loop on a `to_device(enable_pp=True)` model — same greedy tokens as ONE process running the same code."""

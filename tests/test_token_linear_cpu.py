@@ -70,9 +70,9 @@ class _FusedOracleBackend:
     def token_linear_fits(self, n_rows, n_in):
         return n_rows <= 4 and n_in % 8 == 0
 
-    def token_linear(self, x, blocks, norm=None, x2=None, residual=None):
+    def token_linear(self, x, blocks, norm=None, x2=None, residual=None, norm_hf=False):
         self.calls += 1
-        return token_linear_ref(x, blocks, norm=norm, x2=x2, residual=residual)
+        return token_linear_ref(x, blocks, norm=norm, x2=x2, residual=residual, norm_hf=norm_hf)
 
 
 def _tiny_bf16(family, seed):

@@ -50,6 +50,19 @@ def _run(model, heads, max_size=64, wrap=None):
     return torch.cat(outs, 1)
 
 
+def _run_tuple(model):
+    """chunked prefill + decode through the tuple cache of a model patched with enable_duo_attention_eval"""
+    ids = torch.randint(0, 97, (1, sum(CHUNKS)), generator=torch.Generator().manual_seed(1))
+    outs, pos, past = [], 0, None
+    with torch.no_grad():
+        for c in CHUNKS:
+            o = model(input_ids=ids[:, pos:pos + c], past_key_values=past, use_cache=True)
+            past = o.past_key_values
+            outs.append(o.logits)
+            pos += c
+    return torch.cat(outs, 1)
+
+
 def _worker(rank, world, port, q, mode="explicit"):
     _paths()
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -81,6 +94,26 @@ def _worker(rank, world, port, q, mode="explicit"):
             out = _run(model, local, wrap=lambda m: _with_fused_layers(m, _duo))
             assert seen["row_parallel"] == 2 * 3 * 2, seen         # 2 decode steps x 3 layers x (o_proj, down_proj)
             assert be.calls == 2 * 3 * 4
+            if rank == 0:
+                q.put(out.numpy())
+            dist.barrier()
+            return
+        if mode == "patched_first":
+            # the reference's harness order (eval/needle/needle_in_haystack.py:195-214, eval/LongBench/pred.py:243): the
+            # DuoAttention enabler FIRST, to_device(enable_tp=True) on the already reordered model second
+            from duo_attn.patch import enable_duo_attention_eval, get_full_attention_heads
+            from duo_attn.utils import to_device
+
+            enable_duo_attention_eval(model, HEADS.copy(), 4, 8)
+            to_device(model, ["cpu"] * world, enable_tp=True)
+            # every rank holds 2 of the 4 kv heads, retrieval heads first, dealt evenly (3 / 1 / 2 retrieval heads per layer)
+            mine = [l.self_attn.full_attention_heads.tolist() for l in model.model.layers]
+            assert [len(r) for r in mine] == [2, 2, 2] and all(r == sorted(r, reverse=True) for r in mine), mine
+            assert [sum(r) for r in mine] == ([2.0, 0.0, 1.0] if rank == 0 else [1.0, 1.0, 1.0]), (rank, mine)     # extras to the least loaded
+            # the gathered pattern is the unsharded patched model's (reordered) one
+            got = torch.stack(get_full_attention_heads(model)).float().numpy()
+            assert np.array_equal(got, -np.sort(-HEADS, axis=1)), got
+            out = _run_tuple(model)
             if rank == 0:
                 q.put(out.numpy())
             dist.barrier()
@@ -165,6 +198,34 @@ def test_to_device_enable_tp_is_a_drop_in(mode):
     q = ctx.Queue()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-4), np.abs(got - want).max()
+
+
+def test_to_device_enable_tp_after_the_enabler_like_the_reference_harnesses():
+    """enable_duo_attention_eval, THEN to_device(enable_tp=True) — the order of the reference's NIAH / LongBench
+    harnesses — shards the already reordered model and reproduces the single-process tuple-path logits"""
+    _paths()
+    from duo_attn import backend
+    from duo_attn.patch import enable_duo_attention_eval
+    from oracle.duo_oracle import OracleBackend
+
+    backend._set_backend_for_testing(OracleBackend(round_p=False))
+    try:
+        m = _tiny()
+        enable_duo_attention_eval(m, HEADS.copy(), 4, 8)
+        want = _run_tuple(m).numpy()
+    finally:
+        backend._set_backend_for_testing(None)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "patched_first")) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)

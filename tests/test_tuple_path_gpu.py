@@ -83,9 +83,7 @@ class Recorder:
     def __getattr__(self, name):
         return getattr(self.inner, name)
 
-    def attention(self, q, out, group, full, stream, scale):
-        self.inner.attention(q, out, group, full, stream, scale)
-
+    def _record(self, q, out, group, full, stream, scale):
         def cp(desc):
             if desc is None or desc[0] <= 0:
                 return None
@@ -94,6 +92,39 @@ class Recorder:
             return n, off, cpu(a), cpu(b)
 
         self.calls.append((q.detach().cpu().clone(), out.detach().cpu().clone(), group, cp(full), cp(stream), scale))
+
+    def attention(self, q, out, group, full, stream, scale):
+        self.inner.attention(q, out, group, full, stream, scale)
+        self._record(q, out, group, full, stream, scale)
+
+    def attention_batched(self, q, out, group, full, stream, scale):
+        """one launch for all batch rows; recorded as one call per row (the row's slice of every segment)"""
+        self.inner.attention_batched(q, out, group, full, stream, scale)
+
+        def row(desc, b):
+            if desc is None:
+                return None
+            n, off, a, bb = desc
+            sel = lambda seg: None if seg is None else (seg[0][b], seg[1][b])
+            return n, off, sel(a), sel(bb)
+
+        for b in range(q.shape[0]):
+            self._record(q[b], out[b], group, row(full, b), row(stream, b), scale)
+
+    def tuple_decode_attention(self, q, out, groups, nf, arena, N, past_stream, k, v, scale):
+        """the fused tuple decode step's attention: the product's stride-described launch runs, and the call is recorded in
+        the segment form (the same segments written as tensor views) so that it is replayed against the oracle like every
+        other one"""
+        from duo_attn.patch._duo import tuple_decode_attention_by_views
+
+        self.inner.tuple_decode_attention(q, out, groups, nf, arena, N, past_stream, k, v, scale)
+        rec = self
+
+        class _Probe:           # receives the descriptors tuple_decode_attention_by_views builds; computes nothing
+            def attention(self, q_, out_, group, full, stream, scale_):
+                rec._record(q_, out_, group, full, stream, scale_)
+
+        tuple_decode_attention_by_views(_Probe(), q, out, groups, nf, arena, N, past_stream, k, v, scale)
 
 
 def check_calls_against_oracle(calls, what):

@@ -75,9 +75,14 @@ def static(ctx, steps, label=""):
             model(input_ids=tok, past_key_values=kv, use_cache=True)
         kv.evict_last(1)
 
-    wall, host = timed_loop(step, steps)
-    print(f"[static{label}] {wall:.3f} ms/token wall, {host:.3f} ms/token host loop ({ctx} ctx, reference loop unchanged)")
-    print(profile(step, 10))
+    from duo_attn import graph
+
+    for auto in (False, True):
+        graph.AUTO_DECODE_GRAPH = auto
+        wall, host = timed_loop(step, steps)
+        print(f"[static{label}, {'auto-captured graph' if auto else 'eager (DUO_AUTO_DECODE_GRAPH=0)'}] {wall:.3f} ms/token wall, "
+              f"{host:.3f} ms/token host loop ({ctx} ctx, reference loop unchanged)")
+        print(profile(step, 10))
     del model, kv
     torch.cuda.empty_cache()
 
