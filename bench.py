@@ -655,6 +655,121 @@ def int4_leg(device, ctx=1048576, reps=5, parity=True, prefill=True):
     return res
 
 
+def _int4_cache(device, counts, max_size, chunk):
+    """DuoAttentionStaticINT4KVCache of the job's head pattern over pools of plausible rows: random nibbles, scales in
+    (0.01, 0.31), zeros ~ N(0, 1) (timing and the scale vote of the decode kernel see ordinary rows, not zeros)"""
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+
+    class _M:
+        def __init__(self):
+            import types
+
+            self.config = types.SimpleNamespace(num_hidden_layers=len(counts), num_attention_heads=HQ,
+                                                num_key_value_heads=HKV, hidden_size=HQ * D)
+            self._p = torch.zeros(1, device=device, dtype=torch.float16)
+
+        def parameters(self):
+            yield self._p
+
+    heads = [[1.0] * nf + [0.0] * (HKV - nf) for nf in counts]
+    cache = DuoAttentionStaticINT4KVCache(_M(), heads, 1, max_size, SINK, RECENT, chunk)
+    for caches in (cache.full_key_caches, cache.full_value_caches, cache.streaming_key_caches, cache.streaming_value_caches):
+        for c in caches:
+            if c.quantized_data.numel():
+                c.quantized_data.random_(0, 256)
+                c.scale_zero[..., 0].uniform_(0.01, 0.31)
+                c.scale_zero[..., 1].normal_(0.0, 1.0)
+    return cache
+
+
+def int4_whole_step(device, counts, ctx=3_300_000, steps=4):
+    """BASELINE configs[4] as written: the decode step of ALL 32 layers (the shipped pattern at 50 %) over INT4 pools at a
+    3.3 M-token context — 128 retrieval kv heads x 3.3 M rows + 128 streaming heads x 385 rows, 136 B of packed K + V per row
+    = 57.4 GB read per generated token (the bf16 pools of the same context would be 216 GB) — through
+    DuoAttentionStaticINT4KVCache.decode_attention (scan + merge launch per layer), HIP events around whole steps."""
+    cache = _int4_cache(device, counts, ctx + 1, 1)
+    W = SINK + RECENT
+    for l in range(len(counts)):
+        cache.kv_seq_len_list[l] = ctx + 1              # (after put(): the new token's row is in the pools)
+        cache.streaming_kv_seq_len_list[l] = W + 1
+    g = torch.Generator(device=device).manual_seed(3)
+    q = torch.randn(1, 1, HQ, D, generator=g, device=device).to(torch.float16)
+    rows = sum(nf * (ctx + 1) + (HKV - nf) * (W + 1) for nf in counts)
+    nbytes = rows * 2 * 68
+
+    def step():
+        for l in range(len(counts)):
+            cache.decode_attention(l, q)
+
+    step()
+    evs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        step()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+    res = {"context": ctx, "layers": len(counts), "retrieval_kv_heads": int(sum(counts)), "packed_bytes_per_token": float(nbytes),
+           "pool_bytes": int(cache.memory_usage), "ms_per_token": t * 1e3, "achieved": nbytes / t / 1e9, "unit": "GB/s",
+           "frac": nbytes / t / HBM_PEAK, "launches_per_token": 2 * len(counts), "rows_per_us": rows / t / 1e6,
+           "bf16_equivalent_GBps": rows * 512 / t / 1e9,
+           "what": "32-layer decode step over INT4 pools, shipped pattern, whole step incl. the merge launches"}
+    del cache
+    torch.cuda.empty_cache()
+    return res
+
+
+def int4_prefill_chunk(device, counts, ctx=131072, chunk=16384, reps=2):
+    """One chunk of the INT4 chunked prefill as the reference runs it (demo/int4_kv.py:261-436 around
+    demo/w8a8kv4_llama.py:226-274), all 32 layers of the pattern: put() quantises the chunk's K / V rows into the pools,
+    get() dequantises the WHOLE pools into fp16 scratch, flash attention over the scratch (the fp16 MFMA prefill kernel),
+    compress() slides the streaming pools.  The LAST chunk of a `ctx`-token prompt (past = ctx - chunk): tokens per second
+    of the attention path at that depth, and the share of the quantise / dequantise passes."""
+    cache = _int4_cache(device, counts, ctx + 8, chunk)
+    past, W = ctx - chunk, SINK + RECENT
+    g = torch.Generator(device=device).manual_seed(4)
+    mk = lambda h: torch.randn(1, chunk, h, D, generator=g, device=device, dtype=torch.float32).to(torch.float16)
+    q, k, v = mk(HQ), mk(HKV), mk(HKV)
+
+    def one_chunk(attend=True):
+        for l in range(len(counts)):
+            cache.kv_seq_len_list[l] = past
+            cache.streaming_kv_seq_len_list[l] = W
+            cache.put(l, k, v, dequantize=False)
+            if attend:
+                cache.prefill_attention(l, q, k, v)
+            else:
+                cache.get(l)
+            cache.compress(l)
+
+    def timed(fn):
+        fn()
+        evs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+
+    t_all = timed(one_chunk)
+    t_data = timed(lambda: one_chunk(attend=False))          # quantise + dequantise + compress alone
+    G = HQ // HKV
+    tri = chunk * (chunk + 1) / 2
+    flops = sum(4 * D * G * (nf * (chunk * past + tri) + (HKV - nf) * (chunk * W + tri)) for nf in counts)
+    res = {"context": ctx, "chunk": chunk, "past": past, "layers": len(counts), "chunk_ms": t_all * 1e3,
+           "tok_s": chunk / t_all, "quantise_dequantise_compress_ms": t_data * 1e3,
+           "attention_TFLOPs": flops / max(t_all - t_data, 1e-9) / 1e12,
+           "what": "put (quantise) + get (dequantise all pools to fp16) + fp16 MFMA prefill + compress, 32 layers, last chunk"}
+    del cache
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_cfg1_end_to_end(n_layers):
     """BASELINE configs[0] end to end on the host: a random-init Llama-2-7B-32K-shape HuggingFace model (MHA 32 heads,
     linear RoPE factor 8), `enable_duo_attention_eval` (the reference's tuple-cache entry point) at 25 % retrieval heads,
@@ -711,14 +826,23 @@ def model_level(args):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     a = m.parse(["--max_length", str(args.ctx), "--prefilling_chunk_size", str(args.chunk), "--prefill_steps", "1",
-                 "--prefill_warmup", "1", "--decode_steps", "50", "--decode_warmup", "10", "--graph", "--also_module_by_module"])
+                 "--prefill_warmup", "1", "--decode_steps", "50", "--decode_warmup", "10", "--graph", "--also_module_by_module",
+                 "--all_decode_modes", "--also_tuple"])
     r = m.run(a, quiet=True)
+    t = r.get("tuple_path") or {}
     return {"prefill_tok_s": r["prefill_tok_s"], "decode_ms_per_token": r["avg_generation_time_ms"],
             "decode_ms_per_token_module_by_module": r.get("avg_generation_time_module_by_module_ms"),
+            # the reference's decode loop (eval/efficiency/benchmark_static.py:96-105) UNCHANGED, as this package runs it by
+            # default (the step behind model(...) is captured on the way and replayed), and with every step issued from Python
+            "decode_ms_per_token_reference_loop": r.get("avg_generation_time_reference_loop_ms"),
+            "decode_ms_per_token_eager": r.get("avg_generation_time_eager_ms"),
+            # the same model through enable_duo_attention_eval (tuple cache: README quick-start, NIAH, LongBench)
+            "tuple_decode_ms_per_token": t.get("avg_generation_time_ms"), "tuple_prefill_tok_s": t.get("prefill_tok_s"),
             "decode_mode": r["decode_mode"], "kv_cache_MB": r["kv_cache_memory_MB"], "sparsity": r["sparsity"],
-            "what": "whole HF Llama-3-8B-shape model, random init (tools/benchmark_static.py --graph): prefill GEMMs are "
-                    "hipBLASLt; the decode step's token-row linears are duo_token_linear_bf16 (module_by_module: the same "
-                    "step through the library GEMMs at M = 1 and separate norm / activation / add kernels)"}
+            "what": "whole HF Llama-3-8B-shape model, random init (tools/benchmark_static.py --graph --all_decode_modes "
+                    "--also_tuple): prefill GEMMs are hipBLASLt; the decode step's token-row linears are duo_token_linear_bf16 "
+                    "(module_by_module: the same step through the library GEMMs at M = 1 and separate norm / activation / "
+                    "add kernels); decode_ms_per_token = explicit graph replay with evict_last inside the graph"}
 
 
 def main():
@@ -902,6 +1026,9 @@ def main():
         try:
             int4 = int4_leg(device)
             d = int4["decode"]
+            if (args.ctx, L) == (131072, 32):
+                int4["whole_step_3p3M"] = int4_whole_step(device, counts)
+                int4["prefill_chunk_pipeline"] = int4_prefill_chunk(device, counts, args.ctx, args.chunk)
             int4["roofline"] = {"kernel": "duo_int4_decode_mfma_kernel", "bound": "hbm", "achieved": d["kernel_GBps"],
                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": d["kernel_GBps"] * 1e9 / HBM_PEAK,
                                 "traffic": traffic.get("duo_int4_decode_mfma_kernel"), "traffic_source": traffic_source,

@@ -117,13 +117,21 @@ def run(args, quiet=False):
     out = prefill()
     pred = out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)
 
+    from duo_attn import graph as duo_graph
+
     def eager_step():
         with torch.no_grad():
             model(input_ids=pred, past_key_values=kv_cache, use_cache=True)
         kv_cache.evict_last(1)
 
-    def decode_fn():
-        if not args.graph:
+    def decode_fn(mode):
+        """"eager": the reference's loop, every step issued from Python (DUO_AUTO_DECODE_GRAPH=0); "loop": the SAME loop as
+        the package runs it by default — after two eager steps the step is captured and replayed behind the unchanged call
+        (duo_attn.graph.auto_decode_step); "graph": the explicit DecodeStepGraph (evict_last inside the graph)"""
+        duo_graph.AUTO_DECODE_GRAPH = mode == "loop"
+        kv_cache._auto_graph = None
+        kv_cache._decode_graph = None
+        if mode != "graph":
             return eager_step
         from duo_attn.graph import DecodeStepGraph
 
@@ -132,11 +140,17 @@ def run(args, quiet=False):
 
         def step():
             with torch.no_grad():
-                return model(input_ids=pred, past_key_values=kv_cache, use_cache=True).logits
+                return model(input_ids=pred, past_key_values=kv_cache, use_cache=True, _duo_no_auto_graph=True).logits
 
         return DecodeStepGraph(kv_cache, step, evict_after=1).replay    # same protocol: one token, then evict_last(1), inside the graph
 
-    gen_latency, gen_memory = bench_func(decode_fn(), args.decode_steps, args.decode_warmup)
+    auto_default = duo_graph.AUTO_DECODE_GRAPH
+    main_mode = "graph" if args.graph else ("loop" if auto_default else "eager")
+    gen_latency, gen_memory = bench_func(decode_fn(main_mode), args.decode_steps, args.decode_warmup)
+    extra = {}
+    for mode in ("eager", "loop"):
+        if getattr(args, "all_decode_modes", False) and mode != main_mode:
+            extra[mode], _ = bench_func(decode_fn(mode), args.decode_steps, args.decode_warmup)
     unfused_latency = None
     if getattr(args, "also_module_by_module", False):
         # the same decode step with the decoder layer run module by module (library GEMMs at M = 1, separate norm /
@@ -146,20 +160,73 @@ def run(args, quiet=False):
         old = _duo._FUSED_DECODE_LAYER
         _duo._FUSED_DECODE_LAYER = False
         try:
-            unfused_latency, _ = bench_func(decode_fn(), args.decode_steps, args.decode_warmup)
+            unfused_latency, _ = bench_func(decode_fn(main_mode), args.decode_steps, args.decode_warmup)
         finally:
             _duo._FUSED_DECODE_LAYER = old
+    duo_graph.AUTO_DECODE_GRAPH = auto_default
     res = {
         "shape": args.shape, "context_length": args.max_length, "sparsity": float(sparsity),
         "prefilling_chunk_size": C, "avg_context_time_ms": ctx_latency, "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3,
         "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
         "peak_context_memory_MB": ctx_memory, "peak_generation_memory_MB": gen_memory,
         "kv_cache_memory_MB": kv_cache.memory_usage / 1024 / 1024,
-        "decode_mode": "hip graph replay" if args.graph else "eager",
+        "decode_mode": {"graph": "hip graph replay (explicit DecodeStepGraph)", "eager": "eager (DUO_AUTO_DECODE_GRAPH=0)",
+                        "loop": "the reference's unchanged loop (auto-captured HIP graph behind model(...))"}[main_mode],
     }
     if unfused_latency is not None:
         res["avg_generation_time_module_by_module_ms"] = unfused_latency
+    if "eager" in extra:
+        res["avg_generation_time_eager_ms"] = extra["eager"]
+    if "loop" in extra:
+        res["avg_generation_time_reference_loop_ms"] = extra["loop"]
     del model, kv_cache
+    torch.cuda.empty_cache()
+    if getattr(args, "also_tuple", False):
+        res["tuple_path"] = run_tuple(args, heads, quiet=quiet)
+    return res
+
+
+def run_tuple(args, heads, quiet=False):
+    """The same protocol through the TUPLE cache (`enable_duo_attention_eval`, the API of the reference's README quick-start,
+    NIAH and LongBench harnesses): chunked prefill with past_key_values tuples handed back and forth, then greedy decode
+    steps (the tuple API has no evict_last: the context grows by one token per step)."""
+    from duo_attn.patch import enable_duo_attention_eval
+    from duo_attn.patch._duo import release_tuple_arena
+
+    model, config, _ = build_model(args.shape, "cuda", args.seed)
+    enable_duo_attention_eval(model, np.array(heads, dtype=float), args.sink_size, args.recent_size)
+    input_ids = torch.randint(0, config.vocab_size, (1, args.max_length - 1), device="cuda")
+    C = args.prefilling_chunk_size
+
+    def prefill():
+        past = None
+        with torch.no_grad():
+            for i in range(0, input_ids.size(1), C):
+                out = model(input_ids=input_ids[:, i:i + C], past_key_values=past, use_cache=True)
+                past = out.past_key_values
+        return out
+
+    def func1():
+        prefill()
+        release_tuple_arena(model)
+
+    ctx_latency, ctx_memory = bench_func(func1, 1, 1)
+    out = prefill()
+    state = {"past": out.past_key_values, "tok": out.logits[:, -1, :].argmax(dim=-1).unsqueeze(1)}
+    del out
+
+    def step():
+        with torch.no_grad():
+            o = model(input_ids=state["tok"], past_key_values=state["past"], use_cache=True)
+        state["past"] = o.past_key_values
+
+    gen_latency, gen_memory = bench_func(step, args.decode_steps, args.decode_warmup)
+    res = {"avg_context_time_ms": ctx_latency, "prefill_tok_s": input_ids.size(1) / ctx_latency * 1e3,
+           "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
+           "peak_context_memory_MB": ctx_memory, "peak_generation_memory_MB": gen_memory,
+           "what": "enable_duo_attention_eval (tuple cache): decode steps in the fused form — token-row linears, one launch for "
+                   "HF rotary + cache updates, split-KV decode over the arena"}
+    del model, state
     torch.cuda.empty_cache()
     return res
 
@@ -342,6 +409,11 @@ def parse(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--graph", action="store_true",
                     help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
+    ap.add_argument("--all_decode_modes", action="store_true",
+                    help="also time the decode loop eagerly (DUO_AUTO_DECODE_GRAPH=0) and as the reference's unchanged loop "
+                         "(auto-captured graph), next to the mode selected")
+    ap.add_argument("--also_tuple", action="store_true",
+                    help="also run the protocol through the tuple cache (enable_duo_attention_eval)")
     ap.add_argument("--also_module_by_module", action="store_true",
                     help="also time the decode step with the decoder layers run module by module (A/B of the fused layer form)")
     ap.add_argument("--pp", action="store_true", help="layer pipeline over the ranks of torch.distributed.run")
