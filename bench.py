@@ -352,7 +352,7 @@ def measure_traffic(args):
         for name, mean, cnt in rows:
             key = "duo_prefill" if (("duo_prefill_w64_kernel" in name or "duo_prefill_kernel" in name) and "f16" not in name) else (
                 "duo_decode_scan_kernel" if ("duo_decode_scan_kernel" in name or "duo_decode_split_kernel" in name) else (
-                    "duo_int4_decode_mfma_kernel" if "duo_int4_decode_mfma_kernel" in name else (
+                    "duo_int4_decode" if ("duo_int4_decode_fold_kernel" in name or "duo_int4_decode_mfma_kernel" in name) else (
                         "duo_token_linear_kernel" if "duo_token_linear_kernel" in name else None)))
             if key:
                 tot, c0 = acc.get(key, (0.0, 0))
@@ -563,14 +563,14 @@ def int4_leg(device, ctx=1048576, reps=5, parity=True, prefill=True):
     rows = nf * (ctx + 1) + ns * (W + 1)
     nbytes = rows * 2 * 68
 
-    def timed(flags):
+    def timed(flags, mode):
         _hip.set_debug_flags(flags)
         try:
             evs = []
             for i in range(reps + 2):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                _hip.attn_decode_int4(q, out, G, full, stream, scale)
+                _hip.attn_decode_int4(q, out, G, full, stream, scale, fused=mode)
                 b.record()
                 if i >= 2:
                     evs.append((a, b))
@@ -579,13 +579,22 @@ def int4_leg(device, ctx=1048576, reps=5, parity=True, prefill=True):
             _hip.set_debug_flags(0)
         return sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
 
-    t_kernel = timed(2)        # debug bit 1: no merge launch -> the events bracket the split kernel alone
-    t_op = timed(0)            # split + merge: the whole attention of the step
+    # mode 0 = the dequantising kernel (bit-exact reference values per element: the default of DuoAttentionStaticINT4KVCache);
+    # mode 2 = the opt-in folded kernel (scale / zero applied to the score tile and to P, folded_decode=True)
+    t_kernel = timed(2, 0)     # debug bit 1: no merge launch -> the events bracket the split kernel alone
+    t_op = timed(0, 0)         # split + merge: the whole attention of the step
+    t_kernel_f, t_op_f = timed(2, 2), timed(0, 2)
     res["decode"] = {"context": ctx, "algorithmic_bytes_per_launch": float(nbytes), "rows": rows,
+                     "kernel": "duo_int4_decode_mfma_kernel",
                      "kernel_ms": t_kernel * 1e3, "op_ms": t_op * 1e3,
                      "kernel_GBps": nbytes / t_kernel / 1e9, "op_GBps": nbytes / t_op / 1e9,
                      "rows_per_us": rows / t_op / 1e6,
-                     "bf16_equivalent_GBps": rows * 512 / t_op / 1e9}
+                     "bf16_equivalent_GBps": rows * 512 / t_op / 1e9,
+                     "folded_opt_in": {"kernel": "duo_int4_decode_fold_kernel", "kernel_ms": t_kernel_f * 1e3,
+                                       "op_ms": t_op_f * 1e3, "kernel_GBps": nbytes / t_kernel_f / 1e9,
+                                       "frac": nbytes / t_kernel_f / HBM_PEAK,
+                                       "note": "no per-element dequantisation in tame tiles; outputs within one fp16 ulp per "
+                                               "dequantised value of the default's, outside its strict bar (DESIGN §3)"}}
     del fkq, fksz, fvq, fvsz, full
     torch.cuda.empty_cache()
     if prefill:
@@ -701,20 +710,26 @@ def int4_whole_step(device, counts, ctx=3_300_000, steps=4):
         for l in range(len(counts)):
             cache.decode_attention(l, q)
 
-    step()
-    evs = []
-    for _ in range(steps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
+    def timed_steps():
         step()
-        b.record()
-        evs.append((a, b))
-    torch.cuda.synchronize()
-    t = sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+        evs = []
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            step()
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in evs) * 1e-3 / len(evs)
+
+    t = timed_steps()                      # the default: every tile dequantised in registers (duo_int4_decode_mfma_kernel)
+    cache.folded_decode = True
+    t_f = timed_steps()                    # opt-in folded decode (duo_int4_decode_fold_kernel)
     res = {"context": ctx, "layers": len(counts), "retrieval_kv_heads": int(sum(counts)), "packed_bytes_per_token": float(nbytes),
            "pool_bytes": int(cache.memory_usage), "ms_per_token": t * 1e3, "achieved": nbytes / t / 1e9, "unit": "GB/s",
            "frac": nbytes / t / HBM_PEAK, "launches_per_token": 2 * len(counts), "rows_per_us": rows / t / 1e6,
            "bf16_equivalent_GBps": rows * 512 / t / 1e9,
+           "folded_opt_in": {"ms_per_token": t_f * 1e3, "achieved": nbytes / t_f / 1e9, "frac": nbytes / t_f / HBM_PEAK},
            "what": "32-layer decode step over INT4 pools, shipped pattern, whole step incl. the merge launches"}
     del cache
     torch.cuda.empty_cache()
@@ -1029,9 +1044,9 @@ def main():
             if (args.ctx, L) == (131072, 32):
                 int4["whole_step_3p3M"] = int4_whole_step(device, counts)
                 int4["prefill_chunk_pipeline"] = int4_prefill_chunk(device, counts, args.ctx, args.chunk)
-            int4["roofline"] = {"kernel": "duo_int4_decode_mfma_kernel", "bound": "hbm", "achieved": d["kernel_GBps"],
+            int4["roofline"] = {"kernel": d["kernel"], "bound": "hbm", "achieved": d["kernel_GBps"],
                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": d["kernel_GBps"] * 1e9 / HBM_PEAK,
-                                "traffic": traffic.get("duo_int4_decode_mfma_kernel"), "traffic_source": traffic_source,
+                                "traffic": traffic.get("duo_int4_decode"), "traffic_source": traffic_source,
                                 "avg_launch_ms": d["kernel_ms"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"]}
         except Exception as e:      # extra information: never at the price of the bench line
             int4 = {"error": f"{type(e).__name__}: {e}"}

@@ -878,6 +878,453 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
     }
 }
 
+// ----------------------------------------------------------------------------- fused decode, FOLDED form
+// duo_int4_decode_mfma_kernel spends most of its issue slots turning nibbles into the fp16 values the reference's
+// dequantiser would have written (13 VALU instructions per 8 values, 61 % of the issue slots at 5 TB/s): it is the one
+// HBM-streaming kernel of this library that the VALU co-limits.  The attention does not need those values — only their sums:
+//
+//   score(k, q)  = sum_d q_d (n_kd s_k + z_k)     = s_k (N . Q^T)[k, q] + z_k Qsum_q          Qsum_q = sum_d q_d
+//   out(q, d)    = sum_k p_k (n_kd s'_k + z'_k)   = ((P s') . N')[q, d] + sum_k p_k z'_k
+//
+// so the matrix cores multiply the RAW nibbles and the per-row scale / zero are applied to the 16 x 16 score tile (8 values
+// per lane) and to P (8 values per lane) instead of to the 2 x 32 x 128 elements of the tile.  A nibble masked out of a packed
+// word IS an fp16 number: bits 0-3 of a half read as the denormal n 2^-24, bits 4-7 as n 2^-20, and v_mfma_f32_16x16x32_f16
+// keeps fp16 denormals exactly (tools/probes/mfma_denorm_probe.hip, profiles/r4_mfma_denormal_probe.txt) — one v_and_b32
+// per two values and no conversion at all.  The 2^-24 / 2^-20 split is per DIM position: on the K side it is folded into Q
+// (the dims under the low-nibble mask are pre-scaled by 16 — exact), on the V side into the output columns (even dims x 2^-4,
+// once, in the epilogue).  (scale, zero) pairs are fetched in the score tile's own layout (lane (r, g) needs the four keys
+// 4g..4g+3 of each half: 16 contiguous bytes when the pool is head-major, which is what this form requires).
+//
+// Arithmetic of a folded tile: exact products of the exact nibbles with fp16 q (resp. fp16-rounded p s'), fp32 accumulation,
+// scale / zero applied in fp32 — the attention over n s + z WITHOUT the dequantiser's fp16 roundings.  The reference's values
+// are those roundings' (hadd(hmul(n, s), z), or the fma): they differ from n s + z by up to an fp16 ulp OF THE VALUE, which is
+// harmless for rows of ordinary magnitude (2^-11 relative: the size of the fp16 rounding of P the reference's flash-attn
+// performs anyway) and is NOT for rows with huge entries — a key row of magnitude ~10^3 carries rounding errors of ~0.5 per
+// element in the reference, which move its score by tenths of a nat, and the reference's output follows those errors.  So a
+// tile is folded only when every row in it is tame — K and V scales below 1 (row range below 15), zero points inside (-8, 8),
+// the largest V scale not below 2^-12 (P' = p s' stays a normal fp16 number) — by a wave vote over values the tile needs
+// anyway; any other tile (and any NaN) takes the EXACT body: the reference's dequantised values in the form P.fused selects,
+// element by element, exactly like duo_int4_decode_mfma_kernel's general path, accumulated into the same state.
+// OPT-IN (fused == 2, + 1 for the fma form in the exact tiles: fused == 3; DuoAttentionStaticINT4KVCache(folded_decode=True)):
+// measured against the oracle's attention over the reference's dequantised values (profiles/r4_int4_fold.md), the folded
+// tiles' outputs sit at 0.3 of the bar that budgets ONE fp16 ulp per dequantised value (2^-10 sum_k p_k |v_k|), but at 1.6-2.5x
+// the strict decode bar the dequantising kernel meets (0.3-0.65 of it) when the reference is the two-rounding form, and at
+// 0.6-1.2x when it is the fma form: the deviation IS the reference's own rounding of n s (+ z), which no arithmetic on sums
+// can reproduce.  The default decode therefore stays the dequantising kernel; this one is for callers who accept "the
+// reference up to its own value rounding" for 9-15 % more tokens per second.
+// Per folded 32-key tile and lane: 16 v_and + 4 shifts to build the operands of each of K and V, 16 + 16 conversions of (s, z),
+// ~70 fp32 operations for the two fix-ups, the vote and the softmax, 8 v_exp, 16 MFMAs — about 70 % of the issue slots of the
+// dequantising form.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void duo_int4_decode_fold_kernel(const Int4DecodeParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15;    // key row inside a 16-key half / q column / dim column
+    const int g = lane >> 4;    // 16-byte quarter of the packed row / k-slot group
+
+    int b = blockIdx.x;
+    const int ci = b < P.nblk_full ? 0 : 1;
+    if (ci) b -= P.nblk_full;
+    const Int4SegDev C = i4_select(P.cls[0], P.cls[1], ci != 0);
+    const int splits = ci ? P.splits[1] : P.splits[0];
+    const int kvh = b / splits;
+    const int split = b - kvh * splits;
+    const int qh0 = C.q_head_offset + kvh * P.group;
+
+    const int L = C.len;
+    const int units = (L + 63) >> 6;
+    const int uq = units / splits, ur = units - uq * splits;
+    const int u0 = split * uq + min(split, ur);
+    const int un = uq + (split < ur ? 1 : 0);
+    const int c0 = u0 << 6;
+    const int c1 = min((u0 + un) << 6, L);
+    const int per_wave = (((c1 - c0 + 3) >> 2) + 31) & ~31;   // quarter of the chunk, whole 32-key tiles
+    const int w0 = __builtin_amdgcn_readfirstlane(c0 + wave * per_wave);
+    const int w1 = __builtin_amdgcn_readfirstlane(min(w0 + per_wave, c1));
+
+    // uniform row bases of this kv head (token stride == 1 row: the launcher guarantees it) + per-lane byte offsets
+    const int64_t head_row = (int64_t)kvh * C.hs + (int64_t)blockIdx.z * C.bs;
+    const uint8_t *kq = C.kq + head_row * 64;
+    const uint8_t *vq = C.vq + head_row * 64;
+    const uint8_t *ksz = reinterpret_cast<const uint8_t *>(C.ksz) + head_row * 4;
+    const uint8_t *vsz = reinterpret_cast<const uint8_t *>(C.vsz) + head_row * 4;
+    const uint32_t qoff0 = (uint32_t)r * 64u + g * 16, qoff1 = qoff0 + 16u * 64u;
+    const uint32_t soff0 = (uint32_t)g * 16u, soff1 = soff0 + 64u;     // (s, z) of keys 4g..4g+3 / 16+4g..16+4g+3
+
+    // Q^T fragments as in duo_int4_decode_mfma_kernel: column r = q head qh0 + r (zero beyond the group), dims 32g + 8kb +
+    // [1,5 | 0,4 | 3,7 | 2,6]; in qB the pairs that meet LOW-nibble values (n 2^-24: dwords .x and .z) are pre-scaled by 16 so
+    // that every product carries the factor 2^-20 (qX: the plain fragments, for exact tiles).  Qsum = sum of the row's 128
+    // values (fp32), times scale*log2(e).
+    f16x8_t qB[4], qX[4];
+    float qs = 0.f;
+    const h2_t sixteen = h2_splat(16.f);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (r < P.group)
+            w = *reinterpret_cast<const u32x4 *>(P.q + (int64_t)blockIdx.z * P.q_bs + (int64_t)(qh0 + r) * P.q_head_stride + 32 * g + 8 * kb);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 t = __half22float2(*reinterpret_cast<const __half2 *>(&ww[i]));
+            qs += t.x + t.y;
+        }
+        u32x4 o;
+        o.x = (w.x >> 16) | (w.z & 0xffff0000u);          // d1, d5   (low nibbles)
+        o.y = (w.x & 0xffffu) | (w.z << 16);              // d0, d4   (high nibbles)
+        o.z = (w.y >> 16) | (w.w & 0xffff0000u);          // d3, d7
+        o.w = (w.y & 0xffffu) | (w.w << 16);              // d2, d6
+        qX[kb] = as_f16x8(o);
+        o.x = as_u32(as_h2(o.x) * sixteen);
+        o.z = as_u32(as_h2(o.z) * sixteen);
+        qB[kb] = as_f16x8(o);
+    }
+    qs += __shfl_xor(qs, 16);
+    qs += __shfl_xor(qs, 32);
+    const float c_ = P.scale_log2e;
+    const float cA = c_ * 1048576.f;      // scale * log2(e) * 2^20: undoes the operands' common factor
+    const float Bq = c_ * qs;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 8192];
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)lds + wave * 8192;
+    uint32_t wa[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wa[j] = lbase + r * 256 + (((4 * g + j) ^ r) << 4);
+    const int kr = 4 * g + (r >> 2);
+    const uint32_t ra = lbase + kr * 256 + ((((r >> 1) & 1) ^ (kr & 15)) << 4) + 8 * (r & 1);
+
+    uint32_t m0, m4, magic;
+    asm volatile("s_mov_b32 %0, 0x000f000f" : "=s"(m0));
+    asm volatile("s_mov_b32 %0, 0x00f000f0" : "=s"(m4));
+    asm volatile("v_mov_b32 %0, 0x64006400" : "=v"(magic));
+
+    // accumulators in the FOLDED scale: O = sum (p s') n 2^-24 (odd-position dims) / 2^-20 (even-position dims); an exact
+    // tile's true-scale contribution is brought to it by 1 / colscale
+    f32x4 O[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) O[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float colscale = (r & 2) ? 1048576.f : 16777216.f;      // this lane's output columns: 2^20 (high-nibble dims) / 2^24
+    const float colinv = 1.f / colscale;
+    float Lp = 0.f, Zp = 0.f;             // this lane's share (its 8 keys per tile) of sum p and sum p z', q column r
+    float m_ref = kNegSentinelI4;
+
+    struct FTile {
+        u32x4 kw[2], vw[2], ks[2], vs[2];
+    };
+    uint32_t qo0 = qoff0, qo1 = qoff1, so0 = soff0, so1 = soff1;
+    typedef __attribute__((address_space(1))) const uint8_t gbyte_t;
+    typedef __attribute__((address_space(1))) const u32x4 gu32x4_t;
+    typedef __attribute__((address_space(1))) const uint32_t gu32_t;
+    auto ubase = [&](const uint8_t *p) __attribute__((always_inline)) {
+        const uint64_t a = (uint64_t)p;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        return (gbyte_t *)(((uint64_t)hi << 32) | lo);
+    };
+    auto load_full = [&](int t, FTile &T) __attribute__((always_inline)) {
+        gbyte_t *kq_t = ubase(kq + (int64_t)t * 64), *vq_t = ubase(vq + (int64_t)t * 64);
+        gbyte_t *ks_t = ubase(ksz + (int64_t)t * 4), *vs_t = ubase(vsz + (int64_t)t * 4);
+        asm volatile("" : "+v"(qo0), "+v"(qo1), "+v"(so0), "+v"(so1));
+        T.kw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + qo0));
+        T.kw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + qo1));
+        T.ks[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(ks_t + so0));
+        T.ks[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(ks_t + so1));
+        T.vw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + qo0));
+        T.vw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + qo1));
+        T.vs[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vs_t + so0));
+        T.vs[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vs_t + so1));
+    };
+    // the partial last tile: rows past the range re-read the last one, element by element for the (s, z) words
+    auto load_tail = [&](int t, FTile &T) __attribute__((always_inline)) {
+        const int last = w1 - 1 - t;
+        gbyte_t *kq_t = ubase(kq + (int64_t)t * 64), *vq_t = ubase(vq + (int64_t)t * 64);
+        gbyte_t *ks_t = ubase(ksz + (int64_t)t * 4), *vs_t = ubase(vsz + (int64_t)t * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t q_ = (uint32_t)min(16 * h + r, last) * 64u + g * 16;
+            T.kw[h] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + q_));
+            T.vw[h] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + q_));
+            uint32_t ke[4], ve[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t s_ = (uint32_t)min(16 * h + 4 * g + e, last) * 4u;
+                ke[e] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(ks_t + s_));
+                ve[e] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(vs_t + s_));
+            }
+            T.ks[h] = u32x4{ke[0], ke[1], ke[2], ke[3]};
+            T.vs[h] = u32x4{ve[0], ve[1], ve[2], ve[3]};
+        }
+    };
+    // 8 nibbles of a packed dword as 4 x half2 MFMA operand words: [e1 e5 | e0 e4 | e3 e7 | e2 e6], low-nibble pairs as
+    // n 2^-24, high-nibble pairs as n 2^-20
+    auto nib = [&](uint32_t w) __attribute__((always_inline)) -> u32x4 {
+        const uint32_t w8 = w >> 8;
+        return u32x4{w & m0, w & m4, w8 & m0, w8 & m4};
+    };
+    auto lo_f = [](uint32_t x) __attribute__((always_inline)) { return __half2float(__ushort_as_half((unsigned short)(x & 0xffffu))); };
+    auto hi_f = [](uint32_t x) __attribute__((always_inline)) { return __half2float(__ushort_as_half((unsigned short)(x >> 16))); };
+
+    auto process = [&](const FTile &T, int t, auto tail_tag) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic
+            m_ref += __uint_as_float((T.kw[0].x ^ T.kw[1].y ^ T.vw[0].z ^ T.vw[1].w ^ T.ks[0].x ^ T.ks[1].y ^ T.vs[0].z ^ T.vs[1].w) & 1u);
+            return;
+        }
+        // ---- (scale, zero) of this lane's 8 keys, and the vote: is every row of the tile tame? -----------------
+        float ksf[8], kzf[8], vsf[8], vzf[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t ks[4] = {T.ks[h].x, T.ks[h].y, T.ks[h].z, T.ks[h].w};
+            const uint32_t vs[4] = {T.vs[h].x, T.vs[h].y, T.vs[h].z, T.vs[h].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ksf[4 * h + e] = lo_f(ks[e]);
+                kzf[4 * h + e] = hi_f(ks[e]);
+                vsf[4 * h + e] = lo_f(vs[e]);
+                vzf[4 * h + e] = hi_f(vs[e]);
+            }
+        }
+        const float vsm = fmaxf(fmaxf(fmaxf(vsf[0], vsf[1]), fmaxf(vsf[2], vsf[3])), fmaxf(fmaxf(vsf[4], vsf[5]), fmaxf(vsf[6], vsf[7])));
+        const float sm = fmaxf(vsm, fmaxf(fmaxf(fmaxf(ksf[0], ksf[1]), fmaxf(ksf[2], ksf[3])), fmaxf(fmaxf(ksf[4], ksf[5]), fmaxf(ksf[6], ksf[7]))));
+        float zm = fmaxf(fmaxf(fmaxf(fabsf(kzf[0]), fabsf(kzf[1])), fmaxf(fabsf(kzf[2]), fabsf(kzf[3]))),
+                         fmaxf(fmaxf(fabsf(kzf[4]), fabsf(kzf[5])), fmaxf(fabsf(kzf[6]), fabsf(kzf[7]))));
+        zm = fmaxf(zm, fmaxf(fmaxf(fmaxf(fabsf(vzf[0]), fabsf(vzf[1])), fmaxf(fabsf(vzf[2]), fabsf(vzf[3]))),
+                             fmaxf(fmaxf(fabsf(vzf[4]), fabsf(vzf[5])), fmaxf(fabsf(vzf[6]), fabsf(vzf[7])))));
+        // (comparisons written so that a NaN fails them)
+        const bool exact = !__all(sm < 1.0f && zm < 8.0f) || !__any(vsm >= 0.000244140625f);
+
+        float sv[8];
+        if (!exact) {
+            // ---- raw S^T = N . Q'^T, then s_k raw + z_k Qsum (log2 domain) ----------------------------
+            f32x4 S[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(nib(kw[kb])), qB[kb], S[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = nib(vw[j]);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[4 * h + e] = fmaf(S[h][e], ksf[4 * h + e] * cA, kzf[4 * h + e] * Bq);
+        } else {
+            // ---- EXACT tile: the reference's dequantised values, element by element (rare) ---------------
+            // (scale, zero) in the ROW layout dq8 wants (lane (r, g): rows r and 16 + r) — re-read, clamped into the range
+            const int last = w1 - 1 - t;
+            uint32_t krow[2], vrow[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t row = (int64_t)t + min(16 * h + r, last);
+                krow[h] = *reinterpret_cast<const uint32_t *>(ksz + row * 4);
+                vrow[h] = *reinterpret_cast<const uint32_t *>(vsz + row * 4);
+            }
+            f32x4 S[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const RowConst R = row_const(krow[h], false);
+                const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const u32x4 kd = P.fused ? dq8<false, true>(kw[kb], R, m0, m4, magic) : dq8<false, false>(kw[kb], R, m0, m4, magic);
+                    S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(kd), qX[kb], S[h], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const RowConst R = row_const(vrow[h], false);
+                const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) =
+                        P.fused ? dq8<false, true>(vw[j], R, m0, m4, magic) : dq8<false, false>(vw[j], R, m0, m4, magic);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sv[4 * h + e] = S[h][e] * c_;
+        }
+        if constexpr (TAIL) {   // keys past the range score -inf
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (t + 16 * h + 4 * g + e >= w1) sv[4 * h + e] = kNegSentinelI4;
+        }
+        const float mx = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+        if (__any(mx > m_ref + 8.f)) {
+            // raise the reference: true running maximum of every q column, accumulators rescaled
+            float tm = fmaxf(mx, __shfl_xor(mx, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float m_new = fmaxf(m_ref, tm);
+            const float alpha = fast_exp2(m_ref - m_new);
+            m_ref = m_new;
+            Lp *= alpha;            // (this lane's q column is r: its own factor)
+            Zp *= alpha;
+            // O rows are q heads 4g + e: fetch their factors from the lanes that own those columns
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = __shfl(alpha, 4 * g + e);
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) O[nb][e] *= a;
+            }
+        }
+        // ---- p; the A operand of P.V: P' = p s' (folded: the V rows' scales ride on P) or P itself (exact) ---------
+        // (carrying P' as two fp16 operands, hi + lo, was built and measured: the error against the reference's values did
+        //  not move — 0.32 of the bar either way — because it is not P' that differs from the reference but the VALUES: the
+        //  reference's hmul rounds n s to fp16, up to 2e-3 absolute for |n s| in [4, 8), and this form does not; the second
+        //  operand cost 6 % of the step, so it is gone.  profiles/r4_int4_fold.md)
+        u32x4 pw;
+        {
+            float ps[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float p = fast_exp2(sv[i] - m_ref);
+                Lp += p;
+                if (!exact) {
+                    Zp = fmaf(p, vzf[i], Zp);
+                    ps[i] = p * vsf[i];
+                } else {
+                    ps[i] = p;
+                }
+            }
+            pw.x = cvt_pk_f16(ps[0], ps[1]);
+            pw.y = cvt_pk_f16(ps[2], ps[3]);
+            pw.z = cvt_pk_f16(ps[4], ps[5]);
+            pw.w = cvt_pk_f16(ps[6], ps[7]);
+        }
+        const f16x8_t pA = as_f16x8(pw);
+        if (exact) {                // the accumulators take this tile in the true scale ...
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) O[nb] = O[nb] * colscale;
+        }
+        // ---- O += P' . N' : transpose reads two dim blocks at a time, one batch ahead of the MFMAs -----
+        u32x2 va[4], vb[4];
+        __builtin_amdgcn_sched_barrier(0);
+#define DUO_I4_TR_BATCH(buf, nb0)                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
+        const uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                     \
+        DUO_I4_TR_READ(buf[2 * i_], a_, 0);                                         \
+        DUO_I4_TR_READ(buf[2 * i_ + 1], a_, 4096);                                  \
+    }
+#define DUO_I4_PV(buf, nb0)                                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                   \
+        const u32x4 w_ = {buf[2 * i_].x, buf[2 * i_].y, buf[2 * i_ + 1].x, buf[2 * i_ + 1].y};           \
+        O[(nb0) + i_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, as_f16x8(w_), O[(nb0) + i_], 0, 0, 0); \
+    }
+#define DUO_I4_WAIT(n) do { asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+        DUO_I4_TR_BATCH(va, 0);
+        DUO_I4_TR_BATCH(vb, 2);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(va, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        DUO_I4_TR_BATCH(va, 4);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(vb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        DUO_I4_TR_BATCH(vb, 6);
+        DUO_I4_WAIT(4);
+        DUO_I4_PV(va, 4);
+        DUO_I4_WAIT(0);
+        DUO_I4_PV(vb, 6);
+#undef DUO_I4_TR_BATCH
+#undef DUO_I4_PV
+#undef DUO_I4_WAIT
+        if (exact) {                // ... and go back to the folded one (exact powers of two both ways)
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb) O[nb] = O[nb] * colinv;
+        }
+    };
+    // Main loop: as duo_int4_decode_mfma_kernel — the next tile's 8 loads are issued, unconditionally, before the current
+    // tile is touched (behind the last full tile the prefetch re-reads it), so the waits stay counted
+    if (w0 < w1) {
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        const int t_full_end = w0 + (((w1 - w0) >> 5) << 5);
+        int t = w0;
+        if (t < t_full_end) {
+            const int t_last = t_full_end - 32;
+            FTile A, B;
+            load_full(t, A);
+            for (;;) {
+                load_full(min(t + 32, t_last), B);
+                __builtin_amdgcn_sched_barrier(0);
+                process(A, t, F_{});
+                t += 32;
+                if (t > t_last) break;
+                load_full(min(t + 32, t_last), A);
+                __builtin_amdgcn_sched_barrier(0);
+                process(B, t, F_{});
+                t += 32;
+                if (t > t_last) break;
+            }
+        }
+        if (t < w1) {
+            FTile X;
+            load_tail(t, X);
+            process(X, t, T_{});
+        }
+    }
+
+    // ---- combine the 4 waves through LDS ------------------------------------------------------
+    Lp += __shfl_xor(Lp, 16);
+    Lp += __shfl_xor(Lp, 32);
+    Zp += __shfl_xor(Zp, 16);
+    Zp += __shfl_xor(Zp, 32);
+    __syncthreads();   // every wave is done with its V tile: the LDS is reused for the partials
+    float *s_acc = reinterpret_cast<float *>(lds);                 // [4 waves][16 q][128 dims]  = 32 KiB
+    __shared__ float s_ml[4][16][3];
+    if (g == 0) {
+        s_ml[wave][r][0] = m_ref;
+        s_ml[wave][r][1] = Lp;
+        s_ml[wave][r][2] = Zp;
+    }
+    // O[nb][e] = (q row 4g + e, LDS column 16 nb + r); LDS column c <-> dim 8 (c >> 3) + perm[c & 7]; columns whose c & 7 is
+    // 2, 3, 6 or 7 hold high-nibble dims (values x 16): undone here together with the operands' 2^-24
+    {
+        const int permv = (0x62734051u >> (4 * (r & 7))) & 15;   // [1,5,0,4,3,7,2,6][r & 7]
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+            const int dim = 16 * nb + 8 * (r >> 3) + permv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_acc[(wave * 16 + 4 * g + e) * DUO_HEAD_DIM + dim] = O[nb][e] * colscale;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < P.group * DUO_HEAD_DIM; idx += 256) {
+        const int q = idx >> 7;
+        const int d = idx & 127;
+        float M = s_ml[0][q][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, s_ml[w][q][0]);
+        float Lsum = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc = fast_exp2(s_ml[w][q][0] - M);
+            Lsum = fmaf(s_ml[w][q][1], sc, Lsum);
+            o = fmaf(s_acc[(w * 16 + q) * DUO_HEAD_DIM + d] + s_ml[w][q][2], sc, o);     // + sum p z': the same for every dim
+        }
+        const int qh = qh0 + q;
+        if (splits == 1) {
+            P.out[(int64_t)blockIdx.z * P.out_bs + (int64_t)qh * P.out_head_stride + d] = __float2half(o / Lsum);
+        } else {
+            const int64_t slot = (int64_t)qh * P.max_splits + split;
+            P.ws_acc[(int64_t)blockIdx.z * P.ws_row_floats + slot * DUO_HEAD_DIM + d] = o;
+            if (d == 0) {
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 0] = M;
+                P.ws_ml[(int64_t)blockIdx.z * P.ws_row_floats + slot * 2 + 1] = Lsum;
+            }
+        }
+    }
+}
+
 struct Int4MergeParams {
     const float *ws_ml, *ws_acc;
     __half *out;
@@ -1079,8 +1526,9 @@ extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_s
     if (!q || !out || group <= 0 || n_batch < 0 || n_batch > 65535) return DUO_EINVAL;
     if (n_batch == 0) return 0;
     if (n_batch > 1 && ((q_batch_stride & 7) || (out_batch_stride & 3))) return DUO_EINVAL;
+    if (fused < 0 || fused > 3) return DUO_EINVAL;
     Int4DecodeParams P;
-    P.fused = fused != 0;
+    P.fused = fused & 1;
     P.q_bs = q_batch_stride;
     P.out_bs = out_batch_stride;
     P.q = (const __half *)q; P.q_head_stride = q_head_stride;
@@ -1133,6 +1581,16 @@ extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_s
             return x == 0 ? 0 : 1;
         }();
         dim3 grid(nblk, 1, n_batch), block(256);
+        // fused == 2: the folded form (no per-element dequantisation) — needs head-major pools (token stride of one row);
+        // pools in another layout, and debug bit 11, take the dequantising kernel in its default (hmul, hadd) form
+        bool folded = fused >= 2 && !(duo_get_debug_flags() & 2048u);
+        for (int c = 0; c < 2; ++c)
+            if (P.cls[c].n_kv_heads > 0 && P.cls[c].ts != 1) folded = false;
+        if (folded) {
+            if (occ == 2) hipLaunchKernelGGL(duo_int4_decode_fold_kernel<2>, grid, block, 0, st, P);
+            else if (occ == 4) hipLaunchKernelGGL(duo_int4_decode_fold_kernel<4>, grid, block, 0, st, P);
+            else hipLaunchKernelGGL(duo_int4_decode_fold_kernel<3>, grid, block, 0, st, P);
+        } else {
 #define DUO_I4_LAUNCH(W_)                                                                                          \
     do {                                                                                                           \
         if (P.fused) {                                                                                             \
@@ -1147,6 +1605,7 @@ extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_s
         else if (occ == 4) DUO_I4_LAUNCH(4);
         else DUO_I4_LAUNCH(3);
 #undef DUO_I4_LAUNCH
+        }
     } else {
         const int gt = (group % 4 == 0) ? 4 : (group % 2 == 0) ? 2 : 1;
         dim3 grid(nblk, group / gt, n_batch), block(256);

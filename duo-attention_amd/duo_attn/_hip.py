@@ -1072,10 +1072,21 @@ def make_int4_pool(kq, ksz, vq, vsz, length: int, q_head_offset: int) -> Optiona
     return p
 
 
+def _int4_mode(fused) -> int:
+    """``fused`` of the INT4 decode entry points: False / 0 = the reference's hmul-then-hadd values, True / 1 = its fma
+    values (both: dequantise in registers, bit-pinned), 2 / "folded" = no per-element dequantisation in tiles whose rows
+    are tame — scale and zero are applied to the score tile and to P (``duo_int4_decode_fold_kernel``: the values n s + z
+    un-rounded); tiles with outlier rows dequantise element by element in the form 0 (mode 2) or 1 (mode 3)"""
+    if fused == "folded":
+        return 2
+    if fused in (2, 3) and not isinstance(fused, bool):
+        return int(fused)           # 3: folded, with the fma form in the tiles that take the exact body
+    return int(bool(fused))
+
+
 def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[Int4Pool],
-                     stream: Optional[Int4Pool], scale: float, fused: bool = False):
-    """q, out [Hq, 128] fp16: decode attention over the packed pools, dequantisation in registers (``fused``: the
-    one-rounding form, as ``int4_dequantize``)."""
+                     stream: Optional[Int4Pool], scale: float, fused=False):
+    """q, out [Hq, 128] fp16: decode attention over the packed pools; ``fused``: see ``_int4_mode``."""
     lib = load_library()
     _require_gpu(q, "q", torch.float16)
     _require_gpu(out, "out", torch.float16)
@@ -1084,12 +1095,12 @@ def attn_decode_int4(q: torch.Tensor, out: torch.Tensor, group: int, full: Optio
     _check(lib.duo_attn_decode_int4_f16(q.data_ptr(), q.stride(0), out.data_ptr(), out.stride(0), int(group),
                                         byref(full) if full is not None else None,
                                         byref(stream) if stream is not None else None, float(scale), q.shape[1],
-                                        int(bool(fused)), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+                                        _int4_mode(fused), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
            "duo_attn_decode_int4_f16")
 
 
 def attn_decode_int4_batched(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[Int4Pool],
-                             stream: Optional[Int4Pool], scale: float, fused: bool = False):
+                             stream: Optional[Int4Pool], scale: float, fused=False):
     """q, out [B, Hq, 128] fp16; pools built from [B, T, h, ...] views: every batch row in one launch pair"""
     lib = load_library()
     _require_gpu(q, "q", torch.float16)
@@ -1100,7 +1111,7 @@ def attn_decode_int4_batched(q: torch.Tensor, out: torch.Tensor, group: int, ful
                                                 out.stride(1), q.shape[0], int(group),
                                                 byref(full) if full is not None else None,
                                                 byref(stream) if stream is not None else None, float(scale), q.shape[2],
-                                                int(bool(fused)), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
+                                                _int4_mode(fused), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
            "duo_attn_decode_int4_batched_f16")
 
 

@@ -39,11 +39,20 @@ class QuantizedCache:
 
 class DuoAttentionStaticINT4KVCache:
     def __init__(self, model, full_attention_heads, batch_size, max_size, sink_size, recent_size,
-                 prefilling_chunk_size, fused_dequant: bool = False):
+                 prefilling_chunk_size, fused_dequant: bool = False, folded_decode: bool = False):
         """``fused_dequant``: dequantise as ONE fma(q, s, z) instead of the source's hmul-then-hadd (two roundings, the
         default here).  Which of the two the reference's own build computes depends on whether its compiler contracts
-        ``__hadd(__hmul(f, s), z)``; both forms are pinned against builds of the reference's kernel."""
+        ``__hadd(__hmul(f, s), z)``; both forms are pinned against builds of the reference's kernel.
+        ``folded_decode`` (opt-in): the single-token attention applies scale and zero to the score tile and to P instead of
+        dequantising every element, in every 32-key tile whose rows are tame (scales < 1, zero points in (-8, 8)): the
+        attention over ``n s + z`` WITHOUT either form's fp16 roundings (``duo_int4_decode_fold_kernel``); tiles with outlier
+        rows dequantise element by element in the ``fused_dequant`` form.  9-15 % faster per token at multi-million-token
+        contexts; its outputs differ from the reference's by the reference's own value rounding — inside the bar that
+        budgets one fp16 ulp per dequantised value, outside the strict decode bar the default meets (DESIGN §3,
+        profiles/r4_int4_fold.md).  Default ``False``: every tile dequantises in registers, bit for bit the values ``get()``
+        would have written to scratch."""
         self.fused_dequant = bool(fused_dequant)
+        self.folded_decode = bool(folded_decode)
         self.batch_size, self.max_size = batch_size, max_size
         self.sink_size, self.recent_size = sink_size, recent_size
         self.prefilling_chunk_size = prefilling_chunk_size
@@ -227,5 +236,6 @@ class DuoAttentionStaticINT4KVCache:
         sk, sv = self.streaming_key_caches[layer_idx], self.streaming_value_caches[layer_idx]
         full = _hip.make_int4_pool(fk.quantized_data, fk.scale_zero, fv.quantized_data, fv.scale_zero, n, 0) if nf else None
         stream = _hip.make_int4_pool(sk.quantized_data, sk.scale_zero, sv.quantized_data, sv.scale_zero, m, nf * G) if ns else None
-        _hip.attn_decode_int4_batched(query_states[:, 0], out[:, 0], G, full, stream, scale, fused=self.fused_dequant)
+        _hip.attn_decode_int4_batched(query_states[:, 0], out[:, 0], G, full, stream, scale,
+                                      fused=(2 + int(self.fused_dequant)) if self.folded_decode else self.fused_dequant)
         return out

@@ -404,8 +404,14 @@ int duo_int4_stream_compress(void *k_q, void *k_sz, void *v_q, void *v_sz,
 /* decode attention (one fp16 query token) straight over the packed pools: dequantisation in
  * registers instead of the reference's dequantise-everything-to-scratch + flash_attn_func
  * (demo/int4_kv.py:373-436, demo/w8a8kv4_llama.py:240-274).  q/out [n_q_heads, 128] fp16.
- * `fused`: the dequantisation form, as duo_int4_dequantize_f16 (the attention then sees exactly the values
- * that function would have written to scratch).                                                      */
+ * `fused`: 0 / 1 = the dequantisation form, as duo_int4_dequantize_f16 (the attention then sees exactly the values
+ * that function would have written to scratch);  2 / 3 = FOLDED (+ form 0 / 1 in the tiles that are not): in every 32-key
+ * tile whose rows are tame (K and V scales < 1, zero points in (-8, 8)) there is no per-element dequantisation — the matrix
+ * cores multiply the raw nibbles, scale and zero are applied to the 16 x 16 score tile and to P (score = s_k (N.Q^T) + z_k
+ * sum_d q_d, out = (P s').N' + sum_k p_k z'_k): the attention over n s + z WITHOUT the dequantiser's fp16 roundings (<= 1
+ * fp16 ulp per element away from either form), ~70 % of the instruction issue of the dequantising kernel; a tile with an
+ * outlier row (where one fp16 ulp of a value is large enough to show in the reference's own output) dequantises element by
+ * element as fused = 0 / 1 does.  Needs head-major pools (token_stride_rows == 1); other layouts run as fused & 1.       */
 int duo_attn_decode_int4_f16(const void *q, int64_t q_head_stride, void *out, int64_t out_head_stride,
                              int32_t group, const duo_int4_pool *full, const duo_int4_pool *stream_cls,
                              float scale, int32_t head_dim, int32_t fused, void *workspace,

@@ -196,7 +196,8 @@ def test_constant_value_rows_give_that_vector_at_128k():
         assert (err <= want.abs() * 2.0 ** -7 + 1e-5).all(), f"S={S_}: max err {err.max():.3e}"
 
 
-def test_cfg5_int4_decode_3m_tokens():
+@pytest.mark.parametrize("mode", [0, 2])
+def test_cfg5_int4_decode_3m_tokens(mode):
     """int4 pools, 3.3M cached tokens, one layer with 2 retrieval + 2 streaming kv heads: against exact fp32
     attention over pools dequantised by the oracle (oracle/int4_oracle.py, pinned to the reference's own
     kernel by tests/test_int4_golden.py; its torch form runs on the device, and a sample of rows is
@@ -228,7 +229,7 @@ def test_cfg5_int4_decode_3m_tokens():
     svq, svsz = pools(ns, W)
     full = _hip.make_int4_pool(fkq, fksz, fvq, fvsz, N, 0)
     stream = _hip.make_int4_pool(skq, sksz, svq, svsz, W, nf * G)
-    _hip.attn_decode_int4(q, out, G, full, stream, scale)
+    _hip.attn_decode_int4(q, out, G, full, stream, scale, fused=mode)       # (mode 2: the folded kernel)
     rows = torch.randint(0, N, (8192,), generator=g, device=DEV)
     sp, ssz = fkq[rows, 0].cpu(), fksz[rows, 0].cpu()
     assert np.array_equal(dequantize_int4_torch(fkq[rows, 0], fksz[rows, 0]).cpu().numpy().view(np.uint16),

@@ -136,10 +136,13 @@ def _ref_attention(q, kd, vd, group, budget=None):
 @pytest.mark.parametrize("group,nf,ns,n_full,n_stream", [(4, 1, 1, 1, 1), (4, 2, 6, 300, 385), (4, 8, 0, 5000, 0),
                                                           (4, 0, 8, 0, 384), (1, 4, 4, 777, 100), (2, 3, 1, 40000, 50)])
 @pytest.mark.parametrize("odd_rows", [False, True])
-def test_fused_int4_decode(group, nf, ns, n_full, n_stream, odd_rows):
+@pytest.mark.parametrize("mode", [0, 2])
+def test_fused_int4_decode(group, nf, ns, n_full, n_stream, odd_rows, mode):
     """odd_rows: a tenth of the rows are scaled by 1e-3 and a few by several hundred, so their quantisation
     scale leaves [2^-10, 64) and the kernel's per-tile vote takes the subtract-multiply-add dequantisation
-    instead of the exact-fma one; both must reproduce the reference's two-rounding values."""
+    instead of the exact-fma one; both must reproduce the reference's two-rounding values.
+    mode 2: the FOLDED kernel (scale / zero applied to the score tile and to P, no per-element dequantisation) — same bar
+    against the same reference values; the odd rows there move the V scales' wave-uniform exponent (scales beyond 2^7)."""
     from duo_attn import _hip
 
     g = torch.Generator().manual_seed(n_full + n_stream)
@@ -173,13 +176,20 @@ def test_fused_int4_decode(group, nf, ns, n_full, n_stream, odd_rows):
                                                     bud[off:off + n_h * group])
         pools[-1]._keep = (kq, ksz, vq, vsz)
     out = torch.full((Hq, 128), float("nan"), dtype=torch.float16, device=DEV)
-    _hip.attn_decode_int4(q.to(DEV), out, group, pools[0], pools[1], 128 ** -0.5)
+    _hip.attn_decode_int4(q.to(DEV), out, group, pools[0], pools[1], 128 ** -0.5, fused=mode)
     o = out.float().cpu()
     assert torch.isfinite(o).all()
     err = (o - ref).abs()
     # 1e-3 relative + one fp16 output ulp + the P-rounding budget (p in fp16: 2^-11 each, 2^-10 allowed)
     tol = 1e-3 * ref.abs() + 2.0 ** -10 * ref.abs() + 2.0 ** -10 * bud + 1e-3 * ref.pow(2).mean().sqrt()
     assert (err <= tol).all(), f"max err {err.max():.3e}"
+    from helpers import PARITY_LOG
+
+    rms = ref.pow(2).mean().sqrt()
+    PARITY_LOG[f"int4 decode mode={mode} g={group} nf={nf} ns={ns} n={n_full}/{n_stream} odd={odd_rows}"] = {
+        "n": int(o.numel()), "max_abs_err": float(err.max()), "rms_err": float((o - ref).pow(2).mean().sqrt()),
+        "rms_ref": float(rms), "rms_err_over_rms_ref": float((o - ref).pow(2).mean().sqrt() / rms),
+        "worst_err_over_elementwise_tol": float((err / tol.clamp_min(1e-30)).max())}
 
 
 @gpu
@@ -365,3 +375,90 @@ def test_int4_cache_batch_rows_equal_single_rows():
                 A, Bc = getattr(both, name)[l], getattr(solo[b], name)[l]
                 assert torch.equal(A.quantized_data[b, :rows], Bc.quantized_data[0, :rows]), (name, l, b)
                 assert torch.equal(A.scale_zero[b, :rows], Bc.scale_zero[0, :rows]), (name, l, b)
+
+
+@gpu
+@pytest.mark.parametrize("case", ["tiny_scales", "huge_scales", "constant_rows", "mixed", "token_major"])
+def test_folded_int4_decode_scale_extremes(case):
+    """the folded kernel keeps P' = p s' 2^-E inside fp16 for ANY scales (wave-uniform exponent E, re-centred by the tile that
+    leaves the window): pools whose V scales are all tiny / all huge / zero (constant rows) / wildly mixed still meet the bar;
+    token-major pools (token_stride_rows != 1) run through the dequantising kernel and agree as well"""
+    from duo_attn import _hip
+
+    g = torch.Generator().manual_seed(len(case))
+    group, n_h, T = 4, 2, 3000
+    q = torch.randn(n_h * group, 128, generator=g).to(torch.float16)
+    k = torch.randn(T, n_h, 128, generator=g)
+    v = torch.randn(T, n_h, 128, generator=g)
+    if case == "tiny_scales":
+        v *= 3e-4                                  # V scales ~1e-4 < 2^-12: outside the folded window from below
+    elif case == "huge_scales":
+        v *= 2000.0
+    elif case == "constant_rows":
+        v[:] = v[:, :, :1]                       # every row constant: scale = 1e-8 -> 0 in fp16, values = zero point
+        v[::7] = torch.randn(len(v[::7]), n_h, 128, generator=g)
+    elif case == "mixed":
+        f = torch.ones(T, n_h, 1)
+        u = torch.rand(T, n_h, 1, generator=g)
+        f[u < 0.3] = 1e-4
+        f[u > 0.9] = 3000.0
+        v *= f
+        k *= 1.0 + 50.0 * (u > 0.97)
+    k, v = k.to(torch.float16), v.to(torch.float16)
+    if case == "token_major":
+        kq = torch.zeros(T + 3, n_h, 64, dtype=torch.uint8, device=DEV)
+        ksz = torch.zeros(T + 3, n_h, 2, dtype=torch.float16, device=DEV)
+        vq, vsz = torch.zeros_like(kq), torch.zeros_like(ksz)
+    else:
+        kq, ksz = _pools(T + 3, n_h)
+        vq, vsz = _pools(T + 3, n_h)
+    _hip.int4_quantize(k.to(DEV), kq, ksz, 0)
+    _hip.int4_quantize(v.to(DEV), vq, vsz, 0)
+    pool = _hip.make_int4_pool(kq, ksz, vq, vsz, T, 0)
+    kd = torch.from_numpy(dequantize_int4_ref(*quantize_int4_ref(k.float().numpy())).astype(np.float32))
+    vd = torch.from_numpy(dequantize_int4_ref(*quantize_int4_ref(v.float().numpy())).astype(np.float32))
+    bud = torch.empty(n_h * group, 128)
+    ref = _ref_attention(q.float(), kd, vd, group, bud)
+    outs = {}
+    for mode in (0, 2):
+        out = torch.full((n_h * group, 128), float("nan"), dtype=torch.float16, device=DEV)
+        _hip.attn_decode_int4(q.to(DEV), out, group, pool, None, 128 ** -0.5, fused=mode)
+        o = out.float().cpu()
+        assert torch.isfinite(o).all(), (case, mode)
+        err = (o - ref).abs()
+        # (+ one fp16 denormal step: the tiny-scale case's outputs sit at the bottom of the fp16 range)
+        tol = 1e-3 * ref.abs() + 2.0 ** -10 * ref.abs() + 2.0 ** -10 * bud + 1e-3 * ref.pow(2).mean().sqrt() + 2.0 ** -24
+        assert (err <= tol).all(), f"{case} mode {mode}: max err {err.max():.3e} (ref rms {ref.pow(2).mean().sqrt():.3e})"
+        outs[mode] = o
+    if case == "token_major":
+        assert torch.equal(outs[0], outs[2])        # the folded form needs head-major pools: this launch ran as mode 0
+
+
+@gpu
+def test_folded_decode_is_opt_in_and_within_the_value_rounding_budget():
+    """DuoAttentionStaticINT4KVCache(folded_decode=True): same pools, decode outputs within one fp16 ulp per dequantised value
+    (2^-10 sum p |v|) of the default (dequantising) decode; the default is the dequantising kernel"""
+    from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
+
+    counts, Hq, Hkv = [1, 3, 0, 4], 16, 4
+    model = ShapeModel(len(counts), Hq, Hkv, 128, device=DEV, dtype=torch.float16)
+    mk = lambda **kw: DuoAttentionStaticINT4KVCache(model, heads_from_counts(counts, Hkv), 1, 700, 16, 48, 200, **kw)
+    a, b = mk(), mk(folded_decode=True)
+    assert a.folded_decode is False and b.folded_decode is True
+    g = torch.Generator().manual_seed(3)
+    for S in (200, 150, 1, 1):
+        for l in range(len(counts)):
+            k = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16).to(DEV)
+            v = torch.randn(1, S, Hkv, 128, generator=g).to(torch.float16).to(DEV)
+            q = torch.randn(1, S, Hq, 128, generator=g).to(torch.float16).to(DEV)
+            for c in (a, b):
+                c.put(l, k, v, dequantize=False)
+            if S == 1:
+                oa, ob = a.decode_attention(l, q).float(), b.decode_attention(l, q).float()
+                _, fv, _, sv = a.get(l)
+                vmax = max(float(t.abs().max()) for t in (fv, sv) if t.numel())
+                err = (oa - ob).abs()
+                assert (err <= 2.0 ** -10 * vmax + 2.0 ** -10 * oa.abs() + 1e-3 * oa.pow(2).mean().sqrt()).all(), float(err.max())
+                assert not torch.equal(oa, ob)           # (it really is the other kernel)
+            for c in (a, b):
+                c.compress(l)
