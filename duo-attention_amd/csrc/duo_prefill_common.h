@@ -226,3 +226,7 @@ __device__ __forceinline__ bf16x8 join_frag(const u32x2 &a, const u32x2 &b) {
 }
 
 }  // namespace
+
+// the round-1 kernel (8 waves x 32 rows), debug / cross-check paths only: duo_prefill_w32_debug.hip
+// (`params`: a PrefillParams — the type has internal linkage, both translation units see the same definition from this header)
+int duo_prefill_w32_launch(const void *params, bool tr, bool f16, int nblk, int n_batch, int dev, hipStream_t st);

@@ -435,7 +435,13 @@ def _mlp_forward(mlp, x):
     if (hasattr(be, "silu_mul") and x.is_cuda and x.dtype == torch.bfloat16
             and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
             and all(hasattr(mlp, n) for n in ("gate_proj", "up_proj", "down_proj"))):
-        return mlp.down_proj(be.silu_mul(mlp.gate_proj(x), mlp.up_proj(x)))
+        g, u = mlp.gate_proj(x), mlp.up_proj(x)
+        # (the kernel moves 16-byte pieces: inner dimension a multiple of 8, unit inner stride, 16-byte aligned rows —
+        #  anything else takes torch's two kernels, same roundings)
+        if (g.shape == u.shape and g.shape[-1] % 8 == 0 and g.dtype == u.dtype == torch.bfloat16 and g.stride(-1) == 1
+                and u.stride(-1) == 1 and g.data_ptr() % 16 == 0 and u.data_ptr() % 16 == 0):
+            return mlp.down_proj(be.silu_mul(g, u))
+        return mlp.down_proj(mlp.act_fn(g) * u)
     return mlp(x)
 
 

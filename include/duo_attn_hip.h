@@ -119,7 +119,8 @@ const char *duo_error_string(int code);
  *        applies);  bit 8: no key-range split of the prefill launch;  bits 12-15: force that many key-range splits
  *        (capped by the workspace and the tile count);  bit 9: decode scan on the long-prologue kernel
  *        (duo_decode_split_kernel) instead of the short-prologue one;  bit 10: prefill in the plain q-tile-major block
- *        order instead of the XCD-aware one.  Measurement / test aids only. */
+ *        order instead of the XCD-aware one;  bit 11: INT4 decode on the dequantising kernel whatever `fused` asks for.
+ *        Measurement / test aids only. */
 void duo_set_debug_flags(uint32_t flags);
 uint32_t duo_get_debug_flags(void);
 

@@ -43,7 +43,8 @@ def test_struct_layout_matches_header(tmp_path):
 
     pairs = {"duo_kv_seg": _hip.KVSeg, "duo_head_class": _hip.HeadClass, "duo_int4_pool": _hip.Int4Pool,
              "duo_decode_layer_args": _hip.DecodeLayerArgs, "duo_decode_batch": _hip.DecodeBatch,
-             "duo_linear_seg": _hip.LinearSeg, "duo_token_linear_args": _hip.TokenLinearArgs}
+             "duo_linear_seg": _hip.LinearSeg, "duo_token_linear_args": _hip.TokenLinearArgs,
+             "duo_tuple_decode_args": _hip.TupleDecodeArgs}
     gcc = shutil.which("gcc")
     assert gcc, "gcc is part of the image"
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void) {"]
@@ -77,6 +78,14 @@ def test_argument_errors_without_gpu():
     a = _hip.TokenLinearArgs()
     assert lib.duo_token_linear_bf16(ctypes.byref(a), None) == -1      # null x / y
     assert _hip.TOKEN_LINEAR_MAX_ROWS == 4
+    # one padding rule for the LDS limit, shared by the header, the kernel and the Python gate
+    hdr = open(HEADER).read()
+    assert int(re.search(r"#define DUO_TOKEN_LINEAR_PAD (\d+)", hdr).group(1)) == _hip.TOKEN_LINEAR_PAD == 2048
+    assert int(re.search(r"#define DUO_LINEAR_NORM_HF (\d+)", hdr).group(1)) == _hip.LINEAR_NORM_HF
+    assert _hip.token_linear_fits(4, 14336) and not _hip.token_linear_fits(4, 20480 + 8) and _hip.token_linear_fits(1, 4096)
+    t = _hip.TupleDecodeArgs()
+    assert lib.duo_tuple_decode_prep_bf16(ctypes.byref(t), None, None) == -2       # head_dim 0: DUO_EHEADDIM
+    assert lib.duo_attn_decode_int4_f16(None, 0, None, 0, 4, None, None, 1.0, 128, 7, None, 0, None) == -1     # bad q / fused
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -250,8 +250,15 @@ def test_decoder_layer_reference_golden_on_the_hip_path(fused):
                 rel = float((o - r).norm() / r.norm())
                 print(f"layer_a step {si} S={S} fused={fused}: rel L2 {rel:.3e}, max diff / rms {float(diff.max()) / rms:.3e}, bit-equal {(diff == 0).float().mean().item():.3f}")
                 assert (diff <= tol).all(), f"step {si} (S={S}, fused={fused}): max diff {diff.max():.3e}, {int((diff > tol).sum())} beyond the bar"
-                assert rel <= 1e-2, (si, rel)
-                fracs.append((diff == 0).float().mean().item())
+                frac = (diff == 0).float().mean().item()
+                if S == 1:
+                    # decode steps: measured BIT-EQUAL to the reference's hidden states; the bar leaves room for a last-bit
+                    # difference of rsqrt / a dot product's summation order only (was rel <= 1e-2, >= 50 % equal)
+                    assert rel <= 1e-3 and frac >= 0.99, (si, rel, frac)
+                else:
+                    # prefill chunks: bf16-P MFMA attention against the fixture's exact-P stub, measured 3.6e-3
+                    assert rel <= 5e-3, (si, rel)
+                fracs.append(frac)
                 pos += S
     finally:
         _duo._FUSED_DECODE_LAYER = old
