@@ -340,7 +340,8 @@ def test_int4_cache_chunked_prefill_attention():
 def test_int4_cache_batch_rows_equal_single_rows():
     """B = 2 through DuoAttentionStaticINT4KVCache (put / chunked prefill attention in ONE batched fp16 launch / decode /
     compress) == each row through its own B = 1 cache: packed pools bit for bit, prefill outputs bit for bit with the
-    key-range split disabled (same tiles), decode outputs bit for bit (per-row launches either way)."""
+    key-range split disabled (same tiles), decode outputs bit for bit (ONE batched launch pair for both rows — the batch row
+    is grid.z of the same kernel, every row with its own partial area — against one launch pair per row)."""
     from duo_attn import _hip
     from duo_attn.int4_kv import DuoAttentionStaticINT4KVCache
 
