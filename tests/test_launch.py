@@ -123,3 +123,22 @@ def test_bench_single_gpu_path_is_unchanged():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert line["n_gpus"] == 1 and line["pipeline"] is None and "starting" not in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["--pp", "--tp"])
+def test_benchmark_static_starts_its_own_ranks(mode):
+    """`python tools/benchmark_static.py --pp|--tp --gpus 2` with no launcher (shared-GPU rehearsal: both ranks on cuda:0, gloo):
+    the reference's benchmark protocol on the sharded random-init model, one JSON result from rank 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DUO_BENCH_DEBUG_SHARED_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "benchmark_static.py"), mode, "--gpus", "2",
+                        "--shape", "mistral-7b-v0.2", "--max_length", "3001", "--prefilling_chunk_size", "1024",
+                        "--prefill_steps", "1", "--prefill_warmup", "0", "--decode_steps", "3", "--decode_warmup", "1"]
+                       + (["--row_block", "512"] if mode == "--pp" else []),
+                       capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "2 ranks (gloo" in res["mode"] and res["prefill_tok_s"] > 0 and res["avg_generation_time_ms"] > 0
+    assert len(res["stages" if mode == "--pp" else "ranks"]) == 2
+    assert "starting 2 ranks" in r.stderr
