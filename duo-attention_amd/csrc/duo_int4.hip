@@ -1555,11 +1555,19 @@ extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_s
     // matrix-core form for GQA groups up to 16 q heads per kv head; debug flag bit 4 (and wider groups)
     // select the scalar-FMA kernel
     const bool mfma = group <= 16 && !(duo_get_debug_flags() & 16u);
-    static const int occ = [] {
-        const char *e = getenv("DUO_INT4_DECODE_WAVES");   // tuning knob: waves per SIMD the kernel is built for
+    // waves per SIMD (= workgroups per CU) the matrix-core kernels are built and launched for.  The dequantising kernel
+    // needs 144 VGPRs, so THREE fit (512 / 3 = 170) without a spill: round 4, same box, kernel alone at 1 M context
+    // 116 -> 106 us, the 32-layer step at 3.3 M 11.49 -> 11.25 ms (round 3 ran two; four spill).  The folded kernel holds two
+    // sets of Q fragments and the tile's (scale, zero) in fp32 — 228 VGPRs — and stays at two.  DUO_INT4_DECODE_WAVES overrides.
+    static const int occ_env = [] {
+        const char *e = getenv("DUO_INT4_DECODE_WAVES");
         const int x = e ? atoi(e) : 0;
-        return (x >= 2 && x <= 4) ? x : 2;
+        return (x >= 2 && x <= 4) ? x : 0;
     }();
+    bool folded = mfma && fused >= 2 && !(duo_get_debug_flags() & 2048u);
+    for (int c = 0; c < 2; ++c)
+        if (P.cls[c].n_kv_heads > 0 && P.cls[c].ts != 1) folded = false;       // the folded form needs head-major pools
+    const int occ = occ_env ? occ_env : (folded ? 2 : 3);
     // one resident round: 256 CUs x (workgroups per CU = waves per SIMD of the kernel in use)
     const int target = std::max(1, 256 * (mfma ? occ : 2) / n_batch);      // one resident round over all batch rows
     i4_choose_splits(P.cls[1].n_kv_heads, P.cls[1].len, ms, P.cls[0].n_kv_heads > 0 ? P.cls[1].n_kv_heads : target, P.splits[1]);
@@ -1581,11 +1589,8 @@ extern "C" int duo_attn_decode_int4_batched_f16(const void *q, int64_t q_batch_s
             return x == 0 ? 0 : 1;
         }();
         dim3 grid(nblk, 1, n_batch), block(256);
-        // fused == 2: the folded form (no per-element dequantisation) — needs head-major pools (token stride of one row);
-        // pools in another layout, and debug bit 11, take the dequantising kernel in its default (hmul, hadd) form
-        bool folded = fused >= 2 && !(duo_get_debug_flags() & 2048u);
-        for (int c = 0; c < 2; ++c)
-            if (P.cls[c].n_kv_heads > 0 && P.cls[c].ts != 1) folded = false;
+        // fused >= 2: the folded form (no per-element dequantisation; `folded` above) — pools in another layout, and debug
+        // bit 11, take the dequantising kernel in the (fused & 1) form
         if (folded) {
             if (occ == 2) hipLaunchKernelGGL(duo_int4_decode_fold_kernel<2>, grid, block, 0, st, P);
             else if (occ == 4) hipLaunchKernelGGL(duo_int4_decode_fold_kernel<4>, grid, block, 0, st, P);
