@@ -1,4 +1,5 @@
-// The tuple-cache decode step's data movement (gfx950): duo_tuple_decode_prep_bf16.
+// The tuple-cache path's own small kernels (gfx950): duo_tuple_decode_prep_bf16 (the decode step's data movement),
+// duo_rope_hf_inplace_bf16 (HF rotary on prefill chunks), duo_rmsnorm_hf_bf16 (HF's two-rounding RMSNorm).
 //
 // Reference: llama_duo_attention_forward_one_way_reordered, duo_attn/patch/llama.py:146-306, at q_len == 1.  Between the
 // projections and the two flash_attn_func calls the reference issues ~20 small torch kernels per layer and token: the HF
@@ -113,7 +114,118 @@ __global__ __launch_bounds__(256) void duo_tuple_decode_prep_kernel(const TupleP
     }
 }
 
+// ---- HF rotary on whole chunks (the tuple forward's prefill calls, llama.py:177-184): every (token, head) row of q and k in
+//      place, cos / sin rows [n_tokens, 128] bf16 as model.rotary_emb hands them over; torch's bf16 arithmetic as above.
+//      64 threads per token: c = tid & 7 owns dims [8c, 8c+8) and [64+8c, 64+8c+8), hs = (tid >> 3) & 7 strides over the heads.
+struct RopeHfParams {
+    bf16_t *q, *k;
+    int64_t q_ts, q_hs, k_ts, k_hs;
+    const bf16_t *cos_rows, *sin_rows;
+    int64_t cs_ts;
+    int32_t n_q, n_kv, n_tokens;
+};
+
+__global__ __launch_bounds__(256) void duo_rope_hf_kernel(const RopeHfParams P) {
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= P.n_tokens) return;
+    const int c = threadIdx.x & 7, hs = (threadIdx.x >> 3) & 7;
+    const bf16_t *cr = P.cos_rows + (int64_t)tok * P.cs_ts, *sr = P.sin_rows + (int64_t)tok * P.cs_ts;
+    const u32x4 c_lo = *reinterpret_cast<const u32x4 *>(cr + c * 8), c_hi = *reinterpret_cast<const u32x4 *>(cr + 64 + c * 8);
+    const u32x4 s_lo = *reinterpret_cast<const u32x4 *>(sr + c * 8), s_hi = *reinterpret_cast<const u32x4 *>(sr + 64 + c * 8);
+    const uint32_t cl[4] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w}, ch[4] = {c_hi.x, c_hi.y, c_hi.z, c_hi.w};
+    const uint32_t sl[4] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w}, sh[4] = {s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+    auto rot = [](float x, float cosv, float partner, float sinv) {      // bf16(bf16(x cos) + bf16(partner sin))
+        return bf16r(bf16r(x * cosv) + bf16r(partner * sinv));
+    };
+    const int n_heads = P.n_q + P.n_kv;
+    for (int h = hs; h < n_heads; h += 8) {
+        bf16_t *row = h < P.n_q ? P.q + (int64_t)tok * P.q_ts + (int64_t)h * P.q_hs
+                                : P.k + (int64_t)tok * P.k_ts + (int64_t)(h - P.n_q) * P.k_hs;
+        u32x4 *plo = reinterpret_cast<u32x4 *>(row + c * 8), *phi = reinterpret_cast<u32x4 *>(row + 64 + c * 8);
+        const u32x4 lo = *plo, hi = *phi;
+        const uint32_t lw[4] = {lo.x, lo.y, lo.z, lo.w}, hw[4] = {hi.x, hi.y, hi.z, hi.w};
+        uint32_t ol[4], oh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // first half: x1 cos - x2 sin (rotate_half = cat(-x2, x1)); second half: x2 cos + x1 sin
+            const float a0 = rot(bf16_lo(lw[e]), bf16_lo(cl[e]), -bf16_lo(hw[e]), bf16_lo(sl[e]));
+            const float a1 = rot(bf16_hi(lw[e]), bf16_hi(cl[e]), -bf16_hi(hw[e]), bf16_hi(sl[e]));
+            const float b0 = rot(bf16_lo(hw[e]), bf16_lo(ch[e]), bf16_lo(lw[e]), bf16_lo(sh[e]));
+            const float b1 = rot(bf16_hi(hw[e]), bf16_hi(ch[e]), bf16_hi(lw[e]), bf16_hi(sh[e]));
+            ol[e] = (__float_as_uint(a0) >> 16) | (__float_as_uint(a1) & 0xffff0000u);
+            oh[e] = (__float_as_uint(b0) >> 16) | (__float_as_uint(b1) & 0xffff0000u);
+        }
+        *plo = u32x4{ol[0], ol[1], ol[2], ol[3]};
+        *phi = u32x4{oh[0], oh[1], oh[2], oh[3]};
+    }
+}
+
+// ---- HuggingFace's LlamaRMSNorm / MistralRMSNorm.forward on [rows, hidden] bf16 (the tuple path keeps HF's norm modules):
+//      y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) — the normalised activations are rounded to bf16 BEFORE the weight
+//      multiply (duo_rmsnorm_kernel is flashinfer's one-rounding form).  One workgroup per row, fp32 statistics.
+__global__ __launch_bounds__(256) void duo_rmsnorm_hf_kernel(const bf16_t *x, const bf16_t *w, bf16_t *y, int hidden, float eps) {
+    const int64_t row = blockIdx.x;
+    const bf16_t *xr = x + row * hidden;
+    bf16_t *yr = y + row * hidden;
+    const int nchunk = hidden >> 3;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(xr + c * 8);
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ss = fmaf(bf16_lo(vw[e]), bf16_lo(vw[e]), ss);
+            ss = fmaf(bf16_hi(vw[e]), bf16_hi(vw[e]), ss);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float rs = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)hidden + eps);
+    for (int c = threadIdx.x; c < nchunk; c += 256) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(xr + c * 8), g = *reinterpret_cast<const u32x4 *>(w + c * 8);
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w}, gw[4] = {g.x, g.y, g.z, g.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = bf16r(bf16r(bf16_lo(vw[e]) * rs) * bf16_lo(gw[e]));
+            const float b = bf16r(bf16r(bf16_hi(vw[e]) * rs) * bf16_hi(gw[e]));
+            o[e] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+        }
+        *reinterpret_cast<u32x4 *>(yr + c * 8) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
 }  // namespace
+
+extern "C" int duo_rope_hf_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride, int32_t n_q_heads, void *k,
+                                        int64_t k_token_stride, int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                                        const void *cos_rows, const void *sin_rows, int64_t cos_sin_token_stride,
+                                        int32_t head_dim, void *stream) {
+    if (head_dim != DUO_HEAD_DIM) return DUO_EHEADDIM;
+    if (n_tokens <= 0 || n_q_heads + n_kv_heads <= 0) return 0;
+    if ((n_q_heads > 0 && !q) || (n_kv_heads > 0 && !k) || !cos_rows || !sin_rows || n_q_heads < 0 || n_kv_heads < 0) return DUO_EINVAL;
+    if (((q_token_stride | q_head_stride | k_token_stride | k_head_stride | cos_sin_token_stride) & 7) != 0) return DUO_EINVAL;
+    if ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)cos_rows | (uintptr_t)sin_rows) & 15) != 0) return DUO_EINVAL;
+    RopeHfParams P{(bf16_t *)q, (bf16_t *)k, q_token_stride, q_head_stride, k_token_stride, k_head_stride,
+                   (const bf16_t *)cos_rows, (const bf16_t *)sin_rows, cos_sin_token_stride, n_q_heads, n_kv_heads, n_tokens};
+    hipLaunchKernelGGL(duo_rope_hf_kernel, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, P);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int duo_rmsnorm_hf_bf16(const void *x, const void *w, void *y, int64_t n_rows, int32_t hidden, float eps,
+                                   void *stream) {
+    if (n_rows <= 0) return 0;
+    if (!x || !w || !y || hidden <= 0 || (hidden & 7) || n_rows > 0x7fffffffll) return DUO_EINVAL;
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) != 0) return DUO_EINVAL;
+    hipLaunchKernelGGL(duo_rmsnorm_hf_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t *)x,
+                       (const bf16_t *)w, (bf16_t *)y, hidden, eps);
+    DUO_HIP_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int duo_tuple_decode_prep_bf16(const duo_tuple_decode_args *a, int32_t *new_stream_len, void *stream) {
     if (!a) return DUO_EINVAL;

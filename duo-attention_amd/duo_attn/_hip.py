@@ -171,6 +171,12 @@ _SIGNATURES = {
         ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(DecodeBatch), c_void_p, c_void_p, c_int64, c_void_p],
     ),
     "duo_tuple_decode_prep_bf16": (ctypes.c_int, [POINTER(TupleDecodeArgs), POINTER(c_int32), c_void_p]),
+    "duo_rope_hf_inplace_bf16": (
+        ctypes.c_int,
+        [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64,
+         c_int32, c_void_p],
+    ),
+    "duo_rmsnorm_hf_bf16": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "duo_attn_prefill_bf16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, POINTER(HeadClass),
@@ -821,6 +827,34 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
         "duo_rmsnorm_bf16",
     )
     return y.view(x.shape)
+
+
+def rmsnorm_hf(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """transformers LlamaRMSNorm / MistralRMSNorm.forward on [..., hidden] bf16 in one pass: the normalised activations are
+    rounded to bf16 before the weight multiply (two roundings; ``rmsnorm`` is flashinfer's one-rounding form)."""
+    lib = load_library()
+    _require_gpu_bf16(x, "x")
+    _require_gpu_bf16(weight, "weight")
+    x2 = x.contiguous().view(-1, x.shape[-1])
+    w = weight if weight.is_contiguous() else weight.contiguous()
+    y = torch.empty_like(x2)
+    _check(lib.duo_rmsnorm_hf_bf16(x2.data_ptr(), w.data_ptr(), y.data_ptr(), x2.shape[0], x2.shape[1], float(eps),
+                                   _stream_ptr()), "duo_rmsnorm_hf_bf16")
+    return y.view(x.shape)
+
+
+def rope_hf_inplace(q: torch.Tensor, k: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> None:
+    """transformers ``apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)`` IN PLACE on q [S, Hq, D] and k [S, Hkv, D]
+    (views, D contiguous); cos / sin [S, D] bf16 — the rows ``model.rotary_emb`` computed for these positions.  torch's bf16
+    arithmetic (each product and the sum rounded to bf16): bit-equal to the six elementwise kernels it replaces."""
+    lib = load_library()
+    for t, n in ((q, "q"), (k, "k"), (cos, "cos"), (sin, "sin")):
+        _require_gpu_bf16(t, n)
+    S, D = q.shape[0], q.shape[2]
+    assert k.shape[0] == S and cos.shape == (S, D) and sin.shape == (S, D) and cos.stride(0) == sin.stride(0)
+    _check(lib.duo_rope_hf_inplace_bf16(q.data_ptr(), q.stride(0), q.stride(1), q.shape[1], k.data_ptr(), k.stride(0),
+                                        k.stride(1), k.shape[1], S, cos.data_ptr(), sin.data_ptr(), cos.stride(0), D,
+                                        _stream_ptr()), "duo_rope_hf_inplace_bf16")
 
 
 def silu_mul(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:

@@ -113,6 +113,13 @@ class HipBackend:
     def tuple_decode_prep(self, q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent):
         return self._hip.tuple_decode_prep(q, k, v, cos_row, sin_row, n_full, arena, full_len, str_src, sink, recent)
 
+    # -- the tuple path on prefill chunks: HF rotary (llama.py:177-184) and HF's *RMSNorm.forward as single passes
+    def rope_hf_inplace(self, q, k, cos, sin):
+        self._hip.rope_hf_inplace(q, k, cos, sin)
+
+    def rmsnorm_hf(self, x, weight, eps: float):
+        return self._hip.rmsnorm_hf(x, weight, eps)
+
     # -- ... and its two flash_attn_func calls (llama.py:225-262) over the tuple format, segments described by strides
     #    (same kernel as `attention` at q_len == 1; no tensor views on the host)
     def tuple_decode_attention(self, q, out, group, n_full, arena, full_len, str_src, k, v, scale):

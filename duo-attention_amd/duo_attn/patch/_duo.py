@@ -26,7 +26,7 @@ import torch
 from ..backend import get_backend
 from .flashinfer_utils import apply_rope_inplace, enable_flashinfer_rmsnorm
 from .static_kv_cache import DuoAttentionStaticKVCache, enable_duo_attention_static_kv_cache
-from .tuple_kv_cache import enable_tuple_kv_cache_for_model, hf_apply_rotary_pos_emb
+from .tuple_kv_cache import enable_tuple_kv_cache_for_model, hf_apply_rotary_pos_emb, tuple_rotary
 from .utils import reorder_full_attn_heads, reorder_linear_weights
 
 
@@ -587,7 +587,7 @@ def duo_attention_forward_one_way_reordered(
 
     # HF rotary, as the reference's tuple path (:177-184)
     cos, sin = position_embeddings
-    query_states, key_states = hf_apply_rotary_pos_emb(query_states, key_states, cos, sin, unsqueeze_dim=2)
+    query_states, key_states = tuple_rotary(query_states, key_states, cos, sin)
 
     if not hasattr(self, "full_attn_head_mask") or self.full_attn_head_mask is None:
         _tuple_head_split(self, num_heads, num_kv, groups)

@@ -40,6 +40,36 @@ def hf_apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=1):
     return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
 
 
+def tuple_rotary(q, k, cos, sin):
+    """the tuple forwards' rotary call (reference llama.py:177-184: ``apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)``)
+    on q [B, S, Hq, D] / k [B, S, Hkv, D] fresh from the projections: ONE in-place pass per batch row on the GPU
+    (``duo_rope_hf_inplace_bf16``, bit-equal to the torch sequence), the torch sequence itself anywhere else"""
+    be = get_backend()
+    if (hasattr(be, "rope_hf_inplace") and q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
+            and cos.dtype == torch.bfloat16 and cos.dim() == 3 and q.shape[-1] == 128 and q.stride(-1) == 1 and k.stride(-1) == 1
+            and cos.shape[0] in (1, q.shape[0]) and cos.is_contiguous() and sin.is_contiguous()
+            and not (q.requires_grad or k.requires_grad)):
+        for b in range(q.shape[0]):
+            cb = cos[b if cos.shape[0] > 1 else 0]
+            sb = sin[b if sin.shape[0] > 1 else 0]
+            be.rope_hf_inplace(q[b], k[b], cb, sb)
+        return q, k
+    return hf_apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)
+
+
+def _hf_norm(norm, x):
+    """``norm(x)`` for a HuggingFace *RMSNorm module that still runs its own forward: one pass on the GPU
+    (``duo_rmsnorm_hf_bf16``: the module's two-rounding arithmetic), the module itself anywhere else"""
+    be = get_backend()
+    if (hasattr(be, "rmsnorm_hf") and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
+            and not x.requires_grad):
+        from ._duo import _norm_form
+
+        if _norm_form(norm) == "hf":
+            return be.rmsnorm_hf(x, norm.weight, norm.variance_epsilon)
+    return norm(x)
+
+
 def _past_length(past_key_values) -> int:
     if past_key_values is None:
         return 0
@@ -71,7 +101,7 @@ def tuple_full_attention_forward(
     k = self.k_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
     v = self.v_proj(hidden_states).view(bsz, q_len, num_kv, head_dim)
     cos, sin = position_embeddings
-    q, k = hf_apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)
+    q, k = tuple_rotary(q, k, cos, sin)
 
     be = get_backend()
     out = torch.empty_like(q)
@@ -192,8 +222,12 @@ def tuple_decoder_layer_forward(
 
         if tuple_fused_decode_ok(self, hidden_states, past_key_value, position_embeddings, use_cache):
             return duo_tuple_decode_layer_fused(self, hidden_states, past_key_value, position_embeddings)
+    # (chunks: HF's norm arithmetic and the SwiGLU activation product as single passes on the GPU — `_hf_norm`,
+    #  static_kv_cache._mlp_forward; the modules themselves wherever those do not apply)
+    from .static_kv_cache import _mlp_forward
+
     residual = hidden_states
-    hidden_states = self.input_layernorm(hidden_states)
+    hidden_states = _hf_norm(self.input_layernorm, hidden_states)
     hidden_states, _, present = self.self_attn(
         hidden_states=hidden_states,
         position_ids=position_ids,
@@ -203,8 +237,8 @@ def tuple_decoder_layer_forward(
     )
     hidden_states = residual + hidden_states
     residual = hidden_states
-    hidden_states = self.post_attention_layernorm(hidden_states)
-    hidden_states = self.mlp(hidden_states)
+    hidden_states = _hf_norm(self.post_attention_layernorm, hidden_states)
+    hidden_states = _mlp_forward(self.mlp, hidden_states)
     hidden_states = residual + hidden_states
     return hidden_states, present
 

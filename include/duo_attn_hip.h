@@ -45,7 +45,8 @@
  * ABI version 3: + duo_token_linear_bf16, duo_silu_mul_bf16 (additions only).
  * ABI version 4 (round 4, additions only; a v3 caller that zeroed `reserved` is unaffected):
  *   duo_token_linear_args.reserved became `flags` (DUO_LINEAR_NORM_HF), + duo_tuple_decode_prep_bf16 (the tuple-cache
- *   decode step), + duo_decode_layer_batched_dev_bf16 (batched decode step with device-side lengths).
+ *   decode step), + duo_rope_hf_inplace_bf16 / duo_rmsnorm_hf_bf16 (its prefill chunks), + duo_decode_layer_batched_dev_bf16
+ *   (batched decode step with device-side lengths).
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -520,6 +521,20 @@ typedef struct duo_tuple_decode_args {
     int32_t str_len, sink, recent, _pad;
 } duo_tuple_decode_args;
 int duo_tuple_decode_prep_bf16(const duo_tuple_decode_args *args, int32_t *new_stream_len, void *stream);
+
+/* ---- the tuple-cache path on prefill chunks: HF rotary and HF RMSNorm as single passes ---------------------------------
+ * duo_rope_hf_inplace_bf16: transformers apply_rotary_pos_emb as the tuple forward calls it (llama.py:177-184, unsqueeze_dim = 2)
+ * on q [n_tokens, n_q_heads, 128] and k [n_tokens, n_kv_heads, 128] IN PLACE, cos / sin = the [n_tokens, 128] bf16 rows of
+ * model.rotary_emb (rows cos_sin_token_stride elements apart), in torch's bf16 arithmetic — x' = bf16(bf16(x * cos) +
+ * bf16(rotate_half(x) * sin)): bit-equal to the six torch kernels it replaces.
+ * duo_rmsnorm_hf_bf16: LlamaRMSNorm / MistralRMSNorm.forward (the tuple path leaves HF's norm modules in place, reference
+ * tuple_kv_cache.py:431-490): y = bf16(w * bf16(x * rsqrt(mean(x^2) + eps))) — two roundings, where duo_rmsnorm_bf16
+ * (flashinfer's form, the static path's) has one.  Strides multiples of 8 elements, 16-byte aligned bases, hidden % 8 == 0.  */
+int duo_rope_hf_inplace_bf16(void *q, int64_t q_token_stride, int64_t q_head_stride, int32_t n_q_heads, void *k,
+                             int64_t k_token_stride, int64_t k_head_stride, int32_t n_kv_heads, int32_t n_tokens,
+                             const void *cos_rows, const void *sin_rows, int64_t cos_sin_token_stride, int32_t head_dim,
+                             void *stream);
+int duo_rmsnorm_hf_bf16(const void *x, const void *w, void *y, int64_t n_rows, int32_t hidden, float eps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -231,3 +231,49 @@ def test_stride_described_attention_equals_the_view_form(nf, ns, N, n):
         exact = flash_attn_func_ref(q[None, None, nf * G:].cpu(), kk[None], vv[None], causal=True, round_p=False,
                                     out_dtype=torch.float32)
         attn_close(a[None, None, nf * G:], exact, f"tuple stride form, streaming ns={ns} n={n}")
+
+
+@pytest.mark.parametrize("S,Hq,Hkv", [(1, 8, 2), (67, 32, 8), (513, 4, 4)])
+def test_hf_rotary_chunk_kernel_is_bit_equal_to_the_torch_sequence(S, Hq, Hkv):
+    """duo_rope_hf_inplace_bf16 == transformers' apply_rotary_pos_emb(unsqueeze_dim=2) in bf16 (what the reference's tuple
+    forward calls, llama.py:177-184), on the projections' layout and on a strided k view"""
+    from duo_attn import _hip
+    from duo_attn.patch.tuple_kv_cache import hf_apply_rotary_pos_emb
+
+    g = torch.Generator().manual_seed(S + Hq)
+    rn = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16)
+    q, kbuf = rn(1, S, Hq, D_), rn(1, S, Hkv + 1, D_)
+    k = kbuf[:, :, 1:]                                            # a view with a head offset (token stride > Hkv * D)
+    pos = torch.arange(1000, 1000 + S)[:, None].float()
+    inv = 1.0 / (500000.0 ** (torch.arange(0, D_, 2).float() / D_))
+    ang = torch.cat([pos * inv, pos * inv], -1)
+    cos, sin = ang.cos().to(torch.bfloat16)[None], ang.sin().to(torch.bfloat16)[None]
+    wq, wk = hf_apply_rotary_pos_emb(q, k, cos, sin, unsqueeze_dim=2)                      # torch on the CPU
+    dq, dkbuf = q.to(DEV), kbuf.to(DEV)
+    dk = dkbuf[:, :, 1:]
+    gq, gk = hf_apply_rotary_pos_emb(dq, dk, cos.to(DEV), sin.to(DEV), unsqueeze_dim=2)     # torch on the GPU
+    _hip.rope_hf_inplace(dq[0], dk[0], cos[0].to(DEV), sin[0].to(DEV))
+    assert torch.equal(dq.cpu(), wq) and torch.equal(dk.cpu(), wk)
+    assert torch.equal(dq, gq) and torch.equal(dk, gk)
+    assert torch.equal(dkbuf[:, :, 0].cpu(), kbuf[:, :, 0])                               # the neighbouring head is untouched
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 512), (33, 4096), (7, 1000)])
+def test_hf_rmsnorm_kernel_matches_the_transformers_module(rows, hidden):
+    from transformers.models.llama.modeling_llama import LlamaRMSNorm
+
+    from duo_attn import _hip
+    from oracle.duo_oracle import rmsnorm_hf_ref
+
+    g = torch.Generator().manual_seed(rows + hidden)
+    x = (torch.randn(rows, hidden, generator=g) * 2.5).to(torch.bfloat16)
+    norm = LlamaRMSNorm(hidden, eps=1e-5).to(torch.bfloat16)
+    norm.weight.data = (torch.rand(hidden, generator=g) + 0.5).to(torch.bfloat16)
+    want = norm(x)
+    assert torch.equal(rmsnorm_hf_ref(x, norm.weight.data, 1e-5), want)
+    got = _hip.rmsnorm_hf(x.to(DEV), norm.weight.data.to(DEV), 1e-5).cpu()
+    # the statistics are summed in another order than torch's: a last-bit difference of rsqrt can move a rounding
+    assert (got == want).float().mean() >= 0.995, (got == want).float().mean()
+    assert ((got.float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 1e-30).all()
+    on_gpu = norm.to(DEV)(x.to(DEV)).cpu()
+    assert (got == on_gpu).float().mean() >= 0.995
