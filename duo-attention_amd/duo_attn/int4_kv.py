@@ -29,10 +29,13 @@ class QuantizedCache:
         self.batch_size, self.max_size = batch_size, max_size
         self.num_kv_heads, self.head_dim, self.device, self.group_size = num_kv_heads, head_dim, device, group_size
         self.num_groups = 1
-        q = torch.zeros(batch_size, num_kv_heads, max_size, head_dim // 2, device=device, dtype=torch.uint8)
-        sz = torch.zeros(batch_size, num_kv_heads, max_size, 2, device=device, dtype=torch.float16)
-        self.quantized_data = q.permute(0, 2, 1, 3)      # logical [B, T, h, 64]
-        self.scale_zero = sz.permute(0, 2, 1, 3)         # logical [B, T, h, 2]
+        # (a head's rows are padded to a multiple of 4: its (scale, zero) words then start on a 16-byte boundary, which the
+        #  folded decode kernel's 16-byte fetches of four keys' pairs want; the logical shapes are the reference's)
+        rows = (max_size + 3) // 4 * 4
+        q = torch.zeros(batch_size, num_kv_heads, rows, head_dim // 2, device=device, dtype=torch.uint8)
+        sz = torch.zeros(batch_size, num_kv_heads, rows, 2, device=device, dtype=torch.float16)
+        self.quantized_data = q.permute(0, 2, 1, 3)[:, :max_size]      # logical [B, T, h, 64]
+        self.scale_zero = sz.permute(0, 2, 1, 3)[:, :max_size]         # logical [B, T, h, 2]
         self.scale = self.scale_zero[..., 0:1]
         self.zero_point = self.scale_zero[..., 1:2]
 
