@@ -460,6 +460,9 @@ __global__ __launch_bounds__(256) void duo_int4_decode_split_kernel(const Int4De
 // 16+4g+e-4: no cross-lane traffic for P.
 // Softmax keeps a per-q-head reference maximum that is only raised when some score exceeds it by 2^8
 // (wave vote), so the steady state has no cross-lane reduction and no accumulator rescale.
+#ifndef DUO_I4_PROBE
+#define DUO_I4_PROBE 0      // ablation builds only (wrong results by design): bit 0 no exp, bit 1 no K dequantisation, bit 2 no V, bit 3 no LDS transpose
+#endif
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
 
@@ -695,9 +698,15 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const RowConst R = row_const(T.ks[h], FAST);
             const uint32_t kw[4] = {T.kw[h].x, T.kw[h].y, T.kw[h].z, T.kw[h].w};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+            for (int kb = 0; kb < 4; ++kb) {
+#if DUO_I4_PROBE & 2     // ablation build (tools/debug/int4_ablation.sh): K words to the MFMA without dequantisation
+                const u32x4 raw = {kw[kb] & 0x3bff3bffu, (kw[kb] >> 1) & 0x3bff3bffu, R.s[0] != R.z[1] ? kw[kb] & 0x33ff33ffu : 0u, 0u};
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(raw), qB[kb], S[h], 0, 0, 0);
+#else
                 S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST, FUSED>(kw[kb], R, m0, m4, magic)), qB[kb],
                                                               S[h], 0, 0, 0);
+#endif
+            }
         }
         // ---- V^ -> LDS (issued early: the writes drain while the softmax runs) -----------------
 #pragma unroll
@@ -705,8 +714,15 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             const RowConst R = row_const(T.vs[h], FAST);
             const uint32_t vw[4] = {T.vw[h].x, T.vw[h].y, T.vw[h].z, T.vw[h].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+#if DUO_I4_PROBE & 8
+                if (R.s[0] != R.s[0]) m_ref += 1.f;     // (keeps the scale loads alive)
+#elif DUO_I4_PROBE & 4     // ablation build: V words to LDS without dequantisation
+                *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = u32x4{vw[j] & 0x3bff3bffu, (vw[j] >> 1) & 0x3bff3bffu, R.s[0] != R.z[1] ? vw[j] & 0x33ff33ffu : 0u, 0u};
+#else
                 *(lds_u32x4 *)(uintptr_t)(wa[j] + h * 4096) = dq8<FAST, FUSED>(vw[j], R, m0, m4, magic);
+#endif
+            }
         }
 
         // ---- softmax against the reference maximum ---------------------------------------------
@@ -744,7 +760,11 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         {
             float p[8];
 #pragma unroll
+#if DUO_I4_PROBE & 1     // ablation build: no transcendental (a bounded stand-in for the probability)
+            for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_fmed3f(fmaf(sv[i], c_, -m_ref), 0.f, 1.f);
+#else
             for (int i = 0; i < 8; ++i) p[i] = fast_exp2(fmaf(sv[i], c_, -m_ref));
+#endif
             pw.x = cvt_pk_f16(p[0], p[1]);
             pw.y = cvt_pk_f16(p[2], p[3]);
             pw.z = cvt_pk_f16(p[4], p[5]);
@@ -757,6 +777,17 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         // ---- O += P . V^ : transpose reads two dim blocks at a time, one batch ahead of the MFMAs ------
         u32x2 va[4], vb[4];
         __builtin_amdgcn_sched_barrier(0);
+#if DUO_I4_PROBE & 8     // ablation build: no LDS round trip, the MFMAs of P . V^ take the packed words as they are
+        {
+            const u32x4 g0 = {T.vw[0].x & 0x3bff3bffu, T.vw[0].y & 0x3bff3bffu, T.vw[0].z & 0x3bff3bffu, T.vw[0].w & 0x3bff3bffu};
+            const u32x4 g1 = {T.vw[1].x & 0x3bff3bffu, T.vw[1].y & 0x3bff3bffu, T.vw[1].z & 0x3bff3bffu, T.vw[1].w & 0x3bff3bffu};
+#pragma unroll
+            for (int nb = 0; nb < 8; ++nb)
+                O[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, as_f16x8((nb & 1) ? g1 : g0), O[nb], 0, 0, 0);
+            (void)va; (void)vb;
+            return;
+        }
+#endif
 #define DUO_I4_TR_BATCH(buf, nb0)                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
         const uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                     \
