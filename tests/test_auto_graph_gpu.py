@@ -148,24 +148,27 @@ def test_calls_that_are_not_the_reference_decode_call_stay_eager(monkeypatch):
     assert kv._decode_graph is None and getattr(kv, "_auto_graph", None) is None
 
 
+@pytest.mark.parametrize("prefill,sink,recent", [(13, 4, 12), (650, 2, 300)])
 @pytest.mark.parametrize("starts", [[0, 0], [5, 21]])
-def test_batched_decode_step_is_capturable(starts):
+def test_batched_decode_step_is_capturable(starts, prefill, sink, recent):
     """B = 2 through the static attention core with device-side lengths (duo_decode_layer_batched_dev_bf16): one captured
     step replayed == the eager batched steps bit for bit, with equal and with per-row different RoPE positions (a row's
-    offset from the cache length is fixed for the life of the sequence)"""
+    offset from the cache length is fixed for the life of the sequence).  The 650-row variant (650 ... 657 rows: one count of 64-row units, so the eager steps choose the captured partition) has the retrieval heads split
+    over several workgroups AND a saturated streaming pool whose update is folded into the scan — the combination in which
+    every batch row once published its partials into row 0's workspace area (found by tests/fuzz_static_path.py)"""
     from duo_attn.graph import DecodeStepGraph
     from duo_attn.patch._duo import duo_static_attention_core
     from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
 
-    counts, Hq, Hkv, sink, recent, B = [1, 3, 0, 4], 16, 4, 4, 12, 2
+    counts, Hq, Hkv, B = [1, 3, 0, 4], 16, 4, 2
     heads = heads_from_counts(counts, Hkv)
 
     def setup():
         g = torch.Generator().manual_seed(31)
-        cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D, device=DEV), heads, B, 64, sink, recent)
+        cache = DuoAttentionStaticKVCache(ShapeModel(len(counts), Hq, Hkv, D, device=DEV), heads, B, prefill + 51, sink, recent)
         mk = lambda S, h: torch.randn(B, S, h, D, generator=g).to(torch.bfloat16).to(DEV)
         for li in range(len(counts)):
-            duo_static_attention_core(mk(13, Hq), mk(13, Hkv), mk(13, Hkv), cache, li, starts if starts[0] != starts[1] else starts[0],
+            duo_static_attention_core(mk(prefill, Hq), mk(prefill, Hkv), mk(prefill, Hkv), cache, li, starts if starts[0] != starts[1] else starts[0],
                                       1.0, 1e4)
         qs, ks, vs = ([mk(1, h) for _ in counts] for h in (Hq, Hkv, Hkv))
         outs = [torch.zeros(B, 1, Hq, D, dtype=torch.bfloat16, device=DEV) for _ in counts]

@@ -1,0 +1,89 @@
+"""The randomised differential run of the static hot path (tests/fuzz_static_path.py) as tests.
+
+* CPU: the harness itself — a handful of drawn cases with the oracle plugged in as the device backend (oracle against
+  oracle through the product's host plumbing: batch rows, row blocks, evictions), so a harness error cannot hide on the GPU;
+* GPU: the cases the fuzzer FOUND (kept as regressions), and a fixed seed's first cases.
+
+What it found (round 4): a batched (B > 1) fused decode step with the retrieval heads split over several workgroups and the
+streaming-pool update folded into the scan stored every batch row's partials into row 0's workspace area — rows >= 1 merged
+unwritten partials.  No earlier B > 1 decode test had a context long enough to split a retrieval head."""
+import random
+
+import pytest
+
+import fuzz_static_path as F
+
+FOUND = [
+    # B = 2 decode, retrieval heads split, saturated streaming pool (sink + recent < context), group 1 / 2 / 4
+    dict(Hkv=2, group=1, counts=[1, 1], sink=2, recent=300, chunks=[30, 526, 679], row_block=None, decode_steps=2, evict=False,
+         theta=10000.0, rope_scale=1.0, scale=1.0, B=2, seed=1233713562),
+    dict(Hkv=8, group=4, counts=[8, 5], sink=2, recent=256, chunks=[588], row_block=None, decode_steps=2, evict=True,
+         theta=1000000.0, rope_scale=4.0, scale=0.5, B=2, seed=412307310),
+    dict(Hkv=4, group=2, counts=[1, 4], sink=64, recent=100, chunks=[590], row_block=None, decode_steps=1, evict=False,
+         theta=1000000.0, rope_scale=1.0, scale=1.0, B=2, seed=338587798),
+    dict(Hkv=8, group=2, counts=[0, 4], sink=128, recent=3, chunks=[53, 593], row_block=None, decode_steps=4, evict=True,
+         theta=1000000.0, rope_scale=4.0, scale=1.0, B=2, seed=1156546539),
+    dict(Hkv=3, group=2, counts=[0, 2], sink=64, recent=3, chunks=[126, 114, 208, 1], row_block=None, decode_steps=1, evict=False,
+         theta=500000.0, rope_scale=1.0, scale=0.5, B=2, seed=1762049565),
+    # large-magnitude data (peaky softmax), odd group sizes, row blocks
+    dict(Hkv=3, group=3, counts=[0], sink=1, recent=256, chunks=[328, 528], row_block=None, decode_steps=4, evict=True,
+         theta=10000.0, rope_scale=1.0, scale=2.5, B=1, seed=1045457843),
+    dict(Hkv=8, group=4, counts=[8], sink=16, recent=8, chunks=[40, 1575, 480, 683], row_block=512, decode_steps=4, evict=False,
+         theta=10000.0, rope_scale=1.0, scale=2.5, B=1, seed=1093887530),
+    dict(Hkv=2, group=7, counts=[1, 2], sink=4, recent=32, chunks=[17, 300, 1], row_block=64, decode_steps=3, evict=True,
+         theta=500000.0, rope_scale=1.0, scale=1.0, B=2, seed=5),
+]
+
+
+def test_fuzz_harness_on_the_cpu_with_the_oracle_backend(monkeypatch):
+    from duo_attn import backend
+    from oracle.duo_oracle import OracleBackend
+
+    monkeypatch.setattr(F, "DEV", "cpu")
+    backend._set_backend_for_testing(OracleBackend(round_p=False))      # (the expectation is the exact-P oracle)
+    try:
+        rng = random.Random(4)
+        n = 0
+        while n < 12:
+            c = F.draw_case(rng)
+            if sum(c["chunks"]) > 900:
+                continue
+            F.run_case(c)
+            n += 1
+    finally:
+        backend._set_backend_for_testing(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", FOUND, ids=lambda c: f"kv{c['Hkv']}g{c['group']}B{c['B']}n{sum(c['chunks'])}")
+def test_cases_the_fuzzer_found(case):
+    F.run_case(case)
+
+
+@pytest.mark.gpu
+def test_fixed_seed_prefix():
+    rng = random.Random(11)
+    for _ in range(25):
+        F.run_case(F.draw_case(rng))
+
+
+@pytest.mark.gpu
+def test_int4_decode_fixed_seed_prefix():
+    """tests/fuzz_int4_decode.py, default (dequantising) kernel: 60 drawn shapes — any group size up to 16, 1 ... 60 000 rows,
+    head-major and token-major pools, rows with extreme scales"""
+    import fuzz_int4_decode as I
+
+    rng = random.Random(21)
+    for _ in range(60):
+        I.run_case(I.draw_case(rng))
+
+
+@pytest.mark.gpu
+def test_tuple_path_fixed_seed_prefix():
+    """tests/fuzz_tuple_path.py: the tuple-cache attention forward (enable_duo_attention_eval's) on 40 drawn geometries /
+    step sequences — outputs at the attention bar, returned caches bit for bit"""
+    import fuzz_tuple_path as T
+
+    rng = random.Random(31)
+    for _ in range(40):
+        T.run_case(T.draw_case(rng))

@@ -1,11 +1,14 @@
 #!/bin/bash
-# same-box A/B of decode builds: libs under duo-attention_amd/lib/ab/lib_<tag>.so ("cur" = the tree's library)
-rounds=2
-if [ "$1" = "-n" ]; then rounds=$2; shift 2; fi
-for rep in $(seq $rounds); do
-  for v in "$@"; do
-    lib=$PWD/duo-attention_amd/lib/ab/lib_$v.so; [ "$v" = cur ] && lib=$PWD/duo-attention_amd/lib/libduoattn_hip.so
-    echo -n "$v  "
-    DUO_ATTN_HIP_LIB=$lib python tools/bench_kernels.py decode --ctx 131072 --reps 20 2>/dev/null | tail -1 | cut -c1-200
+# same-box A/B of the bench job's decode step between two builds of the library:  tools/debug/ab_decode.sh <old.so> [rounds]
+cd "$(dirname "$0")/../.."
+OLD=$1; N=${2:-3}
+for i in $(seq $N); do
+  for lib in "$OLD" duo-attention_amd/lib/libduoattn_hip.so; do
+    echo -n "$lib: "
+    DUO_ATTN_HIP_LIB=$PWD/$lib python bench.py --steps 2 --warmup 1 --no-full-baseline --no-cpu-baseline --no-traffic --no-model-level \
+        --no-int4 --no-token-linear --no-parity 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('decode ms/token %.4f   whole step frac %s' % (d['decode_ms_per_token'], d['roofline_decode'].get('whole_step', {}).get('frac')))"
   done
 done
