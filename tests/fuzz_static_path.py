@@ -76,7 +76,7 @@ def draw_case(rng: random.Random, big=False):
     if rng.random() < 0.3:
         blocks = rng.choice([17, 64, 128, 200, 256, 512])
     return dict(Hkv=Hkv, group=group, counts=counts, sink=sink, recent=recent, chunks=chunks, row_block=blocks,
-                decode_steps=rng.randint(0, 4), evict=rng.random() < 0.5, theta=rng.choice([1e4, 5e5, 1e6, 3580165449.0]),
+                decode_steps=rng.randint(0, 4), evict=rng.random() < 0.5, graph=rng.random() < 0.35, theta=rng.choice([1e4, 5e5, 1e6, 3580165449.0]),
                 rope_scale=rng.choice([1.0, 1.0, 4.0]), scale=rng.choice([0.5, 1.0, 1.0, 2.5]), B=rng.choice([1, 1, 1, 2]),
                 seed=rng.randint(0, 2 ** 31 - 1))
 
@@ -127,11 +127,50 @@ def _run_steps(c, cache, ref, mk, dev, duo_static_attention_core, duo_static_att
     Hkv, L = c["Hkv"], len(c["counts"])
     Hq = Hkv * c["group"]
     pos = 0
+
+    def check(l, out, q, k, v, S, what, counters=True):
+        """the oracle's call for the same inputs, then outputs / counters / pools"""
+        exp, bud = static_forward_ref(q, k, v, ref, l, pos, c["rope_scale"], c["theta"], round_p=False,
+                                      out_dtype=torch.float32, return_budget=True)
+        try:
+            attn_close(out, exp, "", bud if S > 1 else None)
+        except AssertionError as e:
+            if not _rms_only_on_a_small_sample(str(e), out.numel()):
+                raise AssertionError(f"{what}: attention {e}") from None
+        n, m = ref.kv_seq_len_list[l], ref.streaming_kv_seq_len_list[l]
+        assert not counters or (cache.kv_seq_len_list[l] == n and cache.streaming_kv_seq_len_list[l] == m), what + ": counters"
+        _ulp_close(cache.full_key_states_list[l][:, :n], ref.full_key_states_list[l][:, :n], what + ": full K pool")
+        assert torch.equal(cache.full_value_states_list[l][:, :n].cpu(), ref.full_value_states_list[l][:, :n]), what + ": full V pool"
+        _ulp_close(cache.streaming_key_states_list[l][:, :m], ref.streaming_key_states_list[l][:, :m], what + ": stream K pool")
+        assert torch.equal(cache.streaming_value_states_list[l][:, :m].cpu(),
+                           ref.streaming_value_states_list[l][:, :m]), what + ": stream V pool"
+        ref.full_key_states_list[l][:, :n].copy_(cache.full_key_states_list[l][:, :n].cpu())
+        ref.streaming_key_states_list[l][:, :m].copy_(cache.streaming_key_states_list[l][:, :m].cpu())
+
     steps = [(S, False) for S in c["chunks"]] + [(1, c["evict"])] * c["decode_steps"]
+    graph = None
     for si, (S, evict) in enumerate(steps):
+        decode = si >= len(c["chunks"])
+        if graph is not None:
+            # a replay of the captured step (device-side lengths, the eviction inside the graph): all layers at once
+            data = [(mk(1, Hq), mk(1, Hkv), mk(1, Hkv)) for _ in range(L)]
+            for l, (q, k, v) in enumerate(data):
+                g_q[l].copy_(q); g_k[l].copy_(k); g_v[l].copy_(v)
+            graph.replay()
+            outs = [o.clone() for o in g_out]
+            for l, (q, k, v) in enumerate(data):
+                # (with the eviction inside the graph the host counters are already one step on: compared after the oracle's own)
+                check(l, outs[l], q, k, v, 1, f"step {si} (graph replay) layer {l} pos {pos}", counters=not evict)
+            if evict:
+                ref.evict_last(1)
+                assert cache.kv_seq_len_list == ref.kv_seq_len_list and \
+                    cache.streaming_kv_seq_len_list == ref.streaming_kv_seq_len_list, f"step {si} (graph replay): counters after evict_last"
+            else:
+                pos += 1
+            continue
         for l in range(L):
             q, k, v = mk(S, Hq), mk(S, Hkv), mk(S, Hkv)
-            rb = c["row_block"] if (S > 1 and si < len(c["chunks"])) else None
+            rb = c["row_block"] if (S > 1 and not decode) else None
             if rb and rb < S:
                 parts = [duo_static_attention_row_block(dev(q[:, r0:r0 + rb]), dev(k[:, r0:r0 + rb]),
                                                         dev(v[:, r0:r0 + rb]), cache, l, r0, S, c["rope_scale"], c["theta"])
@@ -139,28 +178,26 @@ def _run_steps(c, cache, ref, mk, dev, duo_static_attention_core, duo_static_att
                 out = torch.cat(parts, 1)
             else:
                 out = duo_static_attention_core(dev(q), dev(k), dev(v), cache, l, pos, c["rope_scale"], c["theta"])
-            exp, bud = static_forward_ref(q, k, v, ref, l, pos, c["rope_scale"], c["theta"], round_p=False,
-                                          out_dtype=torch.float32, return_budget=True)
-            what = f"step {si} (S={S}{' row blocks of %d' % rb if rb and rb < S else ''}) layer {l} pos {pos}"
-            try:
-                attn_close(out, exp, "", bud if S > 1 else None)
-            except AssertionError as e:
-                if not _rms_only_on_a_small_sample(str(e), out.numel()):
-                    raise AssertionError(f"{what}: attention {e}") from None
-            n, m = ref.kv_seq_len_list[l], ref.streaming_kv_seq_len_list[l]
-            assert cache.kv_seq_len_list[l] == n and cache.streaming_kv_seq_len_list[l] == m, what + ": counters"
-            _ulp_close(cache.full_key_states_list[l][:, :n], ref.full_key_states_list[l][:, :n], what + ": full K pool")
-            assert torch.equal(cache.full_value_states_list[l][:, :n].cpu(), ref.full_value_states_list[l][:, :n]), what + ": full V pool"
-            _ulp_close(cache.streaming_key_states_list[l][:, :m], ref.streaming_key_states_list[l][:, :m], what + ": stream K pool")
-            assert torch.equal(cache.streaming_value_states_list[l][:, :m].cpu(),
-                               ref.streaming_value_states_list[l][:, :m]), what + ": stream V pool"
-            ref.full_key_states_list[l][:, :n].copy_(cache.full_key_states_list[l][:, :n].cpu())
-            ref.streaming_key_states_list[l][:, :m].copy_(cache.streaming_key_states_list[l][:, :m].cpu())
+            check(l, out, q, k, v, S, f"step {si} (S={S}{' row blocks of %d' % rb if rb and rb < S else ''}) layer {l} pos {pos}")
         if evict:
             cache.evict_last(1)
             ref.evict_last(1)
         else:
             pos += S
+        if decode and c.get("graph") and graph is None and DEV != "cpu" and si + 1 < len(steps):
+            # the first decode step ran eagerly (library handles, workspaces); the rest are replays of ONE captured step
+            from duo_attn.graph import DecodeStepGraph
+
+            B = c["B"]
+            z = lambda h: torch.zeros(B, 1, h, D, dtype=torch.bfloat16, device=DEV)
+            g_q, g_k, g_v, g_out = [z(Hq) for _ in range(L)], [z(Hkv) for _ in range(L)], [z(Hkv) for _ in range(L)], [z(Hq) for _ in range(L)]
+
+            def step_fn():
+                for l in range(L):
+                    g_out[l].copy_(duo_static_attention_core(g_q[l], g_k[l], g_v[l], cache, l, None, c["rope_scale"], c["theta"]))
+                return g_out
+
+            graph = DecodeStepGraph(cache, step_fn, evict_after=1 if evict else 0)
 
 
 def main():
