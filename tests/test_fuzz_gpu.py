@@ -87,3 +87,14 @@ def test_tuple_path_fixed_seed_prefix():
     rng = random.Random(31)
     for _ in range(40):
         T.run_case(T.draw_case(rng))
+
+
+@pytest.mark.gpu
+def test_token_linear_fixed_seed_prefix():
+    """tests/fuzz_token_linear.py: 150 drawn shapes of the token-row linears (rows 1-4, any feature count that fits, 1-3
+    blocks, padded rows, bias / residual, all four prologues)"""
+    import fuzz_token_linear as L
+
+    rng = random.Random(41)
+    for _ in range(150):
+        L.run_case(L.draw_case(rng))
