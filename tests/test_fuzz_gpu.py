@@ -98,3 +98,15 @@ def test_token_linear_fixed_seed_prefix():
     rng = random.Random(41)
     for _ in range(150):
         L.run_case(L.draw_case(rng))
+
+
+@pytest.mark.gpu
+def test_model_level_forms_agree_fixed_seed_prefix():
+    """tests/fuzz_model_decode.py: 40 drawn tiny HF models (Llama / Mistral, random head geometry, MLP width, biases, batch
+    rows, patterns) — static path module by module == fused == the reference loop under the automatic HIP graph; tuple path
+    module by module == fused"""
+    import fuzz_model_decode as M
+
+    rng = random.Random(51)
+    for _ in range(40):
+        M.run_case(M.draw_case(rng))
