@@ -733,8 +733,8 @@ def attn_prefill(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[
 
 def attention_batched(q: torch.Tensor, out: torch.Tensor, group: int, full: Optional[HeadClass],
                       stream: Optional[HeadClass], scale: float):
-    """q, out: [B, S, Hq, D] views; the classes' segments were built from [B, T, h, D] views (``make_seg``).  S > 1:
-    MFMA prefill, S == 1: split-KV decode — one launch (pair) for all batch rows."""
+    """q, out: [B, S, Hq, D] views; the classes' segments were built from [B, T, h, D] views (``make_seg``).  S > 1 (and
+    fp16 at any S): MFMA prefill, bf16 S == 1: split-KV decode — one launch (pair) for all batch rows."""
     lib = load_library()
     if q.dtype not in (torch.bfloat16, torch.float16):
         raise DuoHipError(f"q must be bfloat16 or float16, got {q.dtype}")
@@ -743,9 +743,7 @@ def attention_batched(q: torch.Tensor, out: torch.Tensor, group: int, full: Opti
     assert q.dim() == 4 and out.shape == q.shape
     B, S = q.shape[0], q.shape[1]
     fc, sc = (byref(full) if full is not None else None), (byref(stream) if stream is not None else None)
-    if S == 1:
-        if q.dtype != torch.bfloat16:
-            raise DuoHipError("single-token attention is bf16 (static pools) or INT4 (attn_decode_int4)")
+    if S == 1 and q.dtype == torch.bfloat16:       # (fp16 single rows: a one-row query block of the MFMA kernel, below)
         ws = decode_workspace(q.device, q.shape[2])      # every batch row gets its own share of the partial area
         _check(lib.duo_attn_decode_batched_bf16(q.data_ptr(), q.stride(0), q.stride(2), out.data_ptr(), out.stride(0),
                                                 out.stride(2), B, int(group), fc, sc, float(scale), q.shape[3],

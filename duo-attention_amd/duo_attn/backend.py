@@ -56,11 +56,12 @@ class HipBackend:
     # -- the flash_attn_func calls of reference llama.py:364-421
     def attention(self, q, out, group: int, full: ClassDesc, stream: ClassDesc, scale: float):
         fc, sc = self._cls(full, q.dtype), self._cls(stream, q.dtype)
-        if q.shape[0] == 1:
-            if q.dtype != torch.bfloat16:
-                raise NotImplementedError("single-token attention is bf16 (static pools) or INT4 (attn_decode_int4)")
+        if q.shape[0] == 1 and q.dtype == torch.bfloat16:
             self._hip.attn_decode(q[0], out[0], group, fc, sc, scale)
         else:
+            # (fp16 — the INT4 demo's dequantised scratch — has no split-KV scan of its own: its decode steps read the packed
+            #  pools (attn_decode_int4), and a ONE-TOKEN chunk over fp16 rows, e.g. a one-token prompt, is a one-row query
+            #  block of the MFMA kernel)
             self._hip.attn_prefill(q, out, group, fc, sc, scale)
 
     # -- batched forms: the batch row is a grid dimension of the same kernels (one launch for all rows).  Views carry a

@@ -110,3 +110,19 @@ def test_model_level_forms_agree_fixed_seed_prefix():
     rng = random.Random(51)
     for _ in range(40):
         M.run_case(M.draw_case(rng))
+
+
+@pytest.mark.gpu
+def test_int4_cache_flows_fixed_seed_prefix_and_one_token_first_chunk():
+    """tests/fuzz_int4_cache.py: put / chunked-prefill attention / fused INT4 decode / compress flows of
+    DuoAttentionStaticINT4KVCache on drawn geometries; first the case the fuzzer found — a ONE-TOKEN first chunk (a one-token
+    prompt) with two batch rows, which the fp16 dispatch used to refuse"""
+    import fuzz_int4_cache as C
+
+    C.run_case(dict(Hkv=1, group=4, counts=[1], sink=16, recent=8, chunk=200, chunks=[1, 57], decode_steps=4, B=2, scale=0.5,
+                    seed=667356813))
+    C.run_case(dict(Hkv=2, group=2, counts=[1, 0], sink=4, recent=8, chunk=64, chunks=[1, 1, 30], decode_steps=2, B=1, scale=1.0,
+                    seed=3))
+    rng = random.Random(61)
+    for _ in range(40):
+        C.run_case(C.draw_case(rng))
