@@ -111,7 +111,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-oracle", action="store_true", help="harness / host-logic self-check: the oracle as device backend, on the CPU")
     a = ap.parse_args()
+    if a.cpu_oracle:
+        global DEV
+        from duo_attn import backend
+        from oracle.duo_oracle import OracleBackend
+
+        DEV = "cpu"
+        backend._set_backend_for_testing(OracleBackend(round_p=False))
     rng = random.Random(a.seed)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
