@@ -20,7 +20,9 @@ def reorder_linear_weights(linear_module: torch.nn.Linear, full_attention_heads:
         linear_module.weight.data = w.index_select(1, perm).contiguous()
     else:
         linear_module.weight.data = w.index_select(0, perm).contiguous()
-        if linear_module.bias is not None:   # bias follows the output rows
+        if linear_module.bias is not None:   # bias follows the output rows (the reference, patch/utils.py:27-32, also indexes
+            #                                     the bias with the mask when the IN channels are reordered — an IndexError for a
+            #                                     biased o_proj; there the bias stays, the output rows do not move)
             linear_module.bias.data = linear_module.bias.data.index_select(0, perm).contiguous()
     return linear_module
 
