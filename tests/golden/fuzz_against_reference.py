@@ -66,11 +66,7 @@ def draw_tuple(rng):
 
 
 def run_static(c):
-    from duo_attn.patch.llama import llama_duo_attention_forward_one_way_reordered_static as ref_fwd       # THE REFERENCE
-    from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache as RefCache
-
-    import importlib.util
-
+    ref_fwd, RefCache = _REF["static_fwd"], _REF["Cache"]                                                  # THE REFERENCE
     ours = _ours()
     from oracle.duo_oracle import StaticCacheRef, static_forward_ref
 
@@ -119,8 +115,7 @@ def run_static(c):
 
 
 def run_tuple(c):
-    from duo_attn.patch.llama import llama_duo_attention_forward_one_way_reordered as ref_fwd                # THE REFERENCE
-
+    ref_fwd = _REF["tuple_fwd"]                                                                              # THE REFERENCE
     ours = _ours()
     from oracle.duo_oracle import tuple_forward_ref
 
@@ -175,9 +170,7 @@ def run_utils(c):
     """sparsify_attention_heads (utils.py:353-373: same numpy random stream, same result or the same exception type),
     reorder_linear_weights / reorder_full_attn_heads (patch/utils.py:7-45)"""
     import numpy as np
-    from duo_attn.patch.utils import reorder_full_attn_heads as ref_rh, reorder_linear_weights as ref_rw     # THE REFERENCE
-    from duo_attn.utils import sparsify_attention_heads as ref_sp
-
+    ref_rh, ref_rw, ref_sp = _REF["reorder_h"], _REF["reorder_w"], _REF["sparsify"]                          # THE REFERENCE
     ours = _ours()
     rs = np.random.RandomState(c["seed"] % (2 ** 32))
     heads = rs.rand(c["L"], c["H"])
@@ -229,25 +222,162 @@ def run_utils(c):
     assert torch.equal(ref_rh(pattern.clone()), ours["reorder_h"](pattern.clone())), "reorder_full_attn_heads differs"
 
 
-_OURS = {}
+def draw_layer(rng):
+    Hkv = rng.choice([1, 2, 4])
+    return dict(kind="layer", Hkv=Hkv, group=rng.choice([1, 2, 4] if Hkv < 4 else [1, 2]), nf=rng.randint(0, Hkv), inter=8 * rng.randint(4, 96),
+                sink=rng.choice([2, 4, 16]), recent=rng.choice([4, 8, 32]), chunks=[rng.randint(1, 40) for _ in range(rng.randint(1, 3))],
+                decode_steps=rng.randint(1, 5), theta=rng.choice([1e4, 5e5]), fused=rng.random() < 0.5, seed=rng.randint(0, 2 ** 31 - 1))
+
+
+class _FusedOracleBackend:
+    """the oracle backend + ``token_linear`` (the oracle's module-by-module restatement): lets ``duo_decode_layer_fused`` —
+    on the GPU the HIP token-row linears — run on the CPU"""
+
+    def __init__(self):
+        from oracle.duo_oracle import OracleBackend
+
+        self._inner = OracleBackend(round_p=False)
+
+    def __getattr__(self, name):
+        return getattr(self._inner, name)
+
+    def token_linear_fits(self, n_rows, n_in):
+        return n_rows <= 4 and n_in % 8 == 0
+
+    def token_linear(self, x, blocks, norm=None, x2=None, residual=None, norm_hf=False):
+        from oracle.duo_oracle import token_linear_ref
+
+        return token_linear_ref(x, blocks, norm=norm, x2=x2, residual=residual, norm_hf=norm_hf)
+
+
+def run_layer(c):
+    """a whole DECODER LAYER: the reference's ``duo_attn_static_kv_cache_llama_decoder_layer_forward`` (static_kv_cache.py:
+    507-546) around its static attention forward, real nn.Linear / LlamaMLP / LlamaRMSNorm modules with its
+    ``flashinfer_rmsnorm_forward``, its real cache — against this package's decoder-layer forward on the same weights, module
+    by module or with the decode steps in the fused form (``duo_decode_layer_fused``): every hidden state within two bf16
+    ulps, >= 99 % of the elements bit-equal (tests/test_token_linear_cpu.py::_layer_close), cache V pools bit for bit."""
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaMLP, LlamaRMSNorm
+
+    from duo_attn import backend
+
+    ours = _ours()
+    Hkv, G, nf = c["Hkv"], c["group"], c["nf"]
+    Hq, H = Hkv * G, Hkv * G * D
+    g = torch.Generator().manual_seed(c["seed"])
+    heads = [[1.0] * nf + [0.0] * (Hkv - nf)]
+    total = sum(c["chunks"]) + c["decode_steps"] + 2
+    rw = lambda o, i: (torch.randn(o, i, generator=g) * i ** -0.5).to(torch.bfloat16)
+    W = {nm: rw(o, i) for nm, o, i in (("q_proj", H, H), ("k_proj", Hkv * D, H), ("v_proj", Hkv * D, H), ("o_proj", H, H),
+                                       ("gate_proj", c["inter"], H), ("up_proj", c["inter"], H), ("down_proj", H, c["inter"]))}
+    NW = {nm: (torch.rand(H, generator=g) + 0.5).to(torch.bfloat16) for nm in ("input_layernorm", "post_attention_layernorm")}
+
+    def build(attn, attn_fwd, layer_fwd, norm_fwd):
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            lin = torch.nn.Linear(W[nm].shape[1], W[nm].shape[0], bias=False).to(torch.bfloat16)
+            lin.weight.data.copy_(W[nm])
+            setattr(attn, nm, lin)
+        attn.forward = types.MethodType(attn_fwd, attn)
+        layer = torch.nn.Module()
+        layer.self_attn = attn
+        layer.mlp = LlamaMLP(LlamaConfig(hidden_size=H, intermediate_size=c["inter"])).to(torch.bfloat16)
+        for nm in ("gate_proj", "up_proj", "down_proj"):
+            getattr(layer.mlp, nm).weight.data.copy_(W[nm])
+        for nm in NW:
+            ln = LlamaRMSNorm(H, eps=1e-5).to(torch.bfloat16)
+            ln.weight.data.copy_(NW[nm])
+            ln.forward = types.MethodType(norm_fwd, ln)
+            setattr(layer, nm, ln)
+        layer.forward = types.MethodType(layer_fwd, layer)
+        return layer.eval()
+
+    model = types.SimpleNamespace(
+        config=types.SimpleNamespace(num_hidden_layers=1, num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=H),
+        parameters=lambda: iter([torch.zeros(1, dtype=torch.bfloat16)]))
+    r_cache = _REF["Cache"](model, heads, 1, total, c["sink"], c["recent"])
+    r_layer = build(MG.fake_attention(Hq, Hkv, D, c["theta"], None), _REF["static_fwd"], _REF["layer_fwd"], _REF["rmsnorm_fwd"])
+    p_attn = torch.nn.Module()
+    p_attn.config = types.SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=H, head_dim=D,
+                                          rope_theta=c["theta"], rope_scaling=None)
+    p_attn.head_dim = D
+    p_layer = build(p_attn, ours["static_attn_fwd"], ours["layer_fwd"], ours["rmsnorm_fwd"])
+    p_cache = ours["Cache"](ours["ShapeModel"](1, Hq, Hkv, D), heads, 1, total, c["sink"], c["recent"])
+    duo = ours["duo"]
+    if c["fused"]:
+        backend._set_backend_for_testing(_FusedOracleBackend())
+    # This run is about the module SEQUENCE around the attention op, so the reference's attention call gets the oracle's
+    # arithmetic for its duration (the static runs above compare the attention itself, against make_golden's independent SDPA
+    # stub): a hidden state that differs is then a difference in norm / projection / residual / MLP order or rounding.
+    from oracle.duo_oracle import flash_attn_func_ref
+
+    r_llama = _REF["llama_mod"]
+    sdpa_stub = r_llama.flash_attn_func
+    r_llama.flash_attn_func = lambda q, k, v, causal=True, dropout_p=0.0, **kw: flash_attn_func_ref(q, k, v, causal=causal, round_p=False)
+    try:
+        pos = 0
+        for si, S in enumerate(list(c["chunks"]) + [1] * c["decode_steps"]):
+            pid = torch.arange(pos, pos + S)[None]
+            h = torch.randn(1, S, H, generator=g).to(torch.bfloat16)
+            want = r_layer(h.clone(), position_ids=pid, kv_cache=r_cache, layer_idx=0)[0]
+            if c["fused"] and S == 1 and p_cache.kv_seq_len_list[0] > 0:
+                got = duo.duo_decode_layer_fused(p_layer, h.clone(), p_cache, 0, None, pid)
+            else:
+                got = p_layer(h.clone(), position_ids=pid, kv_cache=p_cache, layer_idx=0)[0]
+            what = f"step {si} (S={S}{', fused' if c['fused'] and S == 1 else ''}) pos {pos}"
+            o, r = got.float(), want.float()
+            assert o.shape == r.shape, (what, o.shape, r.shape)
+            diff = (o - r).abs()
+            tol = torch.clamp(torch.maximum(o.abs(), r.abs()) * 2.0 ** -6, min=2e-3 * float(r.pow(2).mean().sqrt()))
+            same = (diff == 0).float().mean().item()
+            rel = float((o - r).norm() / r.norm().clamp_min(1e-9))
+            if c["fused"] and S == 1:
+                # the fused form sums the projections' dot products in another order than torch's bf16 GEMM (by design): a
+                # q / k / v element that rounds the other way is then seen through a softmax over a handful of keys (measured: the
+                # worst drawn steps 70 % bit-equal at rel L2 2.6e-3, windows of 8 rows; typical steps > 99 % bit-equal)
+                # The layer output is residual + o_proj(...) + MLP(...): one flipped ulp of an INTERMEDIATE of the residual stream
+                # passes straight through to an output that may itself be a near-cancellation, so the bars are the tensor's:
+                # every element within 2^-5 of the largest one, rel L2 <= 5e-3 (a wrong module order / a missing residual or
+                # norm is an O(1) difference)
+                tol = torch.full_like(diff, float(r.abs().max()) * 2.0 ** -5)
+                assert (diff <= tol).all() and rel <= 5e-3 and same >= 0.4, \
+                    f"{what}: hidden state max diff {diff.max():.3e}, rel L2 {rel:.2e}, {same:.3f} bit-equal"
+            else:
+                assert (diff <= tol).all(), f"{what}: hidden state max diff {diff.max():.3e}, {int((diff > tol).sum())} elements beyond two ulps (rel L2 {rel:.2e}, {same:.3f} bit-equal)"
+                assert same >= 0.99 or o.numel() < 400, f"{what}: only {same:.3f} of the hidden state bit-equal to the reference's"
+            pos += S
+        n, m = r_cache.kv_seq_len_list[0], r_cache.streaming_kv_seq_len_list[0]
+        assert (p_cache.kv_seq_len_list[0], p_cache.streaming_kv_seq_len_list[0]) == (n, m), "counters"
+        ulp_close(p_cache.full_value_states_list[0][:, :n], r_cache.full_value_states_list[0][:, :n], "full V pool", max_frac=0.01)
+        ulp_close(p_cache.streaming_value_states_list[0][:, :m], r_cache.streaming_value_states_list[0][:, :m], "stream V pool", max_frac=0.01)
+    finally:
+        r_llama.flash_attn_func = sdpa_stub
+        if c["fused"]:
+            from oracle.duo_oracle import OracleBackend
+
+            backend._set_backend_for_testing(OracleBackend(round_p=False))
+
+
+_OURS, _REF = {}, {}
 INDEPENDENT_ROPE = False
 KNOWN = __import__("collections").Counter()
 
 
 def _ours():
-    """this repository's package is also called ``duo_attn``: it is loaded under that name from duo-attention_amd/ BEFORE the
-    reference is put on the path under the same name — so the two are kept apart by importing ours first into a private dict
-    and then swapping the ``duo_attn`` entries of sys.modules for the reference's"""
     return _OURS
 
 
 def _load_both():
+    """Both packages are called ``duo_attn``.  Ours is imported first and stays in sys.modules (its functions import lazily
+    by relative name); the reference is imported while ours is hidden, its entry points are kept in ``_REF`` (it has no lazy
+    imports), and its modules are taken out of sys.modules again."""
     import importlib
 
-    # ours first
     import duo_attn.patch._duo as duo
+    import duo_attn.patch.flashinfer_utils as fiu
     import duo_attn.patch.static_kv_cache as skv
     import duo_attn.patch.tuple_kv_cache as tkv
+    import duo_attn.patch.utils as putils
+    import duo_attn.utils as utils
     from duo_attn import backend
     from helpers import ShapeModel
     from oracle.duo_oracle import OracleBackend
@@ -255,15 +385,15 @@ def _load_both():
     backend._set_backend_for_testing(OracleBackend(round_p=False))
     _OURS.update(core=duo.duo_static_attention_core, Cache=skv.DuoAttentionStaticKVCache, ShapeModel=ShapeModel,
                  tuple_fwd=duo.duo_attention_forward_one_way_reordered, release=duo.release_tuple_arena,
-                 hf_rotary=tkv.hf_apply_rotary_pos_emb)
-    import duo_attn.patch.utils as putils
-    import duo_attn.utils as utils
-
-    _OURS.update(sparsify=utils.sparsify_attention_heads, reorder_w=putils.reorder_linear_weights,
-                 reorder_h=putils.reorder_full_attn_heads)
-    mine = {k: v for k, v in sys.modules.items() if k == "duo_attn" or k.startswith("duo_attn.")}
+                 hf_rotary=tkv.hf_apply_rotary_pos_emb, sparsify=utils.sparsify_attention_heads,
+                 reorder_w=putils.reorder_linear_weights, reorder_h=putils.reorder_full_attn_heads,
+                 static_attn_fwd=duo.duo_attention_forward_one_way_reordered_static,
+                 layer_fwd=skv.duo_attn_static_kv_cache_decoder_layer_forward, rmsnorm_fwd=fiu.rmsnorm_forward, duo=duo)
+    is_pkg = lambda k: k == "duo_attn" or k.startswith("duo_attn.")
+    mine = {k: v for k, v in sys.modules.items() if is_pkg(k)}
     for k in mine:
         del sys.modules[k]
+    path0 = list(sys.path)
     sys.path[:] = [p for p in sys.path if not p.endswith("duo-attention_amd")]
     MG.install_shims()                      # puts /root/reference first on the path
     if not INDEPENDENT_ROPE:
@@ -286,7 +416,24 @@ def _load_both():
     import duo_attn as ref_pkg
 
     assert ref_pkg.__file__.startswith(MG.REF), ref_pkg.__file__
-    return mine
+    import duo_attn.patch.flashinfer_utils as r_fiu
+    import duo_attn.patch.llama as r_llama
+    import duo_attn.patch.static_kv_cache as r_skv
+    import duo_attn.patch.utils as r_putils
+    import duo_attn.utils as r_utils
+
+    _REF.update(static_fwd=r_llama.llama_duo_attention_forward_one_way_reordered_static, Cache=r_skv.DuoAttentionStaticKVCache,
+                tuple_fwd=r_llama.llama_duo_attention_forward_one_way_reordered, sparsify=r_utils.sparsify_attention_heads,
+                reorder_w=r_putils.reorder_linear_weights, reorder_h=r_putils.reorder_full_attn_heads,
+                layer_fwd=r_skv.duo_attn_static_kv_cache_llama_decoder_layer_forward, rmsnorm_fwd=r_fiu.flashinfer_rmsnorm_forward,
+                llama_mod=r_llama)
+    for k in [k for k in sys.modules if is_pkg(k)]:
+        del sys.modules[k]
+    sys.modules.update(mine)
+    sys.path[:] = path0
+    import duo_attn as mine_pkg
+
+    assert "duo-attention_amd" in mine_pkg.__file__, mine_pkg.__file__
 
 
 def main():
@@ -301,15 +448,15 @@ def main():
         raise SystemExit("/root/reference is not here: this script runs in the build container only")
     _load_both()
     rng = random.Random(a.seed)
-    t0, n, bad, kinds = time.time(), 0, 0, {"static": 0, "tuple": 0, "utils": 0}
+    t0, n, bad, kinds = time.time(), 0, 0, {"static": 0, "tuple": 0, "utils": 0, "layer": 0}
     with torch.no_grad():
         while time.time() - t0 < a.seconds:
             u = rng.random()
-            c = draw_static(rng) if u < 0.55 else draw_tuple(rng) if u < 0.9 else draw_utils(rng)
+            c = draw_static(rng) if u < 0.45 else draw_tuple(rng) if u < 0.75 else draw_utils(rng) if u < 0.83 else draw_layer(rng)
             n += 1
             kinds[c["kind"]] += 1
             try:
-                {"static": run_static, "tuple": run_tuple, "utils": run_utils}[c["kind"]](c)
+                {"static": run_static, "tuple": run_tuple, "utils": run_utils, "layer": run_layer}[c["kind"]](c)
             except Exception as e:      # noqa: BLE001
                 bad += 1
                 print("FAIL", c, "\n    ", f"{type(e).__name__}: {str(e)[:600]}", flush=True)
