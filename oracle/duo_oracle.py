@@ -32,7 +32,11 @@ Pinning: the reference has no tests or golden vectors.  The oracle 
 pinned against outputs of the REFERENCE'S OWN CODE run in the build container
 with the absent third-party packages stubbed by independent restatements of their
 published semantics — see tests/golden/make_golden.py and
-tests/test_oracle_golden.py.  The attention/RoPE arithmetic itself lives in
+tests/test_oracle_golden.py (five frozen runs), and tests/golden/fuzz_against_reference.py: the
+same construction LIVE over drawn cases — the reference's static forward + cache, tuple forward,
+decoder-layer forward and host utilities next to this oracle and to the product's host path,
+30 490 cases with no difference beyond one bf16 ulp (profiles/r4_oracle_vs_reference_fuzz.txt; a
+20-second slice runs as a CPU test where /root/reference exists).  The attention/RoPE arithmetic itself lives in
 packages that are not under /root/reference, so for that part parity is anchored
 on their documented semantics and cross-checked against
 torch.nn.functional.scaled_dot_product_attention with an explicit mask.
