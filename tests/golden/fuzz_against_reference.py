@@ -357,6 +357,91 @@ def run_layer(c):
             backend._set_backend_for_testing(OracleBackend(round_p=False))
 
 
+def draw_model(rng):
+    Hkv = rng.choice([1, 2, 4])
+    L = rng.randint(1, 3)
+    return dict(kind="model", family=rng.choice(["llama", "mistral"]), Hkv=Hkv, group=rng.choice([1, 2] if Hkv == 4 else [1, 2, 4]), L=L,
+                inter=8 * rng.randint(4, 64), heads=[[float(rng.random() < 0.5) for _ in range(Hkv)] for _ in range(L)],
+                sink=rng.choice([2, 4, 16]), recent=rng.choice([4, 8, 32]), B=rng.choice([1, 1, 2]),
+                chunks=[rng.randint(1, 40) for _ in range(rng.randint(1, 3))], decode_steps=rng.randint(1, 4), evict=rng.random() < 0.5,
+                path=rng.choice(["static", "static", "tuple"]), seed=rng.randint(0, 2 ** 31 - 1))
+
+
+def run_model(c):
+    """A whole HuggingFace model through the reference's ENABLERS and model / decoder-layer / attention forwards —
+    ``enable_{llama,mistral}_duo_attention_static_kv_cache_eval`` + ``DuoAttentionStaticKVCache`` driven like
+    eval/efficiency/benchmark_static.py:68-105 (chunked prefill, decode, optional evict_last), or ``enable_duo_attention_eval``
+    with tuple caches — against this package's same-named API on a copy of the same random-init model: the un-reordered
+    pattern goes in, so the weight reordering (patch/utils.py:7-45, llama.py:523-546) is part of what is compared.  RoPE and
+    attention arithmetic are the oracle's on both sides (see run_layer); every logit within two bf16 ulps, >= 99 % bit-equal."""
+    import copy
+
+    import numpy as np
+    from transformers import LlamaConfig, LlamaForCausalLM, MistralConfig, MistralForCausalLM
+
+    from oracle.duo_oracle import flash_attn_func_ref
+
+    ours = _ours()
+    Hq = c["Hkv"] * c["group"]
+    torch.manual_seed(c["seed"])
+    kw = dict(hidden_size=Hq * D, intermediate_size=c["inter"], num_hidden_layers=c["L"], num_attention_heads=Hq,
+              num_key_value_heads=c["Hkv"], head_dim=D, vocab_size=97, max_position_embeddings=2048, rope_theta=10000.0,
+              attn_implementation="eager", tie_word_embeddings=False)
+    base = (LlamaForCausalLM(LlamaConfig(**kw)) if c["family"] == "llama"
+            else MistralForCausalLM(MistralConfig(sliding_window=None, **kw))).to(torch.bfloat16).eval()
+    heads = np.array(c["heads"])
+    B, total = c["B"], sum(c["chunks"]) + c["decode_steps"] + 2
+    ids = torch.randint(0, 97, (B, sum(c["chunks"]) + c["decode_steps"]), generator=torch.Generator().manual_seed(c["seed"] ^ 1))
+
+    def drive(model, make_cache):
+        outs, pos = [], 0
+        past = make_cache(model)
+        for n in list(c["chunks"]) + [1] * c["decode_steps"]:
+            o = model(input_ids=ids[:, pos:pos + n], past_key_values=past, use_cache=True)
+            outs.append(o.logits[:, -1:].float())
+            decode = pos >= sum(c["chunks"])
+            if c["path"] == "tuple":
+                if not (decode and c["evict"]):
+                    past = o.past_key_values
+            elif decode and c["evict"]:
+                past.evict_last(1)
+            if not (decode and c["evict"]):
+                pos += n
+        return torch.cat(outs, 1)
+
+    ref_model, our_model = copy.deepcopy(base), copy.deepcopy(base)
+    r_mod = _REF[c["family"] + "_mod"]
+    # names the reference reads from HF attention modules that transformers 5 dropped (environment shim, like make_golden's)
+    for layer in ref_model.model.layers:
+        a = layer.self_attn
+        a.num_heads, a.num_key_value_heads, a.hidden_size, a.rope_theta = Hq, c["Hkv"], Hq * D, 10000.0
+        a.num_key_value_groups = c["group"]
+        a.rotary_emb = ref_model.model.rotary_emb
+    sdpa_stub = r_mod.flash_attn_func
+    r_mod.flash_attn_func = lambda q, k, v, causal=True, dropout_p=0.0, **kw_: flash_attn_func_ref(q, k, v, causal=causal, round_p=False)
+    try:
+        if c["path"] == "static":
+            getattr(r_mod, f"enable_{c['family']}_duo_attention_static_kv_cache_eval")(ref_model, heads.copy())
+            want = drive(ref_model, lambda m: _REF["Cache"](m, heads, B, total, c["sink"], c["recent"]))
+        else:
+            getattr(r_mod, f"enable_{c['family']}_duo_attention_eval")(ref_model, heads.copy(), c["sink"], c["recent"])
+            want = drive(ref_model, lambda m: None)
+    finally:
+        r_mod.flash_attn_func = sdpa_stub
+    if c["path"] == "static":
+        ours["enable_static"][c["family"]](our_model, heads.copy())
+        got = drive(our_model, lambda m: ours["Cache"](m, heads, B, total, c["sink"], c["recent"]))
+    else:
+        ours["enable_eval"](our_model, heads.copy(), c["sink"], c["recent"])
+        got = drive(our_model, lambda m: None)
+        ours["release"](our_model)
+    diff = (got - want).abs()
+    tol = torch.clamp(torch.maximum(got.abs(), want.abs()) * 2.0 ** -6, min=2e-3 * float(want.pow(2).mean().sqrt()))
+    same = (diff == 0).float().mean().item()
+    rel = float((got - want).norm() / want.norm().clamp_min(1e-9))
+    assert (diff <= tol).all() and same >= 0.99, f"logits: max diff {diff.max():.3e}, rel L2 {rel:.2e}, {same:.4f} bit-equal to the reference's"
+
+
 _OURS, _REF = {}, {}
 INDEPENDENT_ROPE = False
 KNOWN = __import__("collections").Counter()
@@ -389,6 +474,13 @@ def _load_both():
                  reorder_w=putils.reorder_linear_weights, reorder_h=putils.reorder_full_attn_heads,
                  static_attn_fwd=duo.duo_attention_forward_one_way_reordered_static,
                  layer_fwd=skv.duo_attn_static_kv_cache_decoder_layer_forward, rmsnorm_fwd=fiu.rmsnorm_forward, duo=duo)
+    import duo_attn.patch as our_patch
+    import duo_attn.patch.llama as our_llama
+    import duo_attn.patch.mistral as our_mistral
+
+    _OURS.update(enable_static=dict(llama=our_llama.enable_llama_duo_attention_static_kv_cache_eval,
+                                    mistral=our_mistral.enable_mistral_duo_attention_static_kv_cache_eval),
+                 enable_eval=our_patch.enable_duo_attention_eval)
     is_pkg = lambda k: k == "duo_attn" or k.startswith("duo_attn.")
     mine = {k: v for k, v in sys.modules.items() if is_pkg(k)}
     for k in mine:
@@ -426,7 +518,7 @@ def _load_both():
                 tuple_fwd=r_llama.llama_duo_attention_forward_one_way_reordered, sparsify=r_utils.sparsify_attention_heads,
                 reorder_w=r_putils.reorder_linear_weights, reorder_h=r_putils.reorder_full_attn_heads,
                 layer_fwd=r_skv.duo_attn_static_kv_cache_llama_decoder_layer_forward, rmsnorm_fwd=r_fiu.flashinfer_rmsnorm_forward,
-                llama_mod=r_llama)
+                llama_mod=r_llama, mistral_mod=importlib.import_module("duo_attn.patch.mistral"))
     for k in [k for k in sys.modules if is_pkg(k)]:
         del sys.modules[k]
     sys.modules.update(mine)
@@ -448,15 +540,16 @@ def main():
         raise SystemExit("/root/reference is not here: this script runs in the build container only")
     _load_both()
     rng = random.Random(a.seed)
-    t0, n, bad, kinds = time.time(), 0, 0, {"static": 0, "tuple": 0, "utils": 0, "layer": 0}
+    t0, n, bad, kinds = time.time(), 0, 0, {"static": 0, "tuple": 0, "utils": 0, "layer": 0, "model": 0}
     with torch.no_grad():
         while time.time() - t0 < a.seconds:
             u = rng.random()
-            c = draw_static(rng) if u < 0.45 else draw_tuple(rng) if u < 0.75 else draw_utils(rng) if u < 0.83 else draw_layer(rng)
+            c = (draw_static(rng) if u < 0.4 else draw_tuple(rng) if u < 0.65 else draw_utils(rng) if u < 0.72 else draw_layer(rng) if u < 0.86
+                 else draw_model(rng))
             n += 1
             kinds[c["kind"]] += 1
             try:
-                {"static": run_static, "tuple": run_tuple, "utils": run_utils, "layer": run_layer}[c["kind"]](c)
+                {"static": run_static, "tuple": run_tuple, "utils": run_utils, "layer": run_layer, "model": run_model}[c["kind"]](c)
             except Exception as e:      # noqa: BLE001
                 bad += 1
                 print("FAIL", c, "\n    ", f"{type(e).__name__}: {str(e)[:600]}", flush=True)
