@@ -34,8 +34,8 @@ with the absent third-party packages stubbed by independent restatements of thei
 published semantics — see tests/golden/make_golden.py and
 tests/test_oracle_golden.py (five frozen runs), and tests/golden/fuzz_against_reference.py: the
 same construction LIVE over drawn cases — the reference's static forward + cache, tuple forward,
-decoder-layer forward, whole models through its enablers and host utilities next to this oracle and to
-the product's host path, 37 849 cases with no difference beyond one bf16 ulp (profiles/r4_oracle_vs_reference_fuzz.txt; a
+decoder-layer forward, whole models through its enablers, INT4 demo cache and host utilities next to
+this oracle and to the product's host path, 47 766 cases with no difference beyond one bf16 ulp (profiles/r4_oracle_vs_reference_fuzz.txt; a
 20-second slice runs as a CPU test where /root/reference exists).  The attention/RoPE arithmetic itself lives in
 packages that are not under /root/reference, so for that part parity is anchored
 on their documented semantics and cross-checked against
