@@ -55,6 +55,7 @@ def draw_static(rng):
                 sink=rng.choice([1, 2, 4, 16]), recent=rng.choice([1, 3, 8, 32]), B=B,
                 starts=[0] + [rng.randint(0, 9) for _ in range(B - 1)],
                 chunks=[rng.randint(1, 70) for _ in range(rng.randint(1, 4))], decode_steps=rng.randint(0, 4),
+                evict_n=rng.choice([1, 1, 2, 3]), second_prompt=[rng.randint(1, 40) for _ in range(rng.randint(0, 2))],
                 theta=rng.choice([1e4, 5e5, 1e6]), factor=rng.choice([None, None, 2.0, 8.0]), seed=rng.randint(0, 2 ** 31 - 1))
 
 
@@ -73,7 +74,7 @@ def run_static(c):
     Hkv, G, counts, B = c["Hkv"], c["group"], c["counts"], c["B"]
     Hq, L = Hkv * G, len(counts)
     heads = [[1.0] * nf + [0.0] * (Hkv - nf) for nf in counts]
-    total = sum(c["chunks"]) + c["decode_steps"] + 2
+    total = max(sum(c["chunks"]) + c["decode_steps"], sum(c.get("second_prompt", []))) + 2
     model = types.SimpleNamespace(
         config=types.SimpleNamespace(num_hidden_layers=L, num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=Hq * D),
         parameters=lambda: iter([torch.zeros(1, dtype=torch.bfloat16)]))
@@ -84,8 +85,17 @@ def run_static(c):
     factor = 1.0 if c["factor"] is None else c["factor"]
     g = torch.Generator().manual_seed(c["seed"])
     pos = 0
+    # chunked prefill, decode steps each followed by evict_last(n) (n = 1: the benchmark's protocol; n up to 3 rewinds into the
+    # prompt), then — when drawn — clear() and a second prompt through the same caches
     steps = [(S, False) for S in c["chunks"]] + [(1, True)] * c["decode_steps"]
+    if c.get("second_prompt"):
+        steps += [("clear", False)] + [(S, False) for S in c["second_prompt"]]
     for si, (S, evict) in enumerate(steps):
+        if S == "clear":
+            for cache in (r_cache, o_cache, p_cache):
+                cache.clear()
+            pos = 0
+            continue
         position_ids = torch.stack([torch.arange(pos + s0, pos + s0 + S) for s0 in c["starts"]])
         p0 = pos if B == 1 else [pos + s0 for s0 in c["starts"]]
         for l in range(L):
@@ -106,8 +116,12 @@ def run_static(c):
                 ulp_close(cache.streaming_key_states_list[l][:, :m], r_cache.streaming_key_states_list[l][:, :m], f"{what}: {name} stream K pool")
                 assert torch.equal(cache.streaming_value_states_list[l][:, :m], r_cache.streaming_value_states_list[l][:, :m]), f"{what}: {name} stream V pool"
         if evict:
+            n_ev = c.get("evict_n", 1)
             for cache in (r_cache, o_cache, p_cache):
-                cache.evict_last(1)
+                cache.evict_last(n_ev)
+            pos = pos + 1 - n_ev if pos + 1 - n_ev > 0 else 0
+            if r_cache.kv_seq_len == 0:
+                break       # (rewound to an empty cache: the next call would be a first chunk at position 0 — nothing new)
         else:
             pos += S
     for cache in (o_cache, p_cache):
