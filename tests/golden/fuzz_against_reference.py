@@ -61,7 +61,7 @@ def draw_static(rng):
 
 def draw_tuple(rng):
     Hkv = rng.choice([1, 2, 4])
-    return dict(kind="tuple", Hkv=Hkv, group=rng.choice([1, 2, 4]), nf=rng.randint(0, Hkv), sink=rng.choice([1, 4, 16]),
+    return dict(kind="tuple", Hkv=Hkv, group=rng.choice([1, 2, 4]), nf=rng.randint(0, Hkv), sink=rng.choice([1, 4, 16]), B=rng.choice([1, 1, 2, 3]),
                 recent=rng.choice([2, 8, 32]), steps=[rng.randint(1, 60) for _ in range(rng.randint(1, 3))] + [1] * rng.randint(0, 5),
                 theta=rng.choice([1e4, 5e5]), seed=rng.randint(0, 2 ** 31 - 1))
 
@@ -151,22 +151,23 @@ def run_tuple(c):
 
     r_mod, p_mod = module(), module()
     p_mod.config = types.SimpleNamespace(num_attention_heads=Hq, num_key_value_heads=Hkv, hidden_size=Hq * D, rope_scaling=None)
+    B = c.get("B", 1)
     g = torch.Generator().manual_seed(c["seed"])
     r_past, o_past, p_past, pos = None, None, None, 0
     for si, S in enumerate(c["steps"]):
-        h = torch.randn(1, S, Hq * D, generator=g).to(torch.bfloat16)
-        pid = torch.arange(pos, pos + S)[None]
+        h = torch.randn(B, S, Hq * D, generator=g).to(torch.bfloat16)
+        pid = torch.arange(pos, pos + S)[None].expand(B, S)
         want, _, r_past = ref_fwd(r_mod, h.clone(), position_ids=pid, past_key_value=r_past, use_cache=True)
         cos, sin = rotary_emb(h, pid)
-        q = h.clone().view(1, S, Hq, D)
-        k = h[..., : Hkv * D].clone().view(1, S, Hkv, D)
-        v = h[..., Hq * D - Hkv * D:].clone().view(1, S, Hkv, D)
+        q = h.clone().view(B, S, Hq, D)
+        k = h[..., : Hkv * D].clone().view(B, S, Hkv, D)
+        v = h[..., Hq * D - Hkv * D:].clone().view(B, S, Hkv, D)
         q, k = ours["hf_rotary"](q, k, cos, sin, unsqueeze_dim=2)
         got_o, o_past = tuple_forward_ref(q, k, v, o_past, nf, c["sink"], c["recent"], round_p=False)
         what = f"step {si} (S={S}) pos {pos}"
-        ulp_close(got_o.reshape(1, S, Hq * D), want, what + ": oracle output")
+        ulp_close(got_o.reshape(B, S, Hq * D), want, what + ": oracle output")
         got_p, _, p_past = ours["tuple_fwd"](p_mod, h.clone(), past_key_value=p_past, use_cache=True, position_embeddings=(cos, sin))
-        ulp_close(got_p.reshape(1, S, Hq * D), want, what + ": product host path output")
+        ulp_close(got_p.reshape(B, S, Hq * D), want, what + ": product host path output")
         for name, past in (("oracle", o_past), ("product", p_past)):
             assert torch.equal(past[0], r_past[0]), f"{what}: {name} retrieval cache"
             assert torch.equal(past[1], r_past[1]), f"{what}: {name} streaming cache"
