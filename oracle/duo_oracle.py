@@ -35,7 +35,7 @@ published semantics — see tests/golden/make_golden.py and
 tests/test_oracle_golden.py (five frozen runs), and tests/golden/fuzz_against_reference.py: the
 same construction LIVE over drawn cases — the reference's static forward + cache, tuple forward,
 decoder-layer forward, whole models through its enablers, INT4 demo cache and host utilities next to
-this oracle and to the product's host path, 47 766 cases with no difference beyond one bf16 ulp (profiles/r4_oracle_vs_reference_fuzz.txt; a
+this oracle and to the product's host path, 71 343 cases with no difference beyond one bf16 ulp (profiles/r4_oracle_vs_reference_fuzz.txt; a
 20-second slice runs as a CPU test where /root/reference exists).  The attention/RoPE arithmetic itself lives in
 packages that are not under /root/reference, so for that part parity is anchored
 on their documented semantics and cross-checked against
