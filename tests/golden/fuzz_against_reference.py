@@ -383,7 +383,8 @@ def draw_model(rng):
                 inter=8 * rng.randint(4, 64), heads=[[float(rng.random() < 0.5) for _ in range(Hkv)] for _ in range(L)],
                 sink=rng.choice([2, 4, 16]), recent=rng.choice([4, 8, 32]), B=rng.choice([1, 1, 2]),
                 chunks=[rng.randint(1, 40) for _ in range(rng.randint(1, 3))], decode_steps=rng.randint(1, 4), evict=rng.random() < 0.5,
-                path=rng.choice(["static", "static", "tuple"]), seed=rng.randint(0, 2 ** 31 - 1))
+                path=rng.choice(["static", "static", "tuple"]), explicit_positions=rng.random() < 0.3,
+                starts=[rng.randint(0, 9) for _ in range(2)], seed=rng.randint(0, 2 ** 31 - 1))
 
 
 def run_model(c):
@@ -416,7 +417,12 @@ def run_model(c):
         outs, pos = [], 0
         past = make_cache(model)
         for n in list(c["chunks"]) + [1] * c["decode_steps"]:
-            o = model(input_ids=ids[:, pos:pos + n], past_key_values=past, use_cache=True)
+            kw_pos = {}
+            if c.get("explicit_positions") and c["path"] == "static":
+                # the caller's own position ids, one offset per batch row (a left-padded batch): the static forward hands
+                # position_ids[:, 0] to the RoPE kernel (llama.py:347-352)
+                kw_pos["position_ids"] = torch.stack([torch.arange(pos + s0, pos + s0 + n) for s0 in c["starts"][:B]])
+            o = model(input_ids=ids[:, pos:pos + n], past_key_values=past, use_cache=True, **kw_pos)
             outs.append(o.logits[:, -1:].float())
             decode = pos >= sum(c["chunks"])
             if c["path"] == "tuple":
