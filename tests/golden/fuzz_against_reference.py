@@ -383,7 +383,7 @@ def draw_model(rng):
                 inter=8 * rng.randint(4, 64), heads=[[float(rng.random() < 0.5) for _ in range(Hkv)] for _ in range(L)],
                 sink=rng.choice([2, 4, 16]), recent=rng.choice([4, 8, 32]), B=rng.choice([1, 1, 2]),
                 chunks=[rng.randint(1, 40) for _ in range(rng.randint(1, 3))], decode_steps=rng.randint(1, 4), evict=rng.random() < 0.5,
-                path=rng.choice(["static", "static", "tuple"]), explicit_positions=rng.random() < 0.3,
+                path=rng.choice(["static", "static", "tuple", "full"]), explicit_positions=rng.random() < 0.3,
                 starts=[rng.randint(0, 9) for _ in range(2)], seed=rng.randint(0, 2 ** 31 - 1))
 
 
@@ -425,7 +425,7 @@ def run_model(c):
             o = model(input_ids=ids[:, pos:pos + n], past_key_values=past, use_cache=True, **kw_pos)
             outs.append(o.logits[:, -1:].float())
             decode = pos >= sum(c["chunks"])
-            if c["path"] == "tuple":
+            if c["path"] in ("tuple", "full"):
                 if not (decode and c["evict"]):
                     past = o.past_key_values
             elif decode and c["evict"]:
@@ -443,9 +443,19 @@ def run_model(c):
         a.num_key_value_groups = c["group"]
         a.rotary_emb = ref_model.model.rotary_emb
     sdpa_stub = r_mod.flash_attn_func
-    r_mod.flash_attn_func = lambda q, k, v, causal=True, dropout_p=0.0, **kw_: flash_attn_func_ref(q, k, v, causal=causal, round_p=False)
+    # (flash-attn's own signature: flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, ...) — the tuple
+    #  baseline passes dropout positionally, tuple_kv_cache.py:184-191)
+    shared = lambda q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **kw_: flash_attn_func_ref(
+        q, k, v, causal=causal, softmax_scale=softmax_scale, round_p=False)
+    r_mod.flash_attn_func = shared
+    r_tkv = _REF["tuple_kv_mod"]
+    sdpa_stub_t, r_tkv.flash_attn_func = r_tkv.flash_attn_func, shared
     try:
-        if c["path"] == "static":
+        if c["path"] == "full":
+            # the full-attention tuple baseline (tuple_kv_cache.py:38-120, :493-512 / :766-800): no DuoAttention at all
+            r_tkv.enable_tuple_kv_cache(ref_model)
+            want = drive(ref_model, lambda m: None)
+        elif c["path"] == "static":
             getattr(r_mod, f"enable_{c['family']}_duo_attention_static_kv_cache_eval")(ref_model, heads.copy())
             want = drive(ref_model, lambda m: _REF["Cache"](m, heads, B, total, c["sink"], c["recent"]))
         else:
@@ -453,7 +463,11 @@ def run_model(c):
             want = drive(ref_model, lambda m: None)
     finally:
         r_mod.flash_attn_func = sdpa_stub
-    if c["path"] == "static":
+        r_tkv.flash_attn_func = sdpa_stub_t
+    if c["path"] == "full":
+        ours["enable_tuple_full"](our_model)
+        got = drive(our_model, lambda m: None)
+    elif c["path"] == "static":
         ours["enable_static"][c["family"]](our_model, heads.copy())
         got = drive(our_model, lambda m: ours["Cache"](m, heads, B, total, c["sink"], c["recent"]))
     else:
@@ -626,7 +640,7 @@ def _load_both():
     _OURS.update(Int4Cache=our_int4.DuoAttentionStaticINT4KVCache)
     _OURS.update(enable_static=dict(llama=our_llama.enable_llama_duo_attention_static_kv_cache_eval,
                                     mistral=our_mistral.enable_mistral_duo_attention_static_kv_cache_eval),
-                 enable_eval=our_patch.enable_duo_attention_eval)
+                 enable_eval=our_patch.enable_duo_attention_eval, enable_tuple_full=tkv.enable_tuple_kv_cache)
     is_pkg = lambda k: k == "duo_attn" or k.startswith("duo_attn.")
     mine = {k: v for k, v in sys.modules.items() if is_pkg(k)}
     for k in mine:
@@ -664,7 +678,8 @@ def _load_both():
                 tuple_fwd=r_llama.llama_duo_attention_forward_one_way_reordered, sparsify=r_utils.sparsify_attention_heads,
                 reorder_w=r_putils.reorder_linear_weights, reorder_h=r_putils.reorder_full_attn_heads,
                 layer_fwd=r_skv.duo_attn_static_kv_cache_llama_decoder_layer_forward, rmsnorm_fwd=r_fiu.flashinfer_rmsnorm_forward,
-                llama_mod=r_llama, mistral_mod=importlib.import_module("duo_attn.patch.mistral"))
+                llama_mod=r_llama, mistral_mod=importlib.import_module("duo_attn.patch.mistral"),
+                tuple_kv_mod=importlib.import_module("duo_attn.patch.tuple_kv_cache"))
     import importlib.util
     import torch.utils.cpp_extension as cpp_ext
 
