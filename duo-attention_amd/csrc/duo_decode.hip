@@ -868,16 +868,29 @@ static int decode_target_wgs() {
 // holds.  Measured at 131072 context, 32 layers (profiles/r2_decode_wgs.md): 256 workgroups 1.46-1.49 ms per step of
 // scans, 512 (two per CU, the round-1 choice) 1.54 ms, 384 / 640 (not a multiple of the CU count) 1.63-1.66 ms —
 // fewer, longer workgroups amortise the per-workgroup prologue / epilogue and halve the partials to merge.
+//
+// The split count is a function of the length's BUCKET (64-token units rounded up to a power of two), not of the length:
+// every length inside a bucket gets the same grid.  That is what lets a captured decode step (device-side lengths,
+// duo_decode_layer_dev_bf16) stand for the eager one bit for bit while the cache grows — the kernel deals the CURRENT units
+// to the captured workgroups, and the eager plan of any length in the bucket is that same grid — and it tells the graph's
+// owner exactly when a re-capture pays: when duo_decode_plan_bucket() of the length changes (duo_attn/graph.py does).
+static int plan_bucket_units(int L) {
+    int units = (L + 63) / 64, b = 1;
+    while (b < units) b <<= 1;
+    return b;
+}
+extern "C" int32_t duo_decode_plan_bucket(int32_t n_tokens) { return n_tokens <= 0 ? 0 : plan_bucket_units(n_tokens); }
+
 static void choose_splits(int n_kv_heads, int L, int max_splits, int budget_wgs, int &splits) {
     if (n_kv_heads <= 0 || L <= 0) {
         splits = 0;
         return;
     }
-    const int units = (L + 63) / 64;
+    const int bucket = plan_bucket_units(L);        // units <= bucket < 2 * units
     int s = budget_wgs / n_kv_heads;
-    // keep at least 256 tokens per workgroup so its epilogue stays small
-    s = std::min(s, std::max(1, units / 4));
-    s = std::max(1, std::min(s, std::min(units, max_splits)));
+    // keep at least 256 tokens (four units) per workgroup so its epilogue stays small: bucket / 8 < units / 4
+    s = std::min(s, std::max(1, bucket / 8));
+    s = std::max(1, std::min(s, max_splits));
     splits = s;
 }
 

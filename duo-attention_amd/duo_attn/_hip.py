@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 from typing import Optional
 
@@ -16,7 +17,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
-ABI_VERSION = 4
+ABI_VERSION = 5
 HEAD_DIM = 128
 
 
@@ -167,6 +168,7 @@ _SIGNATURES = {
         ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p],
     ),
     "duo_decode_state_add": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "duo_decode_plan_bucket": (c_int32, [c_int32]),
     "duo_decode_layer_batched_dev_bf16": (
         ctypes.c_int, [POINTER(DecodeLayerArgs), POINTER(DecodeBatch), c_void_p, c_void_p, c_int64, c_void_p],
     ),
@@ -489,6 +491,7 @@ _DECODE_MAX_SPLITS = 512
 DECODE_TICKET_BYTES = 4096      # DUO_DECODE_TICKET_BYTES
 _workspaces = {}
 _tickets = {}
+_graph_tickets = []      # weak references to the tickets owned by captured decode steps (scratch_scope)
 
 
 def _stream_key(device: torch.device):
@@ -500,13 +503,37 @@ def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
     """fp32 scratch for the split-KV partials: one buffer per (device, stream, q-head count), allocated once and
     never replaced or freed — concurrent streams do not share partials, and a captured graph's launches keep
     pointing at live memory whatever other models decode later."""
+    cache = _workspaces if _scratch_scope is None else _scratch_scope
     key = _stream_key(device) + (int(n_q_heads),)
-    ws = _workspaces.get(key)
+    ws = cache.get(key)
     if ws is None:
         need = load_library().duo_attn_decode_workspace_bytes(int(n_q_heads), _DECODE_MAX_SPLITS)
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
-        _workspaces[key] = ws
+        cache[key] = ws
     return ws
+
+
+_scratch_scope = None
+
+
+class scratch_scope:
+    """While active, the decode scratch (split-KV partials, arrival tickets) comes from ``owner`` — a dict the caller keeps —
+    instead of the per-(device, stream) caches.  A captured decode step uses it (duo_attn/graph.py): every graph captures on
+    torch's one shared capture stream, so graphs of two caches would otherwise bake the SAME partials buffer into their
+    launches and race when replayed on two streams."""
+
+    def __init__(self, owner: dict):
+        self.owner = owner
+
+    def __enter__(self):
+        global _scratch_scope
+        self.prev, _scratch_scope = _scratch_scope, self.owner
+        return self.owner
+
+    def __exit__(self, *exc):
+        global _scratch_scope
+        _scratch_scope = self.prev
+        return False
 
 
 def release_workspaces(device=None) -> None:
@@ -529,7 +556,8 @@ def check_decode_tickets(device=None) -> None:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     bad = []
-    for key, t in _tickets.items():
+    graph_owned = [((idx, "graph"), t) for t in (r() for r in _graph_tickets) if t is not None and t.device.index == idx]
+    for key, t in list(_tickets.items()) + graph_owned:
         if key[0] == idx and int(t.abs().sum()) != 0:
             bad.append((key, int(t[-1])))
             t.zero_()
@@ -544,6 +572,12 @@ _one_launch_used = False
 def decode_tickets(device: torch.device) -> torch.Tensor:
     """Arrival tickets of the single-launch decode step (duo_decode_step_bf16): zero-filled once per
     (device, stream); every launch leaves them zeroed."""
+    if _scratch_scope is not None:
+        t = _scratch_scope.get("tickets")
+        if t is None:       # (a captured step: allocated while capturing, so the zero fill is part of the graph — harmless)
+            t = _scratch_scope["tickets"] = torch.zeros(DECODE_TICKET_BYTES // 4, dtype=torch.int32, device=device)
+            _graph_tickets.append(weakref.ref(t))
+        return t
     key = _stream_key(device)
     t = _tickets.get(key)
     if t is None:

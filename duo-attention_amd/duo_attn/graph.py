@@ -8,7 +8,12 @@ whole HF model around it the step is host-bound.  Here the lengths also live in 
 whole step — every layer's token-row linears, the two attention launches per layer, the counter update and
 (for the benchmark protocol) ``evict_last`` — is captured ONCE in a HIP graph and replayed per token.
 The captured split-KV grid keeps working as the context grows: its balanced partition deals the *current*
-number of 64-token units to the captured number of workgroups.
+number of 64-token units to the captured number of workgroups.  The library sizes that grid from the length's BUCKET
+(``duo_decode_plan_bucket``: 64-token units rounded up to a power of two), for eager and captured launches alike, so a
+replay equals the eager step bit for bit anywhere inside the bucket — and when the context leaves the captured bucket
+(a long generation from a short prompt; ``clear()`` and a much longer or shorter prompt through the same cache) the step is
+captured again for the new one (``DecodeStepGraph.replay``): a graph captured at 1K tokens never scans a 128K pool with
+the 1K grid.
 
 Two ways in:
 
@@ -38,6 +43,15 @@ def _host_counters(c):
     return (tuple(c.kv_seq_len_list), tuple(c.streaming_kv_seq_len_list))
 
 
+def plan_key(c):
+    """what the library sizes a decode step's split-KV grids from: the bucket of the rows a retrieval head / a streaming head
+    sees in the next step (cached rows + the new one) — include/duo_attn_hip.h, duo_decode_plan_bucket"""
+    from . import _hip
+
+    bucket = _hip.load_library().duo_decode_plan_bucket
+    return (bucket(max(c.kv_seq_len_list) + 1), bucket(max(c.streaming_kv_seq_len_list) + 1))
+
+
 class DecodeStepGraph:
     """``step_fn()`` must run ONE q_len == 1 forward through ``kv_cache`` (the patched model, or any loop
     over ``duo_static_attention_core``) using static input tensors, and may return its output tensor(s).
@@ -53,17 +67,27 @@ class DecodeStepGraph:
         if kv_cache.kv_seq_len < 1:
             raise ValueError("capture the decode step after the prefill (empty cache)")
         self.cache, self.step_fn, self.evict_after = kv_cache, step_fn, int(evict_after)
+        self._scratch = {}      # this graph's own split-KV partials / tickets (_hip.scratch_scope)
+        self.captures = 0
+        self._capture()
+
+    def _capture(self):
+        from . import _hip
+
+        kv_cache = self.cache
         kv_cache.enable_device_state()
         host = (list(kv_cache.kv_seq_len_list), list(kv_cache.streaming_kv_seq_len_list))
+        self.plan_key = plan_key(kv_cache)
         self.graph = torch.cuda.CUDAGraph()
         try:
-            with torch.cuda.graph(self.graph):
+            with _hip.scratch_scope(self._scratch), torch.cuda.graph(self.graph):
                 self.output = self._body()
         finally:
             # capture records launches without running them: device state and pools are untouched, only the
             # host mirror moved while the Python code ran
             kv_cache.kv_seq_len_list[:], kv_cache.streaming_kv_seq_len_list[:] = host
             kv_cache.use_device_state = False
+        self.captures += 1
         kv_cache.sync_device_state()
 
     def _body(self):
@@ -87,12 +111,17 @@ class DecodeStepGraph:
         counters are compared with ``kv_cache._device_counters`` and re-uploaded when they differ (one small H2D
         copy, outside the graph).  The same graph therefore serves prompt after prompt."""
         c = self.cache
-        if _host_counters(c) != c._device_counters:
-            c.sync_device_state()
         if max(c.kv_seq_len_list) + 1 > c.max_size:
             raise ValueError(
                 f"Trying to put 1 KVs into a cache with max size {c.max_size}, current size: {max(c.kv_seq_len_list)}."
             )
+        if plan_key(c) != self.plan_key:
+            # the context left the length bucket the split-KV grid was sized for: capture the step again for this one
+            # (the eager step would plan exactly this grid, so replays stay bit-equal to it); ``self.output`` is the new
+            # capture's tensor from here on
+            self._capture()
+        elif _host_counters(c) != c._device_counters:
+            c.sync_device_state()
         self.graph.replay()
         W = c.sink_size + c.recent_size
         for i in range(c.num_layers):       # the host mirror follows: one step, then the eviction
@@ -121,18 +150,38 @@ class DecodeStepGraph:
 # ------------------------------------------------------------------------------------------------------------------
 # automatic capture for the reference's UNCHANGED decode loop
 # ------------------------------------------------------------------------------------------------------------------
+def _graph_modules(model):
+    """(every module, the modules that own parameters directly) of ``model``, walked ONCE: the per-token signature below
+    reads plain dicts of these (``_parameters``, ``_forward_hooks``) instead of going through ``nn.Module.__getattr__``"""
+    c = model.__dict__.get("_duo_graph_modules")
+    if c is None:
+        mods = list(model.modules())
+        c = model.__dict__["_duo_graph_modules"] = (mods, [m for m in mods if m._parameters])
+    return c
+
+
 def _model_signature(model):
-    """what the captured launches depend on besides the cache: the layers' forwards and weight storage, and the switches
-    that select kernels — a change of any of them retires the captured step"""
+    """what the captured launches depend on besides the cache: the layers' forwards, the storage of EVERY parameter the step
+    reads (q/k/v/o, gate/up/down, the norms, embed_tokens, lm_head — a captured launch bakes the raw pointers in, so a
+    partial ``.data`` swap must retire it too), and the switches that select kernels — a change of any of them retires the
+    captured step"""
     from . import _hip
     from .patch import _duo
 
     sig = [id(model), _duo._FUSED_DECODE_LAYER, int(_hip.load_library().duo_get_debug_flags())]
     for layer in model.model.layers:
-        a = layer.self_attn
-        sig.append((id(getattr(layer.forward, "__func__", None)), id(getattr(a.forward, "__func__", None)),
-                    a.q_proj.weight.data_ptr(), layer.mlp.down_proj.weight.data_ptr()))
+        sig.append((id(getattr(layer.forward, "__func__", None)), id(getattr(layer.self_attn.forward, "__func__", None))))
+    sig.extend(p.data_ptr() for m in _graph_modules(model)[1] for p in m._parameters.values() if p is not None)
     return tuple(sig)
+
+
+def _has_forward_hooks(model) -> bool:
+    """a replay does not re-enter Python: forward (pre-)hooks of any module would silently stop firing after the capture"""
+    import torch.nn.modules.module as nnm
+
+    if nnm._global_forward_hooks or nnm._global_forward_pre_hooks:
+        return True
+    return any(m._forward_hooks or m._forward_pre_hooks for m in _graph_modules(model)[0])
 
 
 def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs_embeds, labels, kwargs) -> bool:
@@ -156,7 +205,11 @@ def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs
         return False
     if torch.cuda.is_current_stream_capturing():
         return False        # somebody else's capture (DecodeStepGraph, a user's graph): this step is part of theirs
-    return getattr(get_backend(), "name", "") == "hip"
+    if _has_forward_hooks(model):
+        return False        # hooks must keep firing every step
+    from .backend import HipBackend
+
+    return type(get_backend()) is HipBackend      # (a wrapped / recording backend observes calls from Python: never captured)
 
 
 def auto_decode_step(model, eager_forward, input_ids, kv):

@@ -438,6 +438,8 @@ def tuple_fused_decode_ok(layer, hidden_states, past_key_value, position_embeddi
         return False
     if hidden_states.stride(2) != 1 or hidden_states.data_ptr() % 16:
         return False
+    if torch.is_grad_enabled() and (hidden_states.requires_grad or layer.self_attn.q_proj.weight.requires_grad):
+        return False        # the ctypes kernels build no autograd graph: the module path does (as tuple_rotary / _hf_norm)
     refs = _fused_refs(layer, duo_attention_forward_one_way_reordered, "tuple")
     if not refs.ok or not _rows_fit(be, refs, 1):
         return False

@@ -45,9 +45,15 @@ def tuple_rotary(q, k, cos, sin):
     on q [B, S, Hq, D] / k [B, S, Hkv, D] fresh from the projections: ONE in-place pass per batch row on the GPU
     (``duo_rope_hf_inplace_bf16``, bit-equal to the torch sequence), the torch sequence itself anywhere else"""
     be = get_backend()
+
+    def _aligned(t):        # what duo_rope_hf_inplace_bf16 accepts: 16-byte aligned rows (base and every stride in elements % 8)
+        return t.data_ptr() % 16 == 0 and all(st % 8 == 0 for st in t.stride()[:-1])
+
     if (hasattr(be, "rope_hf_inplace") and q.is_cuda and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16
-            and cos.dtype == torch.bfloat16 and cos.dim() == 3 and q.shape[-1] == 128 and q.stride(-1) == 1 and k.stride(-1) == 1
+            and cos.dtype == torch.bfloat16 and sin.dtype == torch.bfloat16 and cos.dim() == 3 and sin.shape == cos.shape
+            and q.dim() == 4 and k.dim() == 4 and q.shape[-1] == 128 and q.stride(-1) == 1 and k.stride(-1) == 1
             and cos.shape[0] in (1, q.shape[0]) and cos.is_contiguous() and sin.is_contiguous()
+            and _aligned(q) and _aligned(k) and _aligned(cos) and _aligned(sin)     # (a sliced cached table: torch sequence)
             and not (q.requires_grad or k.requires_grad)):
         for b in range(q.shape[0]):
             cb = cos[b if cos.shape[0] > 1 else 0]

@@ -63,7 +63,7 @@
 extern "C" {
 #endif
 
-#define DUO_ABI_VERSION 4
+#define DUO_ABI_VERSION 5
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
@@ -283,6 +283,11 @@ int duo_stream_compress_batched_bf16(void *k_pool, void *v_pool, int64_t pool_ba
  * full_len / str_len / pos fields of `args` are only planning hints (they size the split-KV grid; the
  * balanced partition in the kernel adapts to the real length), so a captured launch stays valid as the
  * cache grows.  The caller keeps full_len + 1 <= full_capacity.
+ * The split-KV grid of every decode entry point is a function of duo_decode_plan_bucket(visible rows) — the rows' 64-token
+ * units rounded up to a power of two — not of the length itself: a captured launch therefore equals the eager launch of
+ * every length in its bucket bit for bit, and the owner of a graph re-captures when the bucket of full_len + 1 (or of
+ * str_len + 1) leaves the captured one (duo_attn/graph.py does); replaying beyond it stays correct, only the grid is the
+ * shorter context's (ABI v5).
  * duo_decode_state_add advances (or rewinds: evict_last) the states of all layers in one launch:
  *   full_len = max(0, full_len + d_full); str_len = clamp(str_len + d_str, 0, str_cap); pos += d_pos. */
 typedef struct duo_decode_state {
@@ -295,6 +300,7 @@ int duo_decode_layer_dev_bf16(const duo_decode_layer_args *args, const duo_decod
                               void *workspace, int64_t workspace_bytes, void *stream);
 int duo_decode_state_add(duo_decode_state *dev_states, int32_t n_layers, int32_t d_full, int32_t d_str,
                          int32_t d_pos, int32_t str_cap, void *stream);
+int32_t duo_decode_plan_bucket(int32_t n_tokens);
 /* the batched step (duo_decode_layer_batched_bf16) with device-side lengths: every batch row shares the layer's
  * duo_decode_state (the reference keeps ONE counter per layer, static_kv_cache.py:44-45).  args->pos is the HOST's view
  * of dev_state->pos at the time of the call (the cache length); batch row b runs at dev_state->pos + (batch->pos[b] -

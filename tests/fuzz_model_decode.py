@@ -6,8 +6,8 @@ through the drop-in APIs, decode steps in every form the package has —
     tuple path (enable_duo_attention_eval):  module by module  |  fused decode layer
 
 — within a cache format all forms must agree: logits within 2e-2 relative L2 of that format's module-by-module run (the fused
-forms change only the summation order of the projections), greedy tokens >= 90 % equal, graph == eager to 1e-2 (bit-equal
-while the split partition is the captured one); across the two formats a sanity bound only (different arithmetic by design).
+forms change only the summation order of the projections), greedy tokens >= 90 % equal, graph == eager bit for bit (both planned from the
+same length bucket); across the two formats a sanity bound only (different arithmetic by design).
 
     python tests/fuzz_model_decode.py --seconds 120 [--seed 1]"""
 import argparse
@@ -38,7 +38,10 @@ def draw_case(rng):
     heads = [[float(rng.random() < 0.5) for _ in range(Hkv)] for _ in range(L)]
     return dict(family=rng.choice(["llama", "mistral"]), Hkv=Hkv, group=group, inter=8 * rng.randint(8, 300), L=L, heads=heads,
                 bias=rng.random() < 0.3, B=rng.choice([1, 1, 2, 3]), sink=rng.choice([4, 16, 64]), recent=rng.choice([8, 48, 256]),
-                prompt=rng.choice([rng.randint(2, 60), rng.randint(61, 400), rng.randint(401, 900)]), steps=rng.randint(3, 8),
+                # (a third of the prompts end just below a 64 * 2^k-row boundary: the decode steps cross it and the captured
+                #  step is re-captured for the next length bucket, duo_attn/graph.py)
+                prompt=rng.choice([rng.randint(2, 60), rng.randint(61, 400), rng.randint(401, 900),
+                                   rng.choice([64, 128, 256, 512]) - rng.randint(1, 5)]), steps=rng.randint(3, 8),
                 evict=rng.random() < 0.5, seed=rng.randint(0, 2 ** 31 - 1))
 
 
@@ -137,8 +140,10 @@ def run_case(c):
         # within 2e-2, worst 6.2e-2); the semantic equivalence has its own tests with real bars.
         r = _rel(forms["tuple module by module"], ref)
         assert r < 0.15, f"tuple path vs static path: logits rel L2 {r:.3e}"
-    r = _rel(forms["static reference loop, automatic graph"], forms["static fused eager"])
-    assert r < 1e-2, f"automatic graph vs eager: {r:.3e}"
+    # the library plans eager and captured launches from the same length bucket (duo_decode_plan_bucket): the replayed steps
+    # are the eager steps' kernels on the eager steps' grids — bit-equal, also across a bucket boundary
+    assert torch.equal(forms["static reference loop, automatic graph"], forms["static fused eager"]), \
+        f"automatic graph vs eager: rel {_rel(forms['static reference loop, automatic graph'], forms['static fused eager']):.3e}"
 
 
 def main():

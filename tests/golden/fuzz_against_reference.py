@@ -705,6 +705,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cases", type=int, default=0, help="stop after this many drawn cases instead of after --seconds "
+                    "(a fixed workload: the slice run by tests/ does not depend on how loaded the machine is)")
     ap.add_argument("--independent-rope", action="store_true", help="keep make_golden's fp64 RoPE stub inside the reference")
     a = ap.parse_args()
     global INDEPENDENT_ROPE
@@ -715,7 +717,7 @@ def main():
     rng = random.Random(a.seed)
     t0, n, bad, kinds = time.time(), 0, 0, {"static": 0, "tuple": 0, "utils": 0, "layer": 0, "model": 0, "int4": 0}
     with torch.no_grad():
-        while time.time() - t0 < a.seconds:
+        while (n < a.cases) if a.cases > 0 else (time.time() - t0 < a.seconds):
             u = rng.random()
             c = (draw_static(rng) if u < 0.35 else draw_tuple(rng) if u < 0.58 else draw_utils(rng) if u < 0.64 else draw_layer(rng) if u < 0.76
                  else draw_model(rng) if u < 0.9 else draw_int4(rng))

@@ -73,8 +73,10 @@ def test_reference_decode_loop_is_graph_replayed_and_bit_equal_to_eager(family, 
         assert torch.equal(a, b)
     dev = kv_a.device_state.cpu()
     assert dev[:, 0].tolist() == kv_a.kv_seq_len_list and dev[:, 1].tolist() == kv_a.streaming_kv_seq_len_list
-    # uploads only while the graph is built (during the loop's third step); evict_last is mirrored by a launch afterwards
-    assert syncs and all(at == 2 for at in syncs), syncs
+    # uploads only while a graph is built: during the loop's third step, and — the growing loop (60 -> 72 rows) leaves the
+    # 64-row length bucket at its fifth step — during the re-capture there; evict_last is mirrored by a launch afterwards
+    assert syncs and set(syncs) == ({2} if evict else {2, 4}), syncs
+    assert kv_a._decode_graph.captures == (1 if evict else 2)
     # logits handed out earlier are the caller's: a later replay does not overwrite them
     assert not torch.equal(l_a[-1], l_a[-2]) or evict
 
@@ -198,3 +200,194 @@ def test_batched_decode_step_is_capturable(starts, prefill, sink, recent):
     assert cache_g.kv_seq_len_list == cache_e.kv_seq_len_list
     for a, b in zip(_pools(cache_g), _pools(cache_e)):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the captured grid follows the context (length buckets), the signature covers every weight, hooks keep
+# firing, every graph owns its partials
+# ------------------------------------------------------------------------------------------------------------------
+def _decode(model, kv, tok, n, auto, monkeypatch, feed=None):
+    from duo_attn import graph
+
+    monkeypatch.setattr(graph, "AUTO_DECODE_GRAPH", auto)
+    outs = []
+    with torch.no_grad():
+        for i in range(n):
+            o = model(input_ids=tok, past_key_values=kv, use_cache=True)
+            outs.append(o.logits.clone())
+            tok = o.logits[:, -1, :].argmax(dim=-1).unsqueeze(1) if feed is None else feed[:, i:i + 1]
+    return outs
+
+
+def test_plan_bucket_is_the_power_of_two_of_the_64_token_units():
+    from duo_attn import _hip
+
+    b = _hip.load_library().duo_decode_plan_bucket
+    assert [b(n) for n in (-3, 0, 1, 64, 65, 128, 129, 256, 257, 131072, 131073, 3300000)] == \
+        [0, 0, 1, 1, 2, 2, 4, 4, 8, 2048, 4096, 65536]
+
+
+def test_the_step_is_captured_again_when_the_context_leaves_its_length_bucket(monkeypatch):
+    """A generation that grows through two bucket boundaries (64 and 128 rows), then ``clear()`` and a much shorter prompt
+    through the same cache: the step is re-captured each time the library would plan another split-KV grid
+    (``DecodeStepGraph.captures``), and EVERY step — before, at and after a boundary — is bit-equal to the eager loop, whose
+    launches are planned from the same bucket.  (Before: a graph captured at a short context kept its grid for good.)"""
+    from duo_attn import graph
+
+    ids = torch.randint(0, 211, (1, 400), generator=torch.Generator().manual_seed(7)).to(DEV)
+    model, kv = _setup("llama", max_size=300)
+    ref_model, ref_kv = _setup("llama", max_size=300)
+    with torch.no_grad():
+        for m, c in ((model, kv), (ref_model, ref_kv)):
+            t = m(input_ids=ids[:, :58], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+    feed = ids[:, 100:190]                                       # teacher-forced: both loops see the same tokens
+    got = _decode(model, kv, t, 90, True, monkeypatch, feed)
+    want = _decode(ref_model, ref_kv, t, 90, False, monkeypatch, feed)
+    for s, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"step {s} (cache length {58 + s})"
+    g = kv._decode_graph
+    assert g is not None and ref_kv._decode_graph is None
+    assert g.captures == 3, g.captures                           # at 60 rows, past 64 rows, past 128 rows
+    assert g.plan_key == graph.plan_key(kv) == (4, 2)            # 148 rows -> 3 units -> 4; window 64 + 1 rows -> 2
+    for c in (kv, ref_kv):
+        c.clear()
+    with torch.no_grad():
+        for m, c in ((model, kv), (ref_model, ref_kv)):
+            t = m(input_ids=ids[:, 200:220], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+    got = _decode(model, kv, t, 5, True, monkeypatch)
+    want = _decode(ref_model, ref_kv, t, 5, False, monkeypatch)
+    for s, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"second prompt, step {s}"
+    assert kv._decode_graph is g and g.captures == 4 and g.plan_key == (1, 1)
+    for a, b in zip(_pools(kv), _pools(ref_kv)):
+        assert torch.equal(a, b)
+
+
+def test_llama3_geometry_long_context_the_default_decode_path_equals_eager(monkeypatch):
+    """Llama-3-8B head geometry (32 q / 8 kv heads, two layers), 40 000-token context prefilled in 8 192-token chunks, the
+    reference's decode loop with ``evict_last(1)``: the path users get by default (automatic graph) against the eager loop,
+    bit for bit — first captured at a 100-token context, then serving the long one through the same cache (the capture
+    follows the bucket: this is the case where the short context's grid would scan a 40 000-row pool with one workgroup per
+    kv head)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    from duo_attn import graph
+    from duo_attn.patch.llama import DuoAttentionStaticKVCache, enable_llama_duo_attention_static_kv_cache_eval
+
+    torch.manual_seed(5)
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, vocab_size=128, max_position_embeddings=1048576, rope_theta=3580165449.0,
+                      attn_implementation="eager", tie_word_embeddings=False)
+    heads = np.array([[1.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0], [1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 1.0, 0.0]])
+    N, C = 40000, 8192
+    ids = torch.randint(0, 128, (1, N + 100), generator=torch.Generator().manual_seed(6)).to(DEV)
+
+    def run(auto):
+        monkeypatch.setattr(graph, "AUTO_DECODE_GRAPH", auto)
+        torch.manual_seed(5)
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval().to(DEV)
+        enable_llama_duo_attention_static_kv_cache_eval(model, heads.copy())
+        kv = DuoAttentionStaticKVCache(model, heads, 1, N + 16, 128, 256)
+        logits = []
+        with torch.no_grad():
+            pred = model(input_ids=ids[:, N:N + 100], past_key_values=kv, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+            for _ in range(4):                                   # a short context first
+                logits.append(model(input_ids=pred, past_key_values=kv, use_cache=True).logits.clone())
+                kv.evict_last(1)
+            short_key = graph.plan_key(kv)
+            kv.clear()
+            for lo in range(0, N, C):
+                out = model(input_ids=ids[:, lo:min(lo + C, N)], past_key_values=kv, use_cache=True)
+            pred = out.logits[:, -1, :].argmax(-1).unsqueeze(1)
+            for _ in range(6):                                   # the reference's loop, benchmark_static.py:96-105
+                logits.append(model(input_ids=pred, past_key_values=kv, use_cache=True).logits.clone())
+                kv.evict_last(1)
+        torch.cuda.synchronize()
+        return logits, kv, short_key
+
+    l_a, kv_a, short_key = run(True)
+    l_e, kv_e, _ = run(False)
+    assert kv_e._decode_graph is None and kv_a._decode_graph is not None
+    assert short_key == (2, 2) and kv_a._decode_graph.plan_key == (1024, 8) and kv_a._decode_graph.captures == 2
+    for s, (a, b) in enumerate(zip(l_a, l_e)):
+        assert torch.isfinite(a).all() and torch.equal(a, b), f"step {s}"
+    for a, b in zip(_pools(kv_a), _pools(kv_e)):
+        assert torch.equal(a, b)
+
+
+def test_a_partial_weight_swap_retires_the_captured_step(monkeypatch):
+    """the signature covers the storage of EVERY parameter the step reads, not only q_proj / down_proj: swapping the ``.data``
+    of one k_proj, one norm and the lm_head (new storage, new values) after the capture re-captures the step — a replay of the
+    old graph would read the old (freed) storage — and the result equals the eager loop on an identically modified model"""
+    ids = torch.randint(0, 211, (1, 60), generator=torch.Generator().manual_seed(8)).to(DEV)
+    model, kv = _setup("mistral")
+    ref_model, ref_kv = _setup("mistral")
+    with torch.no_grad():
+        for m, c in ((model, kv), (ref_model, ref_kv)):
+            t = m(input_ids=ids[:, :50], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+    for a, b in zip(_decode(model, kv, t, 5, True, monkeypatch), _decode(ref_model, ref_kv, t, 5, False, monkeypatch)):
+        assert torch.equal(a, b)
+    g1 = kv._decode_graph
+    assert g1 is not None
+    gen = torch.Generator().manual_seed(9)
+    for pick in (lambda m: m.model.layers[1].self_attn.k_proj.weight, lambda m: m.model.layers[2].post_attention_layernorm.weight,
+                 lambda m: m.lm_head.weight):
+        new = (torch.randn(pick(model).shape, generator=gen) * 0.05).to(torch.bfloat16).to(DEV)
+        for m in (model, ref_model):
+            pick(m).data = new.clone()
+    a5, b5 = _decode(model, kv, t, 5, True, monkeypatch), _decode(ref_model, ref_kv, t, 5, False, monkeypatch)
+    assert kv._decode_graph is not None and kv._decode_graph is not g1, "the swap did not retire the captured step"
+    for s, (a, b) in enumerate(zip(a5, b5)):
+        assert torch.equal(a, b), f"step {s} after the swap"
+
+
+def test_forward_hooks_keep_firing(monkeypatch):
+    """a replay does not re-enter Python, so a model with a forward (pre-)hook on any module is decoded eagerly — the hook
+    sees every step; once it is removed the loop is captured"""
+    ids = torch.randint(0, 211, (1, 50), generator=torch.Generator().manual_seed(10)).to(DEV)
+    model, kv = _setup("llama")
+    fired = []
+    h = model.model.layers[1].mlp.register_forward_hook(lambda mod, a, out: fired.append(1))
+    with torch.no_grad():
+        t = model(input_ids=ids[:, :40], past_key_values=kv, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+    n0 = len(fired)
+    _decode(model, kv, t, 6, True, monkeypatch)
+    assert len(fired) == n0 + 6 and kv._decode_graph is None
+    h.remove()
+    _decode(model, kv, t, 6, True, monkeypatch)
+    assert kv._decode_graph is not None
+
+
+def test_every_captured_step_owns_its_split_kv_partials(monkeypatch):
+    """every capture runs on torch's one shared capture stream: the graphs of two caches must not bake the same partials
+    buffer into their launches (they could be replayed on two streams at once).  Two models, two caches, both captured:
+    disjoint scratch, and replays on two streams issued back to back still equal the eager loops."""
+    ids = torch.randint(0, 211, (1, 700), generator=torch.Generator().manual_seed(12)).to(DEV)
+    pairs, refs = [_setup("llama", seed=31 + i, max_size=720) for i in range(2)], [_setup("llama", seed=31 + i, max_size=720) for i in range(2)]
+    toks = []
+    with torch.no_grad():
+        for (m, c), (rm, rc) in zip(pairs, refs):
+            toks.append(m(input_ids=ids[:, :650], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1))
+            rm(input_ids=ids[:, :650], past_key_values=rc, use_cache=True)
+    for (m, c), t in zip(pairs, toks):          # 650 rows: the retrieval heads are split, the partials buffer is in use
+        _decode(m, c, t, 3, True, monkeypatch, ids[:, 650:653])
+    g = [c._decode_graph for _, c in pairs]
+    assert all(x is not None for x in g)
+    bufs = [[t for t in x._scratch.values()] for x in g]
+    assert bufs[0] and bufs[1]
+    assert not {t.data_ptr() for t in bufs[0]} & {t.data_ptr() for t in bufs[1]}
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    torch.cuda.synchronize()
+    from duo_attn import graph
+    monkeypatch.setattr(graph, "AUTO_DECODE_GRAPH", True)
+    with torch.no_grad():
+        for s in range(8):
+            for i, ((m, c), st) in enumerate(zip(pairs, streams)):
+                with torch.cuda.stream(st):
+                    got[i].append(m(input_ids=ids[:, 652 + s:653 + s], past_key_values=c, use_cache=True).logits)
+    torch.cuda.synchronize()
+    for i, ((rm, rc), t) in enumerate(zip(refs, toks)):
+        want = _decode(rm, rc, t, 11, False, monkeypatch, ids[:, 650:661])[3:]
+        for s, (a, b) in enumerate(zip(got[i], want)):
+            assert torch.equal(a, b), f"model {i}, step {s}"

@@ -109,7 +109,7 @@ def test_static_path_on_gpu_matches_hf(family):
     assert cache.kv_seq_len == 700
 
 
-def test_graph_captured_generation_matches_eager():
+def test_graph_captured_generation_matches_eager(eager_decode_steps):
     """Whole patched HF model, greedy generation: DecodeStepGraph (one captured step, device-side cache
     lengths, the sampled token fed back inside the graph) produces the same tokens and logits as the eager
     loop, across the streaming window's fill -> slide transition."""

@@ -129,9 +129,10 @@ def _tiny(family, seed):
 
 
 @pytest.mark.parametrize("family,bsz", [("llama", 1), ("mistral", 1), ("llama", 2)])
-def test_fused_decode_layer_matches_module_by_module(family, bsz):
+def test_fused_decode_layer_matches_module_by_module(family, bsz, eager_decode_steps):
     """the same patched model, the same prefill, then decode steps with the fused layer form and module by module:
-    logits within the bf16 noise of three layers, caches written identically up to the projection's rounding"""
+    logits within the bf16 noise of three layers, caches written identically up to the projection's rounding
+    (eager steps: the test counts the token-row linear launches of every step from Python)"""
     from duo_attn.patch import _duo
 
     mod = __import__(f"duo_attn.patch.{family}", fromlist=["x"])

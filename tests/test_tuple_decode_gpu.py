@@ -277,3 +277,49 @@ def test_hf_rmsnorm_kernel_matches_the_transformers_module(rows, hidden):
     assert ((got.float() - want.float()).abs() <= 2.0 ** -7 * want.float().abs() + 1e-30).all()
     on_gpu = norm.to(DEV)(x.to(DEV)).cpu()
     assert (got == on_gpu).float().mean() >= 0.995
+
+
+def test_gradients_enabled_keep_the_tuple_decode_on_the_module_path():
+    """the fused tuple step runs ctypes kernels that build no autograd graph, so a q_len == 1 step taken with
+    gradients enabled on a model whose parameters require grad goes module by module (as tuple_rotary / _hf_norm already
+    decide for themselves); under no_grad the same call is the fused one"""
+    from duo_attn import backend
+    from duo_attn.patch import enable_duo_attention_eval
+
+    model = tiny("llama", seed=13)
+    enable_duo_attention_eval(model, np.array([[0.0, 1.0], [1.0, 1.0], [0.0, 0.0]]), 16, 48)
+    assert model.model.layers[0].self_attn.q_proj.weight.requires_grad
+    ids = torch.randint(0, 211, (1, 40), generator=torch.Generator().manual_seed(14)).to(DEV)
+    rec = Counting(backend.HipBackend())
+    backend._set_backend_for_testing(rec)
+    try:
+        with torch.no_grad():
+            past = model(input_ids=ids[:, :30], past_key_values=None, use_cache=True).past_key_values
+        with torch.enable_grad():
+            o = model(input_ids=ids[:, 30:31], past_key_values=past, use_cache=True)
+        assert rec.n_prep == 0 and rec.n_linear == 0
+        with torch.no_grad():
+            o2 = model(input_ids=ids[:, 30:31], past_key_values=past, use_cache=True)
+        assert rec.n_prep == 3 and rec.n_linear == 12
+    finally:
+        backend._set_backend_for_testing(None)
+    assert _rel(o2.logits, o.logits.detach()) < 1e-2
+
+
+def test_tuple_rotary_falls_back_on_cos_sin_rows_the_kernel_cannot_take():
+    """cos / sin that are contiguous but not 16-byte aligned (a slice of a cached table at an odd offset) used to
+    reach duo_rope_hf_inplace_bf16, which refuses them (DUO_EINVAL -> DuoHipError); now the torch sequence runs — same values"""
+    from duo_attn.patch.tuple_kv_cache import hf_apply_rotary_pos_emb, tuple_rotary
+
+    g = torch.Generator().manual_seed(15)
+    rn = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+    q, k = rn(1, 5, 4, D_), rn(1, 5, 2, D_)
+    table = rn(2, 1 + 5 * D_)
+    cos, sin = table[0, 1:].view(1, 5, D_), table[1, 1:].view(1, 5, D_)       # contiguous, data_ptr % 16 == 2
+    assert cos.is_contiguous() and cos.data_ptr() % 16 != 0
+    wq, wk = hf_apply_rotary_pos_emb(q.clone(), k.clone(), cos, sin, unsqueeze_dim=2)
+    gq, gk = tuple_rotary(q.clone(), k.clone(), cos, sin)
+    assert torch.equal(gq, wq) and torch.equal(gk, wk)
+    # aligned rows of the same values: the kernel path, bit-equal to the sequence
+    aq, ak = tuple_rotary(q.clone(), k.clone(), cos.clone(), sin.clone())
+    assert torch.equal(aq, wq) and torch.equal(ak, wk)
