@@ -234,6 +234,16 @@ def _decode_step_fused(be, query_states, key_states, value_states, kv_cache, lay
 _FUSED_DECODE_LAYER = os.environ.get("DUO_FUSED_DECODE_LAYER", "1") != "0"     # (0: module by module, for A/B)
 
 
+def modules_hooked(mods) -> bool:
+    """whether a forward (pre-)hook is registered on any of ``mods`` (or globally): the fused forms go around these modules'
+    ``__call__`` — with a hook on one of them the step takes the module sequence, so the hook fires as it does in the reference"""
+    import torch.nn.modules.module as nnm
+
+    if nnm._global_forward_hooks or nnm._global_forward_pre_hooks:
+        return True
+    return any(getattr(m, "_forward_hooks", None) or getattr(m, "_forward_pre_hooks", None) for m in mods)
+
+
 def _row_parallel(m):
     """a tensor-parallel shard's o_proj / down_proj (duo_attn/tp.py: RowParallelLinear): the local slice + the group"""
     return type(m).__name__ == "RowParallelLinear" and hasattr(m, "inner") and hasattr(m, "group")
@@ -277,7 +287,7 @@ class _FusedRefs:
     their ``.data`` may be swapped (weight reorder), the launch reads ``data_ptr()`` at call time."""
 
     __slots__ = ("key", "ok", "attn", "qkv", "o", "gu", "down", "n_w", "n_eps", "n_hf", "p_w", "p_eps", "p_hf", "dims", "inter",
-                 "in_feats", "fits")
+                 "in_feats", "fits", "bypassed")
 
 
 
@@ -336,6 +346,7 @@ def _fused_refs(layer, want_fwd=None, tag="static"):
     lin = lambda m: (m.inner if _row_parallel(m) else m)
     wb = lambda m: (lin(m).weight, lin(m).bias)
     r.attn = attn
+    r.bypassed = [attn, mlp, n_ln, p_ln] + [x for m in mods for x in ((m, m.inner) if _row_parallel(m) else (m,))]   # modules_hooked
     r.qkv = [wb(attn.q_proj), wb(attn.k_proj), wb(attn.v_proj)]
     r.gu = [wb(mlp.gate_proj), wb(mlp.up_proj)]
     r.o, r.down = attn.o_proj, mlp.down_proj            # (modules: _out_linear decides plain / row-parallel)
@@ -375,7 +386,7 @@ def fused_decode_layer_ok(layer, hidden_states, kv_cache, layer_idx) -> bool:
     if hidden_states.stride(2) != 1 or hidden_states.stride(0) % 8 or hidden_states.data_ptr() % 16:
         return False                       # (the kernel's 16-byte row loads)
     refs = _fused_refs(layer)
-    return refs.ok and _rows_fit(be, refs, hidden_states.shape[0])
+    return refs.ok and _rows_fit(be, refs, hidden_states.shape[0]) and not modules_hooked(refs.bypassed)
 
 
 def _norm_kw(hf: bool):
@@ -441,7 +452,7 @@ def tuple_fused_decode_ok(layer, hidden_states, past_key_value, position_embeddi
     if torch.is_grad_enabled() and (hidden_states.requires_grad or layer.self_attn.q_proj.weight.requires_grad):
         return False        # the ctypes kernels build no autograd graph: the module path does (as tuple_rotary / _hf_norm)
     refs = _fused_refs(layer, duo_attention_forward_one_way_reordered, "tuple")
-    if not refs.ok or not _rows_fit(be, refs, 1):
+    if not refs.ok or not _rows_fit(be, refs, 1) or modules_hooked(refs.bypassed):
         return False
     pf, ps = past_key_value
     if not (torch.is_tensor(pf) and torch.is_tensor(ps) and pf.dim() == 4 and ps.dim() == 4 and pf.shape[0] == 2

@@ -428,13 +428,16 @@ def duo_attn_static_kv_cache_decoder_layer_forward(
 def _mlp_forward(mlp, x):
     """HF LlamaMLP / MistralMLP: ``down_proj(act_fn(gate_proj(x)) * up_proj(x))`` with the activation product as ONE
     elementwise pass (duo_silu_mul_bf16) instead of a SiLU kernel and a multiply — same roundings; anything that is not a
-    SiLU-gated bf16 MLP on the GPU (or a backend without the kernel) runs the module as it is"""
+    SiLU-gated bf16 MLP on the GPU (or a backend without the kernel, or an MLP / activation module carrying a forward hook —
+    the bypass would not fire it) runs the module as it is"""
     from ..backend import get_backend
+    from ._duo import modules_hooked
 
     be = get_backend()
     if (hasattr(be, "silu_mul") and x.is_cuda and x.dtype == torch.bfloat16
             and type(getattr(mlp, "act_fn", None)).__name__ in ("SiLUActivation", "SiLU")
-            and all(hasattr(mlp, n) for n in ("gate_proj", "up_proj", "down_proj"))):
+            and all(hasattr(mlp, n) for n in ("gate_proj", "up_proj", "down_proj"))
+            and not modules_hooked((mlp, mlp.act_fn))):
         g, u = mlp.gate_proj(x), mlp.up_proj(x)
         # (the kernel moves 16-byte pieces: inner dimension a multiple of 8, unit inner stride, 16-byte aligned rows —
         #  anything else takes torch's two kernels, same roundings)

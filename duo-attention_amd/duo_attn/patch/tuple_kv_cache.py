@@ -69,9 +69,9 @@ def _hf_norm(norm, x):
     be = get_backend()
     if (hasattr(be, "rmsnorm_hf") and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0
             and not x.requires_grad):
-        from ._duo import _norm_form
+        from ._duo import _norm_form, modules_hooked
 
-        if _norm_form(norm) == "hf":
+        if _norm_form(norm) == "hf" and not modules_hooked((norm,)):
             return be.rmsnorm_hf(x, norm.weight, norm.variance_epsilon)
     return norm(x)
 

@@ -346,16 +346,43 @@ def test_forward_hooks_keep_firing(monkeypatch):
     sees every step; once it is removed the loop is captured"""
     ids = torch.randint(0, 211, (1, 50), generator=torch.Generator().manual_seed(10)).to(DEV)
     model, kv = _setup("llama")
+    ref_model, ref_kv = _setup("llama")
     fired = []
+    # (the MLP module is one the package's forwards go AROUND — SwiGLU product fused on chunks, the whole layer fused on
+    #  decode steps: with a hook on it they call the module instead, as the reference does)
     h = model.model.layers[1].mlp.register_forward_hook(lambda mod, a, out: fired.append(1))
     with torch.no_grad():
         t = model(input_ids=ids[:, :40], past_key_values=kv, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
-    n0 = len(fired)
-    _decode(model, kv, t, 6, True, monkeypatch)
-    assert len(fired) == n0 + 6 and kv._decode_graph is None
+        ref_model(input_ids=ids[:, :40], past_key_values=ref_kv, use_cache=True)
+    assert len(fired) == 1
+    got = _decode(model, kv, t, 6, True, monkeypatch, ids[:, 40:46])         # (teacher-forced: both models see the same tokens)
+    assert len(fired) == 1 + 6 and kv._decode_graph is None
     h.remove()
-    _decode(model, kv, t, 6, True, monkeypatch)
-    assert kv._decode_graph is not None
+    got += _decode(model, kv, t, 6, True, monkeypatch, ids[:, 44:50])
+    assert len(fired) == 7 and kv._decode_graph is not None
+    # one layer ran module by module while hooked: logits within the projections' summation-order noise of the unhooked model
+    want = _decode(ref_model, ref_kv, t, 6, False, monkeypatch, ids[:, 40:46]) + _decode(ref_model, ref_kv, t, 6, False, monkeypatch, ids[:, 44:50])
+    for a, b in zip(got, want):
+        assert ((a.float() - b.float()).norm() / b.float().norm()).item() < 2e-2
+
+
+def test_forward_hooks_fire_on_the_tuple_path_too():
+    from duo_attn.patch import enable_duo_attention_eval
+
+    model = tiny("mistral", seed=17)
+    enable_duo_attention_eval(model, np.array([[0.0, 1.0], [1.0, 1.0], [0.0, 0.0]]), 16, 48)
+    ids = torch.randint(0, 211, (1, 40), generator=torch.Generator().manual_seed(18)).to(DEV)
+    fired = {"mlp": 0, "norm": 0, "o": 0}
+    hs = [model.model.layers[0].mlp.register_forward_hook(lambda *a: fired.__setitem__("mlp", fired["mlp"] + 1)),
+          model.model.layers[1].input_layernorm.register_forward_pre_hook(lambda *a: fired.__setitem__("norm", fired["norm"] + 1)),
+          model.model.layers[2].self_attn.o_proj.register_forward_hook(lambda *a: fired.__setitem__("o", fired["o"] + 1))]
+    with torch.no_grad():
+        past = model(input_ids=ids[:, :30], past_key_values=None, use_cache=True).past_key_values
+        for t in range(30, 35):
+            past = model(input_ids=ids[:, t:t + 1], past_key_values=past, use_cache=True).past_key_values
+    assert fired == {"mlp": 6, "norm": 6, "o": 6}, fired
+    for h in hs:
+        h.remove()
 
 
 def test_every_captured_step_owns_its_split_kv_partials(monkeypatch):
