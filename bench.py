@@ -925,6 +925,7 @@ def main():
     handoff = torch.device("cpu") if shared else device
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver stack
         if shared:
             dist.init_process_group("gloo")
         else:
