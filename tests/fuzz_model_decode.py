@@ -126,7 +126,8 @@ def run_case(c):
         r = _rel(lg, to)
         agree = (lg.argmax(-1) == to.argmax(-1)).float().mean().item()
         assert r < 2e-2, f"{name}: logits rel L2 {r:.3e} from {to_name}"
-        assert agree >= 0.9 or lg.shape[0] * lg.shape[1] < 10, f"{name}: greedy tokens agree with {to_name} on {agree:.2f}"
+        # (>= 0.9 up to float32 rounding of the mean: 9 of 10 tokens is 0.89999998)
+        assert agree >= 0.9 - 1e-6 or lg.shape[0] * lg.shape[1] < 10, f"{name}: greedy tokens agree with {to_name} on {agree:.2f}"
 
     close("static fused eager", forms["static fused eager"], ref, "the module-by-module static run")
     close("static reference loop, automatic graph", forms["static reference loop, automatic graph"], ref, "the module-by-module static run")
