@@ -150,45 +150,47 @@ class DecodeStepGraph:
 # ------------------------------------------------------------------------------------------------------------------
 # automatic capture for the reference's UNCHANGED decode loop
 # ------------------------------------------------------------------------------------------------------------------
-def _graph_modules(model):
-    """(every module, the modules that own parameters directly) of ``model``, walked ONCE: the per-token signature below
-    reads plain dicts of these (``_parameters``, ``_forward_hooks``) instead of going through ``nn.Module.__getattr__``"""
-    c = model.__dict__.get("_duo_graph_modules")
-    if c is None:
-        mods = list(model.modules())
-        c = model.__dict__["_duo_graph_modules"] = (mods, [m for m in mods if m._parameters])
-    return c
+def _walk(model):
+    """ONE pass over the module tree as it is NOW (plain ``_modules`` / ``_parameters`` / hook dicts — no
+    ``nn.Module.__getattr__``, ~0.2 ms for a 32-layer model): (whether any module carries a forward (pre-)hook, the storage
+    address of every parameter).  Walked per decode call rather than cached, so a replaced sub-module or a re-pointed
+    parameter cannot hide behind a stale list."""
+    import torch.nn.modules.module as nnm
+
+    hooked = bool(nnm._global_forward_hooks or nnm._global_forward_pre_hooks)
+    ptrs, stack = [], [model]
+    while stack:
+        m = stack.pop()
+        if m._forward_hooks or m._forward_pre_hooks:
+            hooked = True
+        for p in m._parameters.values():
+            if p is not None:
+                ptrs.append(p.data_ptr())
+        if m._modules:
+            stack.extend(c for c in m._modules.values() if c is not None)
+    return hooked, tuple(ptrs)
 
 
-def _model_signature(model):
+def _model_signature(model, param_ptrs=None):
     """what the captured launches depend on besides the cache: the layers' forwards, the storage of EVERY parameter the step
     reads (q/k/v/o, gate/up/down, the norms, embed_tokens, lm_head — a captured launch bakes the raw pointers in, so a
-    partial ``.data`` swap must retire it too), and the switches that select kernels — a change of any of them retires the
-    captured step"""
+    partial ``.data`` swap or a replaced module must retire it too), and the switches that select kernels — a change of any
+    of them retires the captured step"""
     from . import _hip
     from .patch import _duo
 
     sig = [id(model), _duo._FUSED_DECODE_LAYER, int(_hip.load_library().duo_get_debug_flags())]
     for layer in model.model.layers:
         sig.append((id(getattr(layer.forward, "__func__", None)), id(getattr(layer.self_attn.forward, "__func__", None))))
-    sig.extend(p.data_ptr() for m in _graph_modules(model)[1] for p in m._parameters.values() if p is not None)
+    sig.append(_walk(model)[1] if param_ptrs is None else param_ptrs)
     return tuple(sig)
-
-
-def _has_forward_hooks(model) -> bool:
-    """a replay does not re-enter Python: forward (pre-)hooks of any module would silently stop firing after the capture"""
-    import torch.nn.modules.module as nnm
-
-    if nnm._global_forward_hooks or nnm._global_forward_pre_hooks:
-        return True
-    return any(m._forward_hooks or m._forward_pre_hooks for m in _graph_modules(model)[0])
 
 
 def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs_embeds, labels, kwargs) -> bool:
     """The reference's decode call ``model(input_ids=pred, past_key_values=kv_cache, use_cache=True)``
     (eval/efficiency/benchmark_static.py:98-102): one token, one batch row, implicit positions, a non-empty static cache on
     this GPU, no gradients, a single-process model on the HIP backend."""
-    from .backend import get_backend
+    from .backend import HipBackend, get_backend
 
     if not AUTO_DECODE_GRAPH or input_ids is None or inputs_embeds is not None or labels is not None or position_ids is not None:
         return False
@@ -205,11 +207,13 @@ def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs
         return False
     if torch.cuda.is_current_stream_capturing():
         return False        # somebody else's capture (DecodeStepGraph, a user's graph): this step is part of theirs
-    if _has_forward_hooks(model):
-        return False        # hooks must keep firing every step
-    from .backend import HipBackend
-
-    return type(get_backend()) is HipBackend      # (a wrapped / recording backend observes calls from Python: never captured)
+    if type(get_backend()) is not HipBackend:
+        return False        # (a wrapped / recording backend observes calls from Python: never captured)
+    hooked, ptrs = _walk(model)
+    if hooked:
+        return False        # a replay does not re-enter Python: hooks must keep firing every step
+    model.__dict__["_duo_param_ptrs"] = ptrs        # (handed to auto_decode_step's signature: one walk per call)
+    return True
 
 
 def auto_decode_step(model, eager_forward, input_ids, kv):
@@ -218,7 +222,7 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
     HBM (``kv.device_state``), ``kv.evict_last`` rewinds them with a launch, an eager prefill in between re-uploads them.
     Returns the logits (a fresh tensor per call), or None when this call should run eagerly."""
     st = getattr(kv, "_auto_graph", None)
-    sig = _model_signature(model)
+    sig = _model_signature(model, model.__dict__.pop("_duo_param_ptrs", None))
     if st is None or st["sig"] != sig:
         st = {"sig": sig, "calls": 0, "graph": None, "tok": None}
         kv._auto_graph = st

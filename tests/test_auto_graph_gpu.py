@@ -339,6 +339,17 @@ def test_a_partial_weight_swap_retires_the_captured_step(monkeypatch):
     assert kv._decode_graph is not None and kv._decode_graph is not g1, "the swap did not retire the captured step"
     for s, (a, b) in enumerate(zip(a5, b5)):
         assert torch.equal(a, b), f"step {s} after the swap"
+    # a REPLACED module (new object, new parameter): the module tree is walked per call, not cached
+    g2 = kv._decode_graph
+    w = (torch.randn(model.lm_head.weight.shape, generator=gen) * 0.05).to(torch.bfloat16).to(DEV)
+    for m in (model, ref_model):
+        head = torch.nn.Linear(w.shape[1], w.shape[0], bias=False, dtype=torch.bfloat16, device=DEV)
+        head.weight.data = w.clone()
+        m.lm_head = head
+    a5, b5 = _decode(model, kv, t, 4, True, monkeypatch), _decode(ref_model, ref_kv, t, 4, False, monkeypatch)
+    assert kv._decode_graph is not None and kv._decode_graph is not g2, "the replaced lm_head did not retire the captured step"
+    for s, (a, b) in enumerate(zip(a5, b5)):
+        assert torch.equal(a, b), f"step {s} after the module replacement"
 
 
 def test_forward_hooks_keep_firing(monkeypatch):
