@@ -248,3 +248,100 @@ def test_cfg5_int4_decode_3m_tokens(mode):
     err = (o - r).abs()
     tol = 1e-3 * r.abs() + 2.0 ** -10 * r.abs() + 2.0 ** -10 * bud + 1e-3 * r.pow(2).mean().sqrt()
     assert torch.isfinite(o).all() and (err <= tol).all(), f"max err {err.max():.3e}"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# size-independent properties at the bench workload's own size (131072 cached rows): identities the attention obeys whatever
+# the data, checked between two runs of the SAME kernel — no reference needed, so they hold at sizes no oracle finishes
+# ----------------------------------------------------------------------------------------------------------------------
+def _segments(S, g, nf=2, ns=2, G=4, N=131072, W=384):
+    """one later-chunk call (S new rows on N cached ones): q, the two head classes' segments, as the static forward builds them"""
+    q = _randn((S, (nf + ns) * G, D), g)
+    fk, fv = _pool(nf, N + S, g), _pool(nf, N + S, g)
+    sk, sv = _pool(ns, W, g), _pool(ns, W, g)
+    kn, vn = _pool(ns, S, g), _pool(ns, S, g)
+
+    def call(fv_=fv, sv_=sv, vn_=vn, fk_=fk, q_=q):
+        out = torch.empty_like(q_)
+        full = (nf, 0, (fk_[:N], fv_[:N]), (fk_[N:], fv_[N:]))
+        stream = (ns, nf * G, (sk, sv_), (kn, vn_))
+        _be().attention(q_, out, G, full, stream, D ** -0.5)
+        torch.cuda.synchronize()
+        return out
+
+    return call, dict(q=q, fk=fk, fv=fv, sk=sk, sv=sv, kn=kn, vn=vn, nf=nf, ns=ns, G=G, N=N)
+
+
+@pytest.mark.parametrize("S", [1, 768], ids=["decode", "prefill"])
+def test_value_scaling_by_powers_of_two_is_exact_at_128k(S):
+    """attention is linear in V, and a power-of-two factor is exact in bf16 and in the fp32 accumulators: out(4 V) == 4 out(V)
+    and out(-V) == -out(V) BIT FOR BIT — split-KV decode over 131072 rows (partials and their merge included) and MFMA
+    prefill rows attending to 131072 + 768 keys (bf16 P included: P does not depend on V)"""
+    g = torch.Generator(device=DEV).manual_seed(21 + S)
+    call, t = _segments(S, g)
+    base = call()
+    assert torch.isfinite(base).all() and base.float().abs().max() < 1e3
+    for f in (4.0, -1.0, 0.125):
+        got = call(fv_=t["fv"] * f, sv_=t["sv"] * f, vn_=t["vn"] * f)
+        assert torch.equal(got, base * f), f"factor {f}: {(got.float() - base.float() * f).abs().max():.3e}"
+
+
+@pytest.mark.parametrize("S", [1, 768], ids=["decode", "prefill"])
+def test_heads_do_not_see_each_other_at_128k(S):
+    """a kv head's q heads depend on that head's K / V only: replacing the K and V rows of ONE retrieval head and ONE
+    streaming head leaves every other q head's output bit-identical (no partial, tile or workspace slot is shared across
+    heads), and changes the replaced heads' own outputs"""
+    g = torch.Generator(device=DEV).manual_seed(23 + S)
+    call, t = _segments(S, g)
+    base = call()
+    G, nf = t["G"], t["nf"]
+    fk2, fv2, sv2 = t["fk"].clone(), t["fv"].clone(), t["sv"].clone()
+    fk2[:, 1] = _randn(fk2[:, 1].shape, g)
+    fv2[:, 1] = _randn(fv2[:, 1].shape, g)
+    sv2[:, 0] = _randn(sv2[:, 0].shape, g)
+    got = call(fk_=fk2, fv_=fv2, sv_=sv2)
+    touched = list(range(1 * G, 2 * G)) + list(range(nf * G, (nf + 1) * G))
+    same = [h for h in range(base.shape[1]) if h not in touched]
+    assert torch.equal(got[:, same], base[:, same])
+    assert not torch.equal(got[:, touched], base[:, touched])
+
+
+def test_cached_rows_of_a_retrieval_head_may_come_in_any_order_at_128k():
+    """softmax attention over a SET of keys: a decode step over the 131072 cached rows of a retrieval head and over the same
+    rows permuted (K and V together) agree up to the order of the fp32 sums — one bf16 ulp of the output"""
+    g = torch.Generator(device=DEV).manual_seed(25)
+    call, t = _segments(1, g)
+    base = call()
+    N = t["N"]
+    perm = torch.randperm(N, generator=g, device=DEV)
+    fk2, fv2 = t["fk"].clone(), t["fv"].clone()
+    fk2[:N], fv2[:N] = t["fk"][:N][perm], t["fv"][:N][perm]
+    got = call(fk_=fk2, fv_=fv2)
+    nq = t["nf"] * t["G"]
+    a, b = got[:, :nq].float(), base[:, :nq].float()
+    assert ((a - b).abs() <= b.abs() * 2.0 ** -7 + 1e-3 * b.pow(2).mean().sqrt()).all(), (a - b).abs().max()
+    assert torch.equal(got[:, nq:], base[:, nq:])          # the streaming heads' inputs did not change
+
+
+def test_retrieval_heads_do_not_depend_on_the_chunk_size_at_128k():
+    """SURVEY §8(c) property (ii): a retrieval head's row attends to keys {0 .. its position} whatever the chunking — the last
+    1024 rows of a 131072-token prompt computed as the tail of a 16384-row chunk (past 114688) and as a 1024-row chunk of their
+    own (past 130048) agree within the two runs' independent bf16-P rounding noise"""
+    be = _be()
+    g = torch.Generator(device=DEV).manual_seed(27)
+    nf, G, T, big, small = 2, 4, 131072, 16384, 1024
+    scale = D ** -0.5
+    q = _randn((big, nf * G, D), g)
+    fk, fv = _pool(nf, T, g), _pool(nf, T, g)
+
+    def run(S):
+        past = T - S
+        out = torch.empty(S, nf * G, D, device=DEV, dtype=torch.bfloat16)
+        be.attention(q[big - S:], out, G, (nf, 0, (fk[:past], fv[:past]), (fk[past:], fv[past:])), None, scale)
+        torch.cuda.synchronize()
+        return out[S - small:].float()
+
+    a, b = run(big), run(small)
+    rms = b.pow(2).mean().sqrt()
+    assert (a - b).pow(2).mean().sqrt() <= 3.6e-3 * rms          # sqrt(2) x the 2.5e-3 bar each run holds against exact P
+    assert ((a - b).abs() <= 2.0 ** -6 * b.abs() + 3e-2 * rms).all(), (a - b).abs().max()     # (~9 sigma of that noise)
