@@ -275,13 +275,15 @@ def _segments(S, g, nf=2, ns=2, G=4, N=131072, W=384):
 @pytest.mark.parametrize("S", [1, 768], ids=["decode", "prefill"])
 def test_value_scaling_by_powers_of_two_is_exact_at_128k(S):
     """attention is linear in V, and a power-of-two factor is exact in bf16 and in the fp32 accumulators: out(4 V) == 4 out(V)
-    and out(-V) == -out(V) BIT FOR BIT — split-KV decode over 131072 rows (partials and their merge included) and MFMA
-    prefill rows attending to 131072 + 768 keys (bf16 P included: P does not depend on V)"""
+    BIT FOR BIT — split-KV decode over 131072 rows (partials and their merge included) and MFMA prefill rows attending to
+    131072 + 768 keys (bf16 P included: P does not depend on V).  The decode's scalar fp32 FMAs are sign-symmetric as well
+    (out(-V) == -out(V)); the matrix cores are NOT — measured here: negating V moves single output bits of the MFMA path
+    (the accumulation inside v_mfma does not round sign-symmetrically) — so the prefill case is held to exponent shifts."""
     g = torch.Generator(device=DEV).manual_seed(21 + S)
     call, t = _segments(S, g)
     base = call()
     assert torch.isfinite(base).all() and base.float().abs().max() < 1e3
-    for f in (4.0, -1.0, 0.125):
+    for f in ((4.0, -1.0, 0.125) if S == 1 else (4.0, 0.125, 2.0 ** -6)):
         got = call(fv_=t["fv"] * f, sv_=t["sv"] * f, vn_=t["vn"] * f)
         assert torch.equal(got, base * f), f"factor {f}: {(got.float() - base.float() * f).abs().max():.3e}"
 
