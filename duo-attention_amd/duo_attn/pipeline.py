@@ -9,13 +9,13 @@ link (no all-reduce / all-to-all anywhere on the inference path).
 
 Chunk-level pipelining is what makes prefill scale: chunk c on stage s depends only on chunk c
 from stage s-1 and chunk c-1 on stage s, so with n chunks and P stages the makespan is
-(n + P - 1) chunk-stage slots instead of n*P.  In that (feed-forward) mode the send of item i and the
-receive of item i+1 are issued as ONE ``batch_isend_irecv`` group, so neither waits behind the other on
-the rank's in-order RCCL communicator and a stage computes item i+1 while item i leaves.  (Where the backend hands back
-one request per operation — gloo — the receive is waited for before computing and the send only before its buffer is
-reused.  RCCL returns ONE request for the coalesced group, so there the wait before item i+1 also covers the send of item
-i: a stage cannot run more than one item ahead of its successor — the depth-1 buffering the double-buffered slots give
-anyway.  This has only ever run over gloo: no RCCL run exists)  Decode at batch 1
+(n + P - 1) chunk-stage slots instead of n*P.  Every hand-off is a plain ``isend`` / ``irecv``: on RCCL each PAIR of ranks has
+its own two-rank communicator (and stream), so a stage's send to its successor and its receive from its predecessor do not queue
+behind each other, and both ends of a hop are on the same communicator by construction (a ``batch_isend_irecv`` group runs on the
+GROUP-wide communicator instead and would never match a plain call at the other end — the form this file had until round 5, on
+the middle stages only; see ``run``).  The receive is waited for before computing, the send only before its buffer is reused
+(double-buffered slots: a stage runs at most one item ahead of its successor).  This has only ever run over gloo: no RCCL run
+exists, see DESIGN §9.  Decode at batch 1
 is strictly sequential across stages (latency = sum of stages + hops); sharding it only multiplies KV
 capacity — this is reported as is.
 
@@ -33,18 +33,6 @@ import torch
 import torch.distributed as dist
 
 from .utils import balanced_layer_split, even_layer_split
-
-
-class _WorkGroup:
-    """the request list of one batch_isend_irecv group behind a single wait()"""
-
-    def __init__(self, works):
-        self.works = list(works)
-
-    def wait(self):
-        for w in self.works:
-            w.wait()
-        self.works = []
 
 
 class LayerPipeline:
@@ -139,30 +127,19 @@ class LayerPipeline:
             if send_work[slot] is not None:
                 send_work[slot].wait()   # the buffer of item i-2 has left
             keep_alive[slot] = y.contiguous()
-            if feedback or self.is_first or i + 1 >= n:
-                # Autoregressive stream: the receive of item i+1 must be issued AFTER the send of item i — RCCL
-                # runs a rank's point-to-point ops in issue order, and a receive posted first would wait on a
-                # token that needs that very send (deadlock).  (First stage / last item: nothing to pair with.)
-                send_work[slot] = dist.isend(keep_alive[slot], dst=next_rank, group=self.group)
-                post_recv(i + 1)
-            else:
-                # Feed-forward stream (prefill): send(i) and recv(i+1) go out as ONE group, so the receive does
-                # not queue behind the send (nor the send behind an earlier receive) on the in-order communicator.
-                nslot = (i + 1) & 1
-                recv_bufs[nslot] = torch.empty(shapes[i + 1], device=device, dtype=dtype)
-                works = dist.batch_isend_irecv([
-                    dist.P2POp(dist.isend, keep_alive[slot], next_rank, group=self.group),
-                    dist.P2POp(dist.irecv, recv_bufs[nslot], prev_rank, group=self.group),
-                ])
-                if len(works) == 2:
-                    # the backend hands back one request per operation (gloo; RCCL returns ONE for the coalesced group):
-                    # wait for the receive before computing and for the send only before its buffer is reused, so a slow
-                    # downstream stage does not hold up this stage's next item
-                    send_work[slot], recv_work[nslot] = works[0], works[1]
-                else:
-                    pair = _WorkGroup(works)
-                    send_work[slot] = pair
-                    recv_work[nslot] = pair
+            # Every hand-off is a PLAIN point-to-point operation.  torch's RCCL/NCCL process group picks the communicator of
+            # a point-to-point call by HOW it is issued: a plain isend / irecv runs on the two-rank communicator of its pair,
+            # one inside batch_isend_irecv on the group-wide communicator — and operations on different communicators never
+            # match.  Until round 5 the feed-forward stream paired send(i) with recv(i+1) in one batch on the middle stages
+            # while the first and the last stage issued plain calls: the two ends of every hop past the first item would have
+            # sat on different communicators on three or more GPUs (gloo, the only transport this had run on, matches by
+            # source and tag alone and cannot show it).  Plain calls also give what the pairing was for: the send to the next
+            # stage and the receive from the previous one are on different pair communicators, each with its own stream, so
+            # neither queues behind the other.
+            # Order: the receive of item i+1 is posted AFTER the send of item i — in the autoregressive stream the token that
+            # item i+1 waits for needs that very send, and within a pair operations run in issue order.
+            send_work[slot] = dist.isend(keep_alive[slot], dst=next_rank, group=self.group)
+            post_recv(i + 1)
         for w in send_work:
             if w is not None:
                 w.wait()

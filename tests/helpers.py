@@ -70,3 +70,93 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
         f"at ref {r.flatten()[err.argmax()]:.3e}, rms {rms:.3e}"
     )
     assert err_rms <= 2.5e-3 * rms, f"{what}: rms err {err_rms:.3e} vs rms(ref) {rms:.3e}"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# point-to-point discipline of a multi-process run (what gloo cannot show, RCCL would hang on)
+# ----------------------------------------------------------------------------------------------------------------------
+class P2PAudit:
+    """Records every torch.distributed point-to-point call of this process together with the COMMUNICATOR torch's RCCL/NCCL
+    process group would run it on: a plain ``send / recv / isend / irecv`` uses the two-rank communicator of its pair, the
+    same call inside ``batch_isend_irecv`` the group-wide one (ProcessGroupNCCL::pointToPoint: ``batchP2P`` selects the
+    device key, a single operation the send-recv key) — and operations on different communicators never match.  gloo
+    matches by source and tag alone, so a run over gloo cannot reveal a send issued one way and its receive the other;
+    ``check_p2p_logs`` over the gathered logs can.
+
+        with P2PAudit() as log: ...run...; logs = [None] * world; dist.all_gather_object(logs, log.calls); check_p2p_logs(logs)
+    """
+
+    def __init__(self):
+        self.calls = []         # (direction "send" | "recv", global peer rank, "pair" | "group")
+        self._batched = False
+        self._inside = False
+
+    def __enter__(self):
+        import torch.distributed as dist
+        import torch.distributed.distributed_c10d as c10d
+
+        self._mods, self._saved = (dist, c10d), {}
+
+        def put(name, fn):
+            for m in self._mods:        # both names: P2POp validates its op against distributed_c10d's own globals
+                setattr(m, name, fn)
+
+        def wrap(name, direction, peer_kw):
+            orig = getattr(c10d, name)
+            self._saved[name] = orig
+
+            def f(tensor, *a, **kw):
+                peer = kw.get(peer_kw)
+                if peer is None:
+                    peer = kw.get("group_" + peer_kw, a[0] if a else None)
+                    if kw.get("group") is not None and kw.get("group_" + peer_kw) is not None:
+                        peer = dist.get_global_rank(kw["group"], peer)
+                if self._inside:        # send() / recv() are built on isend() / irecv() in some torch versions: one record
+                    return orig(tensor, *a, **kw)
+                self.calls.append((direction, int(peer), "group" if self._batched else "pair"))
+                self._inside = True
+                try:
+                    return orig(tensor, *a, **kw)
+                finally:
+                    self._inside = False
+
+            f.__name__ = name
+            put(name, f)
+
+        for n, d, k in (("send", "send", "dst"), ("isend", "send", "dst"), ("recv", "recv", "src"), ("irecv", "recv", "src")):
+            wrap(n, d, k)
+        orig_batch = c10d.batch_isend_irecv
+        self._saved["batch_isend_irecv"] = orig_batch
+
+        def batch(ops):      # the calls it makes (through the wrapped isend / irecv) are group-communicator operations
+            self._batched = True
+            try:
+                return orig_batch(ops)
+            finally:
+                self._batched = False
+
+        put("batch_isend_irecv", batch)
+        return self
+
+    def __exit__(self, *exc):
+        for n, o in self._saved.items():
+            for m in self._mods:
+                setattr(m, n, o)
+        return False
+
+
+def check_p2p_logs(logs):
+    """``logs[r]`` = P2PAudit.calls of global rank r.  For every ordered pair (src -> dst): as many sends as receives, and
+    the i-th send runs on the same kind of communicator as the i-th receive."""
+    world = len(logs)
+    n_hops = 0
+    for src in range(world):
+        for dst in range(world):
+            sends = [k for d, p, k in logs[src] if d == "send" and p == dst]
+            recvs = [k for d, p, k in logs[dst] if d == "recv" and p == src]
+            assert len(sends) == len(recvs), f"{src} -> {dst}: {len(sends)} sends, {len(recvs)} receives"
+            for i, (a, b) in enumerate(zip(sends, recvs)):
+                assert a == b, (f"hop {src} -> {dst}, operation {i}: the send runs on the {a} communicator, its receive on the {b} "
+                                f"communicator — they would never match on RCCL/NCCL")
+            n_hops += len(sends)
+    return n_hops

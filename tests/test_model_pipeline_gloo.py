@@ -79,6 +79,15 @@ def _reference_run():
 
 def _worker(rank, world, port, mode, q):
     _setup_paths()
+    from helpers import P2PAudit
+
+    # every point-to-point call of the run is recorded with the communicator RCCL would run it on; the logs are compared hop
+    # by hop at the end (helpers.check_p2p_logs: gloo cannot show a send issued one way and its receive the other)
+    with P2PAudit() as audit:
+        _worker_body(rank, world, port, mode, q, audit)
+
+
+def _worker_body(rank, world, port, mode, q, audit):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -125,6 +134,11 @@ def _worker(rank, world, port, mode, q):
             toks = [int(t) for t in out[0]]
             step_logits = [x.float().numpy() for x in lg]
             assert kv.kv_seq_len == N_PROMPT + N_NEW
+        from helpers import check_p2p_logs
+
+        logs = [None] * world
+        dist.all_gather_object(logs, list(audit.calls))
+        assert check_p2p_logs(logs) >= (world - 1) * (N_PROMPT // CHUNK + N_NEW)
         if rank == world - 1:
             q.put((prefill_logits, toks, step_logits))
         elif mode == "drop_in":

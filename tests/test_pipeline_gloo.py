@@ -1,7 +1,7 @@
 """Layer pipeline (duo_attn/pipeline.py) on CPU: world_size 2 and 3, gloo backend.
 
 Covers the N>1 path of bench.py by construction: the even layer split, the item streaming with
-paired batch_isend_irecv hand-offs / asynchronous sends, and the sharded hot path (each rank owns the dual KV
+plain point-to-point hand-offs (asynchronous sends, receives posted one item ahead), and the sharded hot path (each rank owns the dual KV
 pools of its layers) against a single-process run.  The oracle is the device backend here.
 """
 import os
@@ -59,8 +59,14 @@ def _sample(y):
     return y.float().abs().argmax().reshape(1, 1).to(torch.int64) % 97
 
 
-def _worker(rank, world, port, counts, chunks, q, subgroups=None):
+def _worker(rank, world, port, counts, chunks, q, subgroups=None, audit=False, _audit_log=None):
     _setup_paths()
+    if audit:
+        from helpers import P2PAudit, check_p2p_logs
+
+        with P2PAudit() as log:
+            _worker(rank, world, port, counts, chunks, q, subgroups, _audit_log=log)
+        return
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -106,6 +112,15 @@ def _worker(rank, world, port, counts, chunks, q, subgroups=None):
             return stage(j, torch.roll(inputs[j], tok["t"], dims=-1) if x is None else x, 1)
 
         outs += pipe.run([(1, 1, Hq * D)] * (len(chunks) - n_pre), dec, device="cpu", token_feedback=feedback)
+        if _audit_log is not None:
+            # what RCCL would need and gloo cannot show: both ends of every hop issued the same way (helpers.P2PAudit)
+            from helpers import check_p2p_logs
+
+            logs = [None] * world
+            dist.all_gather_object(logs, list(_audit_log.calls))
+            n_hops = check_p2p_logs(logs)
+            if pipe.is_last:
+                q.put(("audit", n_hops, sorted({k for lg in logs for _, _, k in lg})))
         if pipe.is_last:
             q.put([o.float().numpy() for o in outs])
         dist.barrier()
@@ -174,6 +189,46 @@ def test_sharded_hot_path_equals_single_process(world, counts):
     assert len(got) == len(expected)
     for a, b in zip(got, expected):
         assert (a == b).all()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_both_ends_of_every_hop_run_on_the_same_communicator(world):
+    """torch's RCCL/NCCL process group runs a plain isend / irecv on the two-rank communicator of its pair and a call inside
+    batch_isend_irecv on the group-wide communicator; operations on different communicators never match.  Until round 5 the
+    middle stages of the prefill stream paired send(i) with recv(i+1) in a batch while the first and last stage issued plain
+    calls — invisible over gloo (it matches by source and tag), a hang on three or more GPUs.  The audit records how every
+    point-to-point call of every rank was issued and checks hop by hop that sender and receiver agree."""
+    counts = [1, 2, 0, 1, 1, 2][: world + 2]
+    chunks = [9, 7, 5, 6, 1, 1, 1]
+    expected = _single_process(counts, chunks)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, counts, chunks, q, None, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tag, n_hops, kinds = q.get(timeout=240)
+    got = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # 7 items over world - 1 hops, + 2 token hops back (3 decode tokens: the last needs none)
+    assert tag == "audit" and n_hops == 7 * (world - 1) + 2 and kinds == ["pair"]
+    for a, b in zip(got, expected):
+        assert (a == b).all()
+
+
+def test_the_audit_catches_a_mixed_hop():
+    """the audit itself: a plain send met by a batched receive is reported"""
+    from helpers import check_p2p_logs
+
+    ok = [[("send", 1, "pair")], [("recv", 0, "pair"), ("send", 2, "group")], [("recv", 1, "group")]]
+    assert check_p2p_logs(ok) == 2
+    bad = [[("send", 1, "pair"), ("send", 1, "pair")], [("recv", 0, "pair"), ("recv", 0, "group")]]
+    with pytest.raises(AssertionError, match="never match"):
+        check_p2p_logs(bad)
+    with pytest.raises(AssertionError, match="1 sends, 0 receives"):
+        check_p2p_logs([[("send", 1, "pair")], []])
 
 
 def test_balanced_layer_split():
