@@ -159,4 +159,15 @@ def check_p2p_logs(logs):
                 assert a == b, (f"hop {src} -> {dst}, operation {i}: the send runs on the {a} communicator, its receive on the {b} "
                                 f"communicator — they would never match on RCCL/NCCL")
             n_hops += len(sends)
+    # and inside one pair communicator operations run in issue order on BOTH ranks, a send completing only against the
+    # receive posted opposite it: the two ranks' sequences on the pair must mirror each other (send facing receive at every
+    # position) — two sends facing each other wait for receives queued behind them.  (The autoregressive stream on two
+    # stages — items one way, tokens back on the same pair — is the case that exercises it.)
+    for a in range(world):
+        for b in range(a + 1, world):
+            sa = [d for d, p, k in logs[a] if p == b and k == "pair"]
+            sb = [d for d, p, k in logs[b] if p == a and k == "pair"]
+            assert len(sa) == len(sb), f"pair ({a}, {b}): {len(sa)} vs {len(sb)} operations"
+            for i, (x, y) in enumerate(zip(sa, sb)):
+                assert x != y, f"pair ({a}, {b}), operation {i}: both ranks {x} — neither can complete on an in-order communicator"
     return n_hops

@@ -60,12 +60,14 @@ def _sample(y):
 
 
 def _worker(rank, world, port, counts, chunks, q, subgroups=None, audit=False, _audit_log=None):
+    """every run is audited (helpers.P2PAudit / check_p2p_logs: both ends of every hop issued the same way, pair
+    communicators mirrored); ``audit=True`` additionally reports the hop count to the parent"""
     _setup_paths()
-    if audit:
-        from helpers import P2PAudit, check_p2p_logs
+    if _audit_log is None:
+        from helpers import P2PAudit
 
         with P2PAudit() as log:
-            _worker(rank, world, port, counts, chunks, q, subgroups, _audit_log=log)
+            _worker(rank, world, port, counts, chunks, q, subgroups, audit, _audit_log=log)
         return
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -119,7 +121,7 @@ def _worker(rank, world, port, counts, chunks, q, subgroups=None, audit=False, _
             logs = [None] * world
             dist.all_gather_object(logs, list(_audit_log.calls))
             n_hops = check_p2p_logs(logs)
-            if pipe.is_last:
+            if pipe.is_last and audit:
                 q.put(("audit", n_hops, sorted({k for lg in logs for _, _, k in lg})))
         if pipe.is_last:
             q.put([o.float().numpy() for o in outs])
@@ -229,6 +231,11 @@ def test_the_audit_catches_a_mixed_hop():
         check_p2p_logs(bad)
     with pytest.raises(AssertionError, match="1 sends, 0 receives"):
         check_p2p_logs([[("send", 1, "pair")], []])
+    # counts and kinds agree, but both ranks send first on their in-order pair communicator
+    crossed = [[("send", 1, "pair"), ("recv", 1, "pair")], [("send", 0, "pair"), ("recv", 0, "pair")]]
+    with pytest.raises(AssertionError, match="both ranks send"):
+        check_p2p_logs(crossed)
+    assert check_p2p_logs([[("send", 1, "pair"), ("recv", 1, "pair")], [("recv", 0, "pair"), ("send", 0, "pair")]]) == 2
 
 
 def test_balanced_layer_split():
