@@ -91,6 +91,14 @@ def reference_run(c):
 
 def _worker(rank, c, port, q):
     _setup_paths()
+    from helpers import P2PAudit
+
+    # (how every point-to-point call was issued is recorded and compared hop by hop at the end: helpers.check_p2p_logs)
+    with P2PAudit() as audit:
+        _worker_body(rank, c, port, q, audit)
+
+
+def _worker_body(rank, c, port, q, audit):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     world = c["world"]
@@ -133,6 +141,11 @@ def _worker(rank, c, port, q):
             toks = [out[:, i].tolist() for i in range(out.shape[1])]
             steps = [x.float().numpy() for x in lg]
             assert kv.kv_seq_len == c["prompt"] + c["n_new"]
+        from helpers import check_p2p_logs
+
+        logs = [None] * world
+        dist.all_gather_object(logs, list(audit.calls))
+        check_p2p_logs(logs)
         q.put((rank, prefill_logits, toks, steps))
         dist.barrier()
     except Exception:      # noqa: BLE001
