@@ -1,0 +1,52 @@
+"""Build container only: the reference's OWN efficiency harnesses run VERBATIM against this package.
+
+``eval/efficiency/benchmark_static.py`` (the loop BASELINE.json's metric is defined on) and ``benchmark_dynamic.py`` (the
+tuple-cache / ``enable_duo_attention_eval`` loop) are executed from /root/reference with ``runpy`` — not a line of them is
+copied or edited — while ``import duo_attn`` resolves to THIS package: every name they import, every signature they call and
+every attribute they read has to exist for the script to reach its last line and write ``benchmark_result.txt``
+(tests/golden/run_reference_harness.py: tiny random Llama + tokenizer + head pattern in a temp directory; the CPU oracle as the
+device backend and a "cuda" -> "cpu" shim, because this container has no GPU and the product has no CPU path).
+Skipped where /root/reference does not exist (the GPU box); nothing under -m gpu, smoke() or bench.py reads the reference."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_REF = os.path.isdir("/root/reference/eval/efficiency")
+
+
+def _run(script, tmp_path):
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "golden", "run_reference_harness.py"), script, str(tmp_path)],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:]
+    return dict(x.split(": ", 1) for x in json.loads(line[-1][len("RESULT "):])), r.stdout
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_reference_benchmark_static_runs_unchanged(tmp_path):
+    """benchmark_static.py:20-130 — get_tokenizer / get_model / to_device / load_attn_pattern / sparsify_attention_heads /
+    enable_llama_duo_attention_static_kv_cache_eval / DuoAttentionStaticKVCache(model, heads, 1, max_size, sink, recent) /
+    13 chunked-prefill passes with kv_cache.clear() / 150 decode calls with kv_cache.evict_last(1) / kv_cache.memory_usage"""
+    res, out = _run("benchmark_static.py", tmp_path)
+    assert res["Context length"] == "50" and res["Prefilling chunk size"] == "20" and res["Sparsity"] == "0.5"
+    assert "True Sparsity: 0.5" in out and "torch.Size([1, 49])" in out and "Max size: 54" in out
+    # three layers x (one retrieval head x 54 rows + one streaming head x 16 rows) x 128 dims x bf16 x (K, V) = 107 520 B:
+    # the number the reference's own formula gives on its token-major pools (static_kv_cache.py:299-315)
+    assert res["KV cache memory usage"] == "0.1025 MB"
+    assert float(res["Average generation time"].split()[0]) > 0 and float(res["Average context time"].split()[0]) > 0
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_reference_benchmark_dynamic_runs_unchanged(tmp_path):
+    """benchmark_dynamic.py:17-104 — enable_duo_attention_eval(model, heads, 16, 64), one single-shot prefill with
+    past_key_values=None, outputs.past_key_values handed back for 110 decode calls"""
+    res, out = _run("benchmark_dynamic.py", tmp_path)
+    assert res["Context length"] == "50" and res["Sparsity"] == "0.5"
+    assert "Enabling DuoAttention evaluation using sink size 16 and recent size 64" in out
+    assert float(res["Average generation time"].split()[0]) > 0
