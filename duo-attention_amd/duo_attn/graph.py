@@ -153,7 +153,7 @@ class DecodeStepGraph:
 def _walk(model):
     """ONE pass over the module tree as it is NOW (plain ``_modules`` / ``_parameters`` / hook dicts — no
     ``nn.Module.__getattr__``, ~0.2 ms for a 32-layer model): (whether any module carries a forward (pre-)hook, the storage
-    address of every parameter).  Walked per decode call rather than cached, so a replaced sub-module or a re-pointed
+    address of every parameter and buffer).  Walked per decode call rather than cached, so a replaced sub-module or a re-pointed
     parameter cannot hide behind a stale list."""
     import torch.nn.modules.module as nnm
 
@@ -166,6 +166,9 @@ def _walk(model):
         for p in m._parameters.values():
             if p is not None:
                 ptrs.append(p.data_ptr())
+        for b in m._buffers.values():       # (rotary inv_freq, the registered head pattern: baked into the launches as well)
+            if b is not None:
+                ptrs.append(b.data_ptr())
         if m._modules:
             stack.extend(c for c in m._modules.values() if c is not None)
     return hooked, tuple(ptrs)
