@@ -77,6 +77,53 @@ def cuda_shim():
     torch.cuda.max_memory_allocated = lambda *a, **k: 0
 
 
+def readme_quick_start(work):
+    """the ```python block of the reference's README "Quick Start for DuoAttention" (README.md:119-153), executed as it
+    is printed there — relative model / pattern paths, keyword ``sparsity=0.5``, ``enable_duo_attention_eval(model, heads,
+    sink_size=64, recent_size=256)``, ``model.cuda()`` — then the prefill + greedy decode loop the README describes,
+    through the tuple caches"""
+    import re
+    import shutil
+
+    import numpy as np
+    import torch
+    from transformers import LlamaConfig, LlamaForCausalLM
+
+    text = open(os.path.join(REF, "README.md")).read()
+    block = re.search(r"## Quick Start for DuoAttention.*?```python\n(.*?)```", text, re.S).group(1)
+    model_rel = re.search(r'from_pretrained\(\s*"([^"]+)"', block).group(1)
+    pattern_rel = re.search(r'load_attn_pattern\(\s*"([^"]+)"', block).group(1)
+    # the paths of the snippet, relative to the working directory: a random-init model of the pattern's geometry (32 layers
+    # x 8 kv heads, one q head per kv head) and the reference's own shipped pattern files, copied at run time
+    os.makedirs(os.path.join(work, os.path.dirname(pattern_rel)), exist_ok=True)
+    shutil.copytree(os.path.join(REF, pattern_rel), os.path.join(work, pattern_rel))
+    heads = np.loadtxt(os.path.join(work, pattern_rel, "full_attention_heads.tsv"), delimiter="\t")
+    torch.manual_seed(4)
+    cfg = LlamaConfig(hidden_size=heads.shape[1] * 128, intermediate_size=64, num_hidden_layers=heads.shape[0],
+                      num_attention_heads=heads.shape[1], num_key_value_heads=heads.shape[1], head_dim=128, vocab_size=32,
+                      max_position_embeddings=4096, rope_theta=10000.0, tie_word_embeddings=False)
+    LlamaForCausalLM(cfg).to(torch.bfloat16).save_pretrained(os.path.join(work, model_rel))
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    os.chdir(work)
+    ns = {}
+    exec(compile(block, "reference README.md quick start", "exec"), ns)
+    model, sparsity = ns["model"], ns["sparsity"]
+    ids = torch.randint(0, 32, (1, 333), generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        out = model(input_ids=ids[:, :330], past_key_values=None, use_cache=True)
+        past = out.past_key_values
+        toks = []
+        for t in range(330, 333):
+            out = model(input_ids=ids[:, t:t + 1], past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            toks.append(int(out.logits[0, -1].argmax()))
+    nf = [int((np.asarray(h) > 0.5).sum()) for h in ns["attn_heads"]]
+    shapes_ok = all(past[l][0].shape == (2, nf[l], 333, 128) and past[l][1].shape == (2, heads.shape[1] - nf[l], 64 + 256, 128)
+                    for l in range(heads.shape[0]))
+    print("RESULT " + json.dumps([f"sparsity: {sparsity}", f"retrieval heads: {sum(nf)}", f"cache shapes ok: {shapes_ok}",
+                                  f"finite: {bool(torch.isfinite(out.logits).all())}", f"tokens: {len(toks)}"]))
+
+
 def main():
     script, work = sys.argv[1], sys.argv[2]
     if not os.path.isdir(os.path.join(REF, "eval", "efficiency")):
@@ -93,6 +140,8 @@ def main():
     assert os.path.realpath(duo_attn.__file__).startswith(os.path.realpath(ROOT)), duo_attn.__file__
     backend._set_backend_for_testing(OracleBackend())
     cuda_shim()
+    if script == "README":
+        return readme_quick_start(work)
     out = os.path.join(work, "out")
     sys.argv = [script, "--model_name", mdir, "--attn_load_dir", pdir, "--sparsity", "0.5", "--max_length", "50",
                 "--prefilling_chunk_size", "20", "--device", "cpu", "--output_dir", out, "--seed", "42"]

@@ -50,3 +50,17 @@ def test_reference_benchmark_dynamic_runs_unchanged(tmp_path):
     assert res["Context length"] == "50" and res["Sparsity"] == "0.5"
     assert "Enabling DuoAttention evaluation using sink size 16 and recent size 64" in out
     assert float(res["Average generation time"].split()[0]) > 0
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_reference_readme_quick_start_runs_as_printed(tmp_path):
+    """The ```python block of the reference's README "Quick Start for DuoAttention" (README.md:119-153) is extracted and
+    exec'd as printed — ``from duo_attn.utils import load_attn_pattern, sparsify_attention_heads``, ``from duo_attn.patch
+    import enable_duo_attention_eval``, the keyword call ``sparsify_attention_heads(attn_heads, sparsity=0.5)``,
+    ``enable_duo_attention_eval(model, attn_heads, sink_size=64, recent_size=256)`` — on the reference's own shipped
+    Llama-3-8B-1048k pattern (copied into the temp directory at run time) and a random-init model of its geometry; then a
+    333-token generation through the tuple caches: 128 of 256 kv heads retrieval heads, every layer's cache in the
+    reference's format ``(full [2, nf, N, 128], streaming [2, ns, sink + recent, 128])``"""
+    res, out = _run("README", tmp_path)
+    assert res == {"sparsity": "0.5", "retrieval heads": "128", "cache shapes ok": "True", "finite": "True", "tokens": "3"}
+    assert "Enabling DuoAttention evaluation using sink size 64 and recent size 256" in out
