@@ -32,6 +32,12 @@ FOUND = [
          theta=10000.0, rope_scale=1.0, scale=2.5, B=1, seed=1093887530),
     dict(Hkv=2, group=7, counts=[1, 2], sink=4, recent=32, chunks=[17, 300, 1], row_block=64, decode_steps=3, evict=True,
          theta=500000.0, rope_scale=1.0, scale=1.0, B=2, seed=5),
+    # round 5: low-variance data (x 0.5: a flat softmax whose weights straddle 0.5, where one bf16 rounding is relatively
+    # largest) — the reference's OWN arithmetic (bf16 P, bf16 output) is 2.550e-3 of rms away from exact P on the second
+    # chunk's streaming-only layer, the HIP kernel 2.549e-3: past the 2.5e-3 bar, not past the reference
+    # (fuzz_static_path._no_noisier_than_the_reference_arithmetic)
+    dict(Hkv=1, group=8, counts=[1, 0], sink=64, recent=256, chunks=[1344, 551], row_block=None, decode_steps=4, evict=True,
+         graph=True, theta=500000.0, rope_scale=1.0, scale=0.5, B=1, seed=483580883),
 ]
 
 
