@@ -86,3 +86,30 @@ def test_stub_attention_equals_the_package_binding(S, past):
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and a.float().abs().max() > 0
     assert torch.equal(a, b)
+
+
+def test_stub_token_linear_equals_the_package_binding():
+    """the ``token_linear`` wrapper of INTEGRATION.md §B "The token-row linears either side of it", exec'd as printed (up to
+    its usage sketch) on top of the stub above: q|k|v with the RMSNorm prologue and a bias, and down_proj with the SiLU * up
+    prologue and the residual epilogue — bit for bit what duo_attn/_hip.py's own wrapper returns"""
+    from duo_attn import _hip
+
+    ns = _stub()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = [b for b in re.findall(r"```python\n(.*?)```", doc, flags=re.S) if "def token_linear(" in b]
+    assert len(block) == 1
+    exec(compile(block[0].split("# decoder layer, q_len == 1")[0], "INTEGRATION.md token_linear stub", "exec"), ns)
+    g = torch.Generator().manual_seed(7)
+    rn = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16).to(DEV)
+    h, nw = rn(2, 1024), (torch.rand(1024, generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    blocks = [(rn(512, 1024, sc=1 / 32), rn(512)), (rn(128, 1024, sc=1 / 32), None), (rn(128, 1024, sc=1 / 32), None)]
+    got = ns["token_linear"](h, blocks, norm=(nw, 1e-5))
+    want = _hip.token_linear(h, blocks, norm=(nw, 1e-5))
+    gu, res, wd = rn(2, 2 * 768), rn(2, 1024), rn(1024, 768, sc=1 / 28)
+    got2 = ns["token_linear"](gu[:, :768], [(wd, None)], x2=gu[:, 768:], residual=res)
+    want2 = _hip.token_linear(gu[:, :768], [(wd, None)], x2=gu[:, 768:], residual=res)
+    got3 = ns["token_linear"](h, blocks[1:], norm=(nw, 1e-5), norm_hf=True)
+    want3 = _hip.token_linear(h, blocks[1:], norm=(nw, 1e-5), norm_hf=True)
+    torch.cuda.synchronize()
+    for a, b in ((got, want), (got2, want2), (got3, want3)):
+        assert a.shape == b.shape and torch.isfinite(a).all() and torch.equal(a, b)
