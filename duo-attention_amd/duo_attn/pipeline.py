@@ -9,13 +9,14 @@ link (no all-reduce / all-to-all anywhere on the inference path).
 
 Chunk-level pipelining is what makes prefill scale: chunk c on stage s depends only on chunk c
 from stage s-1 and chunk c-1 on stage s, so with n chunks and P stages the makespan is
-(n + P - 1) chunk-stage slots instead of n*P.  Every hand-off is a plain ``isend`` / ``irecv``: on RCCL each PAIR of ranks has
-its own two-rank communicator (and stream), so a stage's send to its successor and its receive from its predecessor do not queue
-behind each other, and both ends of a hop are on the same communicator by construction (a ``batch_isend_irecv`` group runs on the
-GROUP-wide communicator instead and would never match a plain call at the other end — the form this file had until round 5, on
-the middle stages only; see ``run``).  The receive is waited for before computing, the send only before its buffer is reused
-(double-buffered slots: a stage runs at most one item ahead of its successor).  This has only ever run over gloo: no RCCL run
-exists, see DESIGN §9.  Decode at batch 1
+(n + P - 1) chunk-stage slots instead of n*P.  Every hand-off of the stream is issued through ``batch_isend_irecv`` — so both
+ends of every hop are on the group's own communicator whatever way the process group was initialised (see ``run``) — and on the
+middle stages the send of item i and the receive of item i+1 are ONE group, so neither waits behind the other on the rank's
+in-order communicator and a stage computes item i+1 while item i leaves.  (Where the backend hands back one request per
+operation — gloo — the receive is waited for before computing and the send only before its buffer is reused.  RCCL returns ONE
+request for the coalesced group, so there the wait before item i+1 also covers the send of item i: a stage cannot run more than
+one item ahead of its successor — the depth-1 buffering the double-buffered slots give anyway.  This has only ever run over
+gloo: no RCCL run exists)  Decode at batch 1
 is strictly sequential across stages (latency = sum of stages + hops); sharding it only multiplies KV
 capacity — this is reported as is.
 
@@ -33,6 +34,18 @@ import torch
 import torch.distributed as dist
 
 from .utils import balanced_layer_split, even_layer_split
+
+
+class _WorkGroup:
+    """the request list of one batch_isend_irecv call behind a single wait()"""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
 
 
 class LayerPipeline:
@@ -97,21 +110,36 @@ class LayerPipeline:
         keep_alive = [None, None]   # tensors of in-flight sends
         outs: List[Optional[torch.Tensor]] = []
 
+        # EVERY point-to-point operation of the stream — singletons included — is issued through batch_isend_irecv.
+        # Why: torch's RCCL/NCCL process group picks the COMMUNICATOR of a point-to-point call by how it is issued and by
+        # how the group was initialised: inside a batch it is always the group's own communicator; a plain isend / irecv
+        # runs on the group's communicator when the group was initialised eagerly (init_process_group(device_id=...)) but
+        # on a separate two-rank communicator of its pair otherwise — and operations on different communicators never
+        # match.  Rounds 2-4 paired send(i) with recv(i+1) in a batch on the middle stages while the first / last stage
+        # and the decode stream issued plain calls: correct under eager initialisation (what bench.py uses), a hang on
+        # three or more GPUs for a caller that initialised lazily (gloo, the only transport this had run on, matches by
+        # source and tag alone and shows neither).  With every call batched both ends of every hop are on the group's
+        # communicator in either mode.  That communicator runs a rank's operations IN ISSUE ORDER, which the order of the
+        # calls below respects (a send completes against the receive posted opposite it; see the notes at each site).
+        def p2p(*ops):
+            return dist.batch_isend_irecv([dist.P2POp(fn, t, peer, group=self.group) for fn, t, peer in ops])
+
         def post_recv(i):
             if self.is_first or i >= n:
                 return
             slot = i & 1
             recv_bufs[slot] = torch.empty(shapes[i], device=device, dtype=dtype)
-            recv_work[slot] = dist.irecv(recv_bufs[slot], src=prev_rank, group=self.group)
+            recv_work[slot] = _WorkGroup(p2p((dist.irecv, recv_bufs[slot], prev_rank)))
 
         feedback = token_feedback is not None and self.world_size > 1
+        tok_out = None              # the token tensor of the last stage's in-flight hop back
         post_recv(0)
         for i in range(n):
             slot = i & 1
             x = None
             if feedback and self.is_first and i > 0:
                 tok = torch.empty(shapes[i][0], 1, device=device, dtype=torch.int64)
-                dist.recv(tok, src=last_rank, group=self.group)
+                _WorkGroup(p2p((dist.irecv, tok, last_rank))).wait()
                 token_feedback(i, tok)
             if not self.is_first:
                 recv_work[slot].wait()
@@ -120,26 +148,36 @@ class LayerPipeline:
             if self.is_last:
                 outs.append(y)
                 if feedback and i + 1 < n:
-                    dist.send(token_feedback(i, y), dst=first_rank, group=self.group)
+                    tok_out = token_feedback(i, y).contiguous()
+                    _WorkGroup(p2p((dist.isend, tok_out, first_rank))).wait()
                 post_recv(i + 1)
                 continue
             outs.append(None)
             if send_work[slot] is not None:
                 send_work[slot].wait()   # the buffer of item i-2 has left
             keep_alive[slot] = y.contiguous()
-            # Every hand-off is a PLAIN point-to-point operation.  torch's RCCL/NCCL process group picks the communicator of
-            # a point-to-point call by HOW it is issued: a plain isend / irecv runs on the two-rank communicator of its pair,
-            # one inside batch_isend_irecv on the group-wide communicator — and operations on different communicators never
-            # match.  Until round 5 the feed-forward stream paired send(i) with recv(i+1) in one batch on the middle stages
-            # while the first and the last stage issued plain calls: the two ends of every hop past the first item would have
-            # sat on different communicators on three or more GPUs (gloo, the only transport this had run on, matches by
-            # source and tag alone and cannot show it).  Plain calls also give what the pairing was for: the send to the next
-            # stage and the receive from the previous one are on different pair communicators, each with its own stream, so
-            # neither queues behind the other.
-            # Order: the receive of item i+1 is posted AFTER the send of item i — in the autoregressive stream the token that
-            # item i+1 waits for needs that very send, and within a pair operations run in issue order.
-            send_work[slot] = dist.isend(keep_alive[slot], dst=next_rank, group=self.group)
-            post_recv(i + 1)
+            if feedback or self.is_first or i + 1 >= n:
+                # Autoregressive stream: the receive of item i+1 must be issued AFTER the send of item i — the communicator
+                # runs a rank's operations in issue order, and a receive posted first would wait on a token that needs
+                # that very send (deadlock).  (First stage / last item: nothing to pair with.)
+                send_work[slot] = _WorkGroup(p2p((dist.isend, keep_alive[slot], next_rank)))
+                post_recv(i + 1)
+            else:
+                # Feed-forward stream (prefill): send(i) and recv(i+1) go out as ONE group, so the receive does not queue
+                # behind the send (nor the send behind an earlier receive) on the in-order communicator: a stage computes
+                # item i+1 while item i leaves.
+                nslot = (i + 1) & 1
+                recv_bufs[nslot] = torch.empty(shapes[i + 1], device=device, dtype=dtype)
+                works = p2p((dist.isend, keep_alive[slot], next_rank), (dist.irecv, recv_bufs[nslot], prev_rank))
+                if len(works) == 2:
+                    # the backend hands back one request per operation (gloo; RCCL returns ONE for the coalesced group):
+                    # wait for the receive before computing and for the send only before its buffer is reused, so a slow
+                    # downstream stage does not hold up this stage's next item
+                    send_work[slot], recv_work[nslot] = _WorkGroup(works[:1]), _WorkGroup(works[1:])
+                else:
+                    # one request for the pair: the wait before item i+1 also covers the send of item i — a stage cannot run
+                    # more than one item ahead of its successor, the depth the double-buffered slots give anyway
+                    send_work[slot] = recv_work[nslot] = _WorkGroup(works)
         for w in send_work:
             if w is not None:
                 w.wait()

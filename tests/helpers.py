@@ -77,9 +77,11 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
 # ----------------------------------------------------------------------------------------------------------------------
 class P2PAudit:
     """Records every torch.distributed point-to-point call of this process together with the COMMUNICATOR torch's RCCL/NCCL
-    process group would run it on: a plain ``send / recv / isend / irecv`` uses the two-rank communicator of its pair, the
-    same call inside ``batch_isend_irecv`` the group-wide one (ProcessGroupNCCL::pointToPoint: ``batchP2P`` selects the
-    device key, a single operation the send-recv key) — and operations on different communicators never match.  gloo
+    process group would run it on when the group was initialised LAZILY (the stricter case): a plain ``send / recv / isend /
+    irecv`` uses the two-rank communicator of its pair, the same call inside ``batch_isend_irecv`` the group-wide one
+    (ProcessGroupNCCL::pointToPoint: ``batchP2P`` selects the device key, a single operation the send-recv key; with eager
+    initialisation — ``init_process_group(device_id=...)`` — plain calls run on the group's communicator too) — and operations
+    on different communicators never match.  gloo
     matches by source and tag alone, so a run over gloo cannot reveal a send issued one way and its receive the other;
     ``check_p2p_logs`` over the gathered logs can.
 
@@ -87,9 +89,10 @@ class P2PAudit:
     """
 
     def __init__(self):
-        self.calls = []         # (direction "send" | "recv", global peer rank, "pair" | "group")
+        self.calls = []         # (direction "send" | "recv", global peer rank, "pair" | "group", batch id)
         self._batched = False
         self._inside = False
+        self._batch_id = 0
 
     def __enter__(self):
         import torch.distributed as dist
@@ -113,7 +116,9 @@ class P2PAudit:
                         peer = dist.get_global_rank(kw["group"], peer)
                 if self._inside:        # send() / recv() are built on isend() / irecv() in some torch versions: one record
                     return orig(tensor, *a, **kw)
-                self.calls.append((direction, int(peer), "group" if self._batched else "pair"))
+                if not self._batched:
+                    self._batch_id += 1         # a plain call is a batch of its own
+                self.calls.append((direction, int(peer), "group" if self._batched else "pair", self._batch_id))
                 self._inside = True
                 try:
                     return orig(tensor, *a, **kw)
@@ -129,6 +134,7 @@ class P2PAudit:
         self._saved["batch_isend_irecv"] = orig_batch
 
         def batch(ops):      # the calls it makes (through the wrapped isend / irecv) are group-communicator operations
+            self._batch_id += 1
             self._batched = True
             try:
                 return orig_batch(ops)
@@ -147,7 +153,11 @@ class P2PAudit:
 
 def check_p2p_logs(logs):
     """``logs[r]`` = P2PAudit.calls of global rank r.  For every ordered pair (src -> dst): as many sends as receives, and
-    the i-th send runs on the same kind of communicator as the i-th receive."""
+    the i-th send runs on the same kind of communicator as the i-th receive; pair communicators mirror each other; and the
+    batches issued on the GROUP communicator — which runs each rank's batches in issue order, the operations of one batch
+    together — can all complete (a simulation of exactly that: stuck = a hang on RCCL)."""
+    full = [[(c + (1_000_000 + i,))[:4] for i, c in enumerate(lg)] for lg in logs]      # (3-tuples: every call its own batch)
+    logs = [[c[:3] for c in lg] for lg in full]
     world = len(logs)
     n_hops = 0
     for src in range(world):
@@ -170,4 +180,41 @@ def check_p2p_logs(logs):
             assert len(sa) == len(sb), f"pair ({a}, {b}): {len(sa)} vs {len(sb)} operations"
             for i, (x, y) in enumerate(zip(sa, sb)):
                 assert x != y, f"pair ({a}, {b}), operation {i}: both ranks {x} — neither can complete on an in-order communicator"
+    _simulate_group_communicator(full)                       # lazily initialised group: batched calls on its communicator
+    _simulate_group_communicator(full, plain_too=True)       # eagerly initialised group: plain calls run there as well
     return n_hops
+
+
+def _simulate_group_communicator(logs, plain_too=False):
+    """in-order execution of every rank's batches on one communicator: the head batch of a rank retires when each of its
+    operations has met its complement (send <-> recv, facing ranks) in the head batch of the peer.  ``plain_too``: plain
+    calls are batches of one on the same communicator (what torch does for a group initialised with ``device_id``)"""
+    queues = []
+    for lg in logs:
+        q, last = [], None
+        for d, p, k, b in lg:
+            if k != "group" and not plain_too:
+                continue
+            if b != last:
+                q.append([])
+                last = b
+            q[-1].append((d, p))
+        queues.append(q)
+    progress = True
+    while progress:
+        progress = False
+        for r, q in enumerate(queues):
+            while q and not q[0]:
+                q.pop(0)
+                progress = True
+            if not q:
+                continue
+            for op in list(q[0]):
+                d, p = op
+                want = ("recv" if d == "send" else "send", r)
+                if queues[p] and want in queues[p][0]:
+                    q[0].remove(op)
+                    queues[p][0].remove(want)
+                    progress = True
+    stuck = {r: q[0] for r, q in enumerate(queues) if q}
+    assert not stuck, f"the group communicator cannot make progress (head batch per rank): {stuck}"

@@ -1,7 +1,7 @@
 """Layer pipeline (duo_attn/pipeline.py) on CPU: world_size 2 and 3, gloo backend.
 
 Covers the N>1 path of bench.py by construction: the even layer split, the item streaming with
-plain point-to-point hand-offs (asynchronous sends, receives posted one item ahead), and the sharded hot path (each rank owns the dual KV
+batched point-to-point hand-offs (send(i) paired with recv(i+1) on the middle stages, asynchronous sends), and the sharded hot path (each rank owns the dual KV
 pools of its layers) against a single-process run.  The oracle is the device backend here.
 """
 import os
@@ -122,7 +122,7 @@ def _worker(rank, world, port, counts, chunks, q, subgroups=None, audit=False, _
             dist.all_gather_object(logs, list(_audit_log.calls))
             n_hops = check_p2p_logs(logs)
             if pipe.is_last and audit:
-                q.put(("audit", n_hops, sorted({k for lg in logs for _, _, k in lg})))
+                q.put(("audit", n_hops, sorted({c[2] for lg in logs for c in lg})))
         if pipe.is_last:
             q.put([o.float().numpy() for o in outs])
         dist.barrier()
@@ -195,11 +195,12 @@ def test_sharded_hot_path_equals_single_process(world, counts):
 
 @pytest.mark.parametrize("world", [3, 4])
 def test_both_ends_of_every_hop_run_on_the_same_communicator(world):
-    """torch's RCCL/NCCL process group runs a plain isend / irecv on the two-rank communicator of its pair and a call inside
-    batch_isend_irecv on the group-wide communicator; operations on different communicators never match.  Until round 5 the
-    middle stages of the prefill stream paired send(i) with recv(i+1) in a batch while the first and last stage issued plain
-    calls — invisible over gloo (it matches by source and tag), a hang on three or more GPUs.  The audit records how every
-    point-to-point call of every rank was issued and checks hop by hop that sender and receiver agree."""
+    """torch's RCCL/NCCL process group (lazily initialised) runs a plain isend / irecv on the two-rank communicator of its
+    pair and a call inside batch_isend_irecv on the group-wide communicator; operations on different communicators never
+    match.  Until round 5 the middle stages of the prefill stream paired send(i) with recv(i+1) in a batch while the first
+    and last stage issued plain calls — invisible over gloo (it matches by source and tag), a hang on three or more GPUs
+    unless the group was initialised eagerly.  The audit records how every point-to-point call of every rank was issued,
+    checks hop by hop that sender and receiver agree, and replays the batches on an in-order communicator to the end."""
     counts = [1, 2, 0, 1, 1, 2][: world + 2]
     chunks = [9, 7, 5, 6, 1, 1, 1]
     expected = _single_process(counts, chunks)
@@ -215,7 +216,7 @@ def test_both_ends_of_every_hop_run_on_the_same_communicator(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     # 7 items over world - 1 hops, + 2 token hops back (3 decode tokens: the last needs none)
-    assert tag == "audit" and n_hops == 7 * (world - 1) + 2 and kinds == ["pair"]
+    assert tag == "audit" and n_hops == 7 * (world - 1) + 2 and kinds == ["group"]     # every call batched: the group's communicator
     for a, b in zip(got, expected):
         assert (a == b).all()
 
@@ -236,6 +237,13 @@ def test_the_audit_catches_a_mixed_hop():
     with pytest.raises(AssertionError, match="both ranks send"):
         check_p2p_logs(crossed)
     assert check_p2p_logs([[("send", 1, "pair"), ("recv", 1, "pair")], [("recv", 0, "pair"), ("send", 0, "pair")]]) == 2
+    # the group communicator runs batches in issue order: rank 0 sends to 1 first, rank 1 waits for rank 2 first, rank 2 for
+    # rank 0 — nobody's head batch can retire; the same calls paired into batches can
+    ring = [[("send", 1, "group", 1), ("recv", 2, "group", 2)], [("send", 2, "group", 1), ("recv", 0, "group", 2)],
+            [("send", 0, "group", 1), ("recv", 1, "group", 2)]]
+    with pytest.raises(AssertionError, match="cannot make progress"):
+        check_p2p_logs(ring)
+    assert check_p2p_logs([[(d, p, k, 1) for d, p, k, _ in lg] for lg in ring]) == 3
 
 
 def test_balanced_layer_split():
