@@ -53,9 +53,12 @@ def cuda_shim():
 
     orig_to = torch.Tensor.to
 
+    def on_gpu(x):
+        return (isinstance(x, str) and x.startswith("cuda")) or (isinstance(x, torch.device) and x.type == "cuda")
+
     def to(self, *a, **kw):
-        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
-        if isinstance(kw.get("device"), str) and kw["device"].startswith("cuda"):
+        a = tuple("cpu" if on_gpu(x) else x for x in a)
+        if on_gpu(kw.get("device")):
             kw["device"] = "cpu"
         return orig_to(self, *a, **kw)
 
@@ -75,6 +78,7 @@ def cuda_shim():
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.reset_peak_memory_stats = lambda *a, **k: None
     torch.cuda.max_memory_allocated = lambda *a, **k: 0
+    torch.cuda.device_count = lambda: 1         # (the needle harness hands every visible GPU to to_device(..., enable_tp=True))
 
 
 def readme_quick_start(work):
@@ -124,6 +128,122 @@ def readme_quick_start(work):
                                   f"finite: {bool(torch.isfinite(out.logits).all())}", f"tokens: {len(toks)}"]))
 
 
+def needle_in_a_haystack(work):
+    """``eval/needle/needle_in_haystack.py`` VERBATIM (the accuracy harness of the tuple-cache API: enable_duo_attention_eval with
+    --sink_size / --recent_size overrides, to_device(model, [gpus], enable_tp=True) on one device, chunked prefill handing
+    ``output.past_key_values`` back, the question fed one token at a time, greedy generation until EOS) on a random-init model:
+    two context lengths x two needle depths.  Its one missing third-party import, ``rouge_score``, is stood in for by a
+    ten-line module written into the temp directory (the score of a random model is meaningless either way)."""
+    import string
+
+    import numpy as np
+    import torch
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast
+
+    mdir, pdir = os.path.join(work, "tiny-llama"), os.path.join(work, "pattern")
+    for d in (mdir, pdir, os.path.join(work, "PaulGrahamEssays"), os.path.join(work, "rouge_score")):
+        os.makedirs(d, exist_ok=True)
+    chars = ["<unk>", "<s>", "</s>"] + sorted(set(string.ascii_letters + string.digits + string.punctuation + " \n"))
+    tok = Tokenizer(models.WordLevel({c: i for i, c in enumerate(chars)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", behavior="isolated")
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>").save_pretrained(mdir)
+    torch.manual_seed(6)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                      head_dim=128, vocab_size=128, max_position_embeddings=4096, rope_theta=10000.0, tie_word_embeddings=False,
+                      bos_token_id=1, eos_token_id=2)
+    LlamaForCausalLM(cfg).to(torch.bfloat16).save_pretrained(mdir)
+    np.savetxt(os.path.join(pdir, "full_attention_heads.tsv"), np.array([[0.9, 0.1], [0.2, 0.7], [0.95, 0.6]]), delimiter="\t")
+    with open(os.path.join(pdir, "config.json"), "w") as f:
+        json.dump({"sink_size": 64, "recent_size": 256}, f)
+    with open(os.path.join(work, "PaulGrahamEssays", "essay.txt"), "w") as f:
+        f.write("the quick brown fox jumps over the lazy dog and keeps running through the long grass. " * 40)
+    with open(os.path.join(work, "rouge_score", "__init__.py"), "w") as f:
+        f.write("from . import rouge_scorer\n")
+    with open(os.path.join(work, "rouge_score", "rouge_scorer.py"), "w") as f:
+        f.write("import collections\nScore = collections.namedtuple('Score', 'precision recall fmeasure')\n"
+                "class RougeScorer:\n    def __init__(self, kinds, use_stemmer=False):\n        self.kinds = kinds\n"
+                "    def score(self, target, prediction):\n        a, b = set(target.split()), set(prediction.split())\n"
+                "        f = 2 * len(a & b) / max(1, len(a) + len(b))\n        return {k: Score(f, f, f) for k in self.kinds}\n")
+    sys.path.insert(0, work)
+    os.chdir(work)
+    sys.argv = ["needle_in_haystack.py", "-s", "300", "-e", "700", "--model_path", mdir, "--attn_load_dir", pdir, "--sink_size", "8",
+                "--recent_size", "24", "--simulation_length", "6", "--context_lengths_num_intervals", "2",
+                "--document_depth_percent_intervals", "2", "--context_lengths_min", "450", "--context_lengths_max", "600",
+                "--prefilling_chunk_size", "96", "--sparsity", "0.5"]
+    runpy.run_path(os.path.join(REF, "eval", "needle", "needle_in_haystack.py"), run_name="__main__")
+    import glob
+
+    res = [json.load(open(p)) for p in sorted(glob.glob(os.path.join(work, "results", "tiny-llama", "*_results.json")))]
+    print("RESULT " + json.dumps([f"results: {len(res)}", f"lengths: {sorted({r['context_length'] for r in res})}",
+                                  f"depths: {sorted({r['depth_percent'] for r in res})}",
+                                  f"fields ok: {all('model_response' in r and 'score' in r for r in res)}"]))
+
+
+def _char_model(work, name):
+    """a random-init three-layer Llama with a character-level tokenizer and a generation config, saved under work/name"""
+    import string
+
+    import torch
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast
+
+    mdir = os.path.join(work, name)
+    os.makedirs(mdir, exist_ok=True)
+    chars = ["<unk>", "<s>", "</s>"] + sorted(set(string.ascii_letters + string.digits + string.punctuation + " \n"))
+    tok = Tokenizer(models.WordLevel({c: i for i, c in enumerate(chars)}, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Split("", behavior="isolated")
+    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>").save_pretrained(mdir)
+    torch.manual_seed(6)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
+                      head_dim=128, vocab_size=128, max_position_embeddings=4096, rope_theta=10000.0, tie_word_embeddings=False,
+                      bos_token_id=1, eos_token_id=2)
+    LlamaForCausalLM(cfg).to(torch.bfloat16).save_pretrained(mdir)
+    return mdir
+
+
+def longbench_pred(work, method):
+    """``eval/LongBench/pred.py`` VERBATIM, task ``trec``, with ``--method duo_attn`` (enable_duo_attention_eval, sink / recent
+    overrides, sparsify with the keyword ``sparsity=``) or ``--method full`` (``enable_tuple_kv_cache``: the full-attention tuple
+    baseline); ``to_device(model, [gpu ids], enable_tp=True)`` on one device; single-shot prefill, the last 50
+    prompt tokens fed one at a time, greedy generation.  The harness's relative config paths are created in the temp directory
+    (prompt / length tables copied from the reference at run time, the model table pointing at the random-init model);
+    ``datasets.load_dataset`` — the hub is unreachable — is stood in for by a module returning three drawn TREC-shaped records."""
+    import shutil
+
+    import numpy as np
+
+    mdir = _char_model(work, "tiny-llama")
+    pdir = os.path.join(work, "pattern")
+    cfg_dir = os.path.join(work, "eval", "LongBench", "config")
+    for d in (pdir, cfg_dir, os.path.join(work, "datasets")):
+        os.makedirs(d, exist_ok=True)
+    np.savetxt(os.path.join(pdir, "full_attention_heads.tsv"), np.array([[0.9, 0.1], [0.2, 0.7], [0.95, 0.6]]), delimiter="\t")
+    json.dump({"sink_size": 64, "recent_size": 256}, open(os.path.join(pdir, "config.json"), "w"))
+    for n in ("dataset2prompt.json", "dataset2maxlen.json"):
+        shutil.copy(os.path.join(REF, "eval", "LongBench", "config", n), cfg_dir)
+    json.dump({"tiny-llama": mdir}, open(os.path.join(cfg_dir, "model2path.json"), "w"))
+    json.dump({"tiny-llama": 400}, open(os.path.join(cfg_dir, "model2maxlen.json"), "w"))
+    with open(os.path.join(work, "datasets", "__init__.py"), "w") as f:
+        f.write("def load_dataset(name, subset, split='test'):\n"
+                "    assert (name, subset, split) == ('THUDM/LongBench', 'trec', 'test')\n"
+                "    mk = lambda i, n: {'context': 'Question: what is item %d ?\\nType: number\\n' % i * n, 'input': 'Question: how many ?\\nType:',\n"
+                "                       'answers': ['number'], 'all_classes': ['number', 'person'], 'length': 40 * n}\n"
+                "    return [mk(1, 6), mk(2, 14), mk(3, 3)]\n")       # (the second record is longer than max_length: truncated in the middle)
+    sys.path.insert(0, work)
+    os.chdir(work)
+    sys.argv = ["pred.py", "--model", "tiny-llama", "--task", "trec", "--method", method, "--decoding_simulation_length", "7"]
+    if method == "duo_attn":
+        sys.argv += ["--attn_load_dir", pdir, "--sink_size", "8", "--recent_size", "24", "--sparsity", "0.5"]
+    runpy.run_path(os.path.join(REF, "eval", "LongBench", "pred.py"), run_name="__main__")
+    import glob
+
+    out = glob.glob(os.path.join(work, "eval", "LongBench", "pred", "tiny-llama", "trec-*.jsonl"))
+    rows = [json.loads(ln) for ln in open(out[0])]
+    print("RESULT " + json.dumps([f"file: {os.path.basename(out[0])}", f"records: {len(rows)}",
+                                  f"fields ok: {all(set(r) == {'pred', 'answers', 'all_classes', 'length'} for r in rows)}"]))
+
+
 def main():
     script, work = sys.argv[1], sys.argv[2]
     if not os.path.isdir(os.path.join(REF, "eval", "efficiency")):
@@ -142,6 +262,10 @@ def main():
     cuda_shim()
     if script == "README":
         return readme_quick_start(work)
+    if script == "needle":
+        return needle_in_a_haystack(work)
+    if script.startswith("longbench:"):
+        return longbench_pred(work, script.split(":", 1)[1])
     out = os.path.join(work, "out")
     sys.argv = [script, "--model_name", mdir, "--attn_load_dir", pdir, "--sparsity", "0.5", "--max_length", "50",
                 "--prefilling_chunk_size", "20", "--device", "cpu", "--output_dir", out, "--seed", "42"]

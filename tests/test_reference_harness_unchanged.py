@@ -64,3 +64,30 @@ def test_reference_readme_quick_start_runs_as_printed(tmp_path):
     res, out = _run("README", tmp_path)
     assert res == {"sparsity": "0.5", "retrieval heads": "128", "cache shapes ok": "True", "finite": "True", "tokens": "3"}
     assert "Enabling DuoAttention evaluation using sink size 64 and recent size 256" in out
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_reference_needle_in_a_haystack_runs_unchanged(tmp_path):
+    """eval/needle/needle_in_haystack.py:176-330, 497-557 VERBATIM — the accuracy harness of the API north_star names:
+    ``enable_duo_attention_eval(model, heads, sink, recent)`` with the command-line overrides, ``to_device(model, [gpu ids],
+    enable_tp=True)`` on one device, chunked prefill handing ``output.past_key_values`` back and forth, the question fed one
+    token at a time, greedy generation — two context lengths x two needle depths on a random-init model; the four result
+    files it writes are read back.  (``rouge_score``, absent from the image, is a ten-line stand-in in the temp directory.)"""
+    res, out = _run("needle", tmp_path)
+    assert res == {"results": "4", "lengths": "[450, 600]", "depths": "[0.0, 100.0]", "fields ok": "True"}
+    assert "Enabling DuoAttention evaluation using sink size 8 and recent size 24" in out
+    assert out.count("-- Test Summary --") == 4
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+@pytest.mark.parametrize("method,file", [("duo_attn", "trec-duo_attn-pattern-pattern-sp-0.5.jsonl"), ("full", "trec-full.jsonl")])
+def test_reference_longbench_pred_runs_unchanged(method, file, tmp_path):
+    """eval/LongBench/pred.py:85-330 VERBATIM on task trec: ``--method duo_attn`` (load_attn_pattern, the keyword call
+    ``sparsify_attention_heads(heads, None, sparsity=...)``, ``enable_duo_attention_eval`` with sink / recent overrides) and
+    ``--method full`` (``duo_attn.patch.tuple_kv_cache.enable_tuple_kv_cache``: the full-attention tuple baseline, SURVEY row
+    a12); ``to_device(model, [gpu ids], enable_tp=True)``; single-shot prefill, 7 prompt tokens fed one at a time, greedy
+    generation; the prediction file it writes is read back (three records, the second truncated in the middle by the harness)."""
+    res, out = _run(f"longbench:{method}", tmp_path)
+    assert res == {"file": file, "records": "3", "fields ok": "True"}
+    assert out.count("Prediction:") == 3
+    assert ("Enabling DuoAttention evaluation using sink size 8 and recent size 24" in out) == (method == "duo_attn")
