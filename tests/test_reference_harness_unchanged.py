@@ -30,7 +30,7 @@ def _run(script, tmp_path):
 
 @pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
 def test_reference_benchmark_static_runs_unchanged(tmp_path):
-    """benchmark_static.py:20-130 — get_tokenizer / get_model / to_device / load_attn_pattern / sparsify_attention_heads /
+    """benchmark_static.py:20-119 — get_tokenizer / get_model / to_device / load_attn_pattern / sparsify_attention_heads /
     enable_llama_duo_attention_static_kv_cache_eval / DuoAttentionStaticKVCache(model, heads, 1, max_size, sink, recent) /
     13 chunked-prefill passes with kv_cache.clear() / 150 decode calls with kv_cache.evict_last(1) / kv_cache.memory_usage"""
     res, out = _run("benchmark_static.py", tmp_path)
@@ -44,7 +44,7 @@ def test_reference_benchmark_static_runs_unchanged(tmp_path):
 
 @pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
 def test_reference_benchmark_dynamic_runs_unchanged(tmp_path):
-    """benchmark_dynamic.py:17-104 — enable_duo_attention_eval(model, heads, 16, 64), one single-shot prefill with
+    """benchmark_dynamic.py:17-103 — enable_duo_attention_eval(model, heads, 16, 64), one single-shot prefill with
     past_key_values=None, outputs.past_key_values handed back for 110 decode calls"""
     res, out = _run("benchmark_dynamic.py", tmp_path)
     assert res["Context length"] == "50" and res["Sparsity"] == "0.5"
@@ -82,7 +82,7 @@ def test_reference_needle_in_a_haystack_runs_unchanged(tmp_path):
 @pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
 @pytest.mark.parametrize("method,file", [("duo_attn", "trec-duo_attn-pattern-pattern-sp-0.5.jsonl"), ("full", "trec-full.jsonl")])
 def test_reference_longbench_pred_runs_unchanged(method, file, tmp_path):
-    """eval/LongBench/pred.py:85-330 VERBATIM on task trec: ``--method duo_attn`` (load_attn_pattern, the keyword call
+    """eval/LongBench/pred.py:85-297 VERBATIM on task trec: ``--method duo_attn`` (load_attn_pattern, the keyword call
     ``sparsify_attention_heads(heads, None, sparsity=...)``, ``enable_duo_attention_eval`` with sink / recent overrides) and
     ``--method full`` (``duo_attn.patch.tuple_kv_cache.enable_tuple_kv_cache``: the full-attention tuple baseline, SURVEY row
     a12); ``to_device(model, [gpu ids], enable_tp=True)``; single-shot prefill, 7 prompt tokens fed one at a time, greedy
