@@ -59,8 +59,8 @@ def test_reference_readme_quick_start_runs_as_printed(tmp_path):
     import enable_duo_attention_eval``, the keyword call ``sparsify_attention_heads(attn_heads, sparsity=0.5)``,
     ``enable_duo_attention_eval(model, attn_heads, sink_size=64, recent_size=256)`` — on the reference's own shipped
     Llama-3-8B-1048k pattern (copied into the temp directory at run time) and a random-init model of its geometry; then a
-    333-token generation through the tuple caches: 128 of 256 kv heads retrieval heads, every layer's cache in the
-    reference's format ``(full [2, nf, N, 128], streaming [2, ns, sink + recent, 128])``"""
+    43-token generation through the tuple caches: 128 of 256 kv heads retrieval heads, every layer's cache in the
+    reference's format ``(full [2, nf, N, 128], streaming [2, ns, min(N, sink + recent), 128])`` (eviction has its own tests)"""
     res, out = _run("README", tmp_path)
     assert res == {"sparsity": "0.5", "retrieval heads": "128", "cache shapes ok": "True", "finite": "True", "tokens": "3"}
     assert "Enabling DuoAttention evaluation using sink size 64 and recent size 256" in out
