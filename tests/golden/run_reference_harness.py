@@ -134,25 +134,11 @@ def needle_in_a_haystack(work):
     ``output.past_key_values`` back, the question fed one token at a time, greedy generation until EOS) on a random-init model:
     two context lengths x two needle depths.  Its one missing third-party import, ``rouge_score``, is stood in for by a
     ten-line module written into the temp directory (the score of a random model is meaningless either way)."""
-    import string
-
     import numpy as np
-    import torch
-    from tokenizers import Tokenizer, models, pre_tokenizers
-    from transformers import LlamaConfig, LlamaForCausalLM, PreTrainedTokenizerFast
 
-    mdir, pdir = os.path.join(work, "tiny-llama"), os.path.join(work, "pattern")
-    for d in (mdir, pdir, os.path.join(work, "PaulGrahamEssays"), os.path.join(work, "rouge_score")):
+    mdir, pdir = _char_model(work, "tiny-llama"), os.path.join(work, "pattern")
+    for d in (pdir, os.path.join(work, "PaulGrahamEssays"), os.path.join(work, "rouge_score")):
         os.makedirs(d, exist_ok=True)
-    chars = ["<unk>", "<s>", "</s>"] + sorted(set(string.ascii_letters + string.digits + string.punctuation + " \n"))
-    tok = Tokenizer(models.WordLevel({c: i for i, c in enumerate(chars)}, unk_token="<unk>"))
-    tok.pre_tokenizer = pre_tokenizers.Split("", behavior="isolated")
-    PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>", bos_token="<s>", eos_token="</s>").save_pretrained(mdir)
-    torch.manual_seed(6)
-    cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=3, num_attention_heads=4, num_key_value_heads=2,
-                      head_dim=128, vocab_size=128, max_position_embeddings=4096, rope_theta=10000.0, tie_word_embeddings=False,
-                      bos_token_id=1, eos_token_id=2)
-    LlamaForCausalLM(cfg).to(torch.bfloat16).save_pretrained(mdir)
     np.savetxt(os.path.join(pdir, "full_attention_heads.tsv"), np.array([[0.9, 0.1], [0.2, 0.7], [0.95, 0.6]]), delimiter="\t")
     with open(os.path.join(pdir, "config.json"), "w") as f:
         json.dump({"sink_size": 64, "recent_size": 256}, f)
