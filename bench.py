@@ -871,7 +871,7 @@ def main():
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--row-block", type=int, default=-1,
                     help="N > 1: query rows per pipeline item (a chunk is handed through the stages in row blocks); "
-                         "0 = whole chunks, -1 = automatic (4096 rows on 2 GPUs, 2048 on more)")
+                         "0 = whole chunks, -1 = automatic (4096 rows on up to 4 GPUs, 2048 on more)")
     ap.add_argument("--no-full-baseline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
@@ -974,7 +974,9 @@ def main():
         # finer blocks fill the pipeline sooner but run the kernels at smaller launches (one GPU, whole job:
         # 4096-row blocks 94 %, 2048 89 %, 1024 78 % of the whole-chunk prefill rate): with P stages the
         # fill costs ~(P-1) block slots, so more stages want smaller blocks
-        args.row_block = 4096 if world <= 2 else 2048
+        # (tools/pipeline_model.py on this build's one-GPU block efficiencies — 4096 rows 0.935, 2048 rows 0.872: 4096-row
+        #  blocks win on 2 and, by ~2 %, on 4 stages; 2048 on 8, where the fill of the longer pipeline weighs more)
+        args.row_block = 4096 if world <= 4 else 2048
     use_blocks = args.row_block > 0 and (world > 1 or os.environ.get("DUO_BENCH_FORCE_BLOCKS") == "1")
     if use_blocks:
         hp.set_row_blocks(args.row_block)

@@ -4,7 +4,7 @@ available in five rounds; the driver's SCALE run is the measurement).
 
 The layer pipeline of bench.py (duo_attn/pipeline.py) replayed on paper from ONE-GPU measurements of the same build:
 
-  * prefill: the job's row blocks (2048 rows on > 2 GPUs, 4096 on 2) flow through the cost-balanced contiguous stages
+  * prefill: the job's row blocks (4096 rows on up to 4 GPUs, 2048 on more: bench.py's automatic choice) flow through the cost-balanced contiguous stages
     (``balanced_layer_split`` over the per-layer algorithmic FLOPs, as bench.py does); a block costs its algorithmic FLOPs on
     the stage's layers / (the measured one-GPU whole-job prefill rate x the measured efficiency of that block size), a
     hand-off costs block bytes / one xGMI link + a fixed latency; finish[s][b] = max(finish[s][b-1], finish[s-1][b] + hop)
@@ -45,7 +45,7 @@ def model(counts, ctx, chunk, world, rate, eff, link, hop, dec_fixed, dec_bw, n_
     pf = bench.prefill_flops(counts, ctx, chunk)
     layer_cost = [sum(row[l] for row in pf) for l in range(len(counts))]
     bounds = balanced_layer_split(layer_cost, world) if world > 1 else [(0, len(counts))]
-    rb = chunk if world == 1 else (4096 if world == 2 else 2048)
+    rb = chunk if world == 1 else (4096 if world <= 4 else 2048)
     blocks = [(s, r0, min(rb, min(chunk, ctx - s) - r0)) for s in range(0, ctx, chunk) for r0 in range(0, min(chunk, ctx - s), rb)]
     r = rate * eff[rb]
     finish = [[0.0] * len(blocks) for _ in range(world)]
