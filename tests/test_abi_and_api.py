@@ -71,6 +71,14 @@ def test_argument_errors_without_gpu():
 
     lib = _hip.load_library()
     assert lib.duo_attn_decode_workspace_bytes(32, 512) == 32 * 512 * 130 * 4
+    # ABI v5: the decode entry points size their split-KV grid from the bucket of the visible rows — 64-token units rounded
+    # up to a power of two (host arithmetic; duo_attn/graph.py re-captures a decode step when it changes)
+    assert [lib.duo_decode_plan_bucket(n) for n in (-3, 0, 1, 64, 65, 128, 129, 256, 257, 131072, 131073, 3300000)] == \
+        [0, 0, 1, 1, 2, 2, 4, 4, 8, 2048, 4096, 65536]
+    for n in range(1, 5000, 37):
+        b = lib.duo_decode_plan_bucket(n)
+        units = (n + 63) // 64
+        assert b & (b - 1) == 0 and units <= b < 2 * units
     rc = lib.duo_rope_inplace_bf16(None, 0, 0, 0, None, 0, 0, 0, 4, 0, 1.0, 1e4, 64, None)
     assert rc == -2   # DUO_EHEADDIM
     rc = lib.duo_attn_prefill_bf16(None, 0, 0, None, 0, 0, 4, 4, None, None, 1.0, 128, None)
