@@ -52,6 +52,10 @@ def plan_key(c):
     return (bucket(max(c.kv_seq_len_list) + 1), bucket(max(c.streaming_kv_seq_len_list) + 1))
 
 
+class RecaptureError(RuntimeError):
+    """the step could not be captured again for a new length bucket (``DecodeStepGraph.replay``); no launch was issued"""
+
+
 class DecodeStepGraph:
     """``step_fn()`` must run ONE q_len == 1 forward through ``kv_cache`` (the patched model, or any loop
     over ``duo_static_attention_core``) using static input tensors, and may return its output tensor(s).
@@ -119,7 +123,10 @@ class DecodeStepGraph:
             # the context left the length bucket the split-KV grid was sized for: capture the step again for this one
             # (the eager step would plan exactly this grid, so replays stay bit-equal to it); ``self.output`` is the new
             # capture's tensor from here on
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:      # nothing was launched and the host counters are restored: the caller may step eagerly
+                raise RecaptureError(f"{type(e).__name__}: {e}") from e
         elif _host_counters(c) != c._device_counters:
             c.sync_device_state()
         self.graph.replay()
@@ -221,7 +228,7 @@ def auto_decode_eligible(model, input_ids, position_ids, past_key_values, inputs
 
 def auto_decode_step(model, eager_forward, input_ids, kv):
     """One decode step of the unchanged reference loop through a HIP graph captured on the way: the first eligible steps
-    after a change run eagerly, then the step is captured ONCE per (model, cache) and replayed — the cache lengths live in
+    after a change run eagerly, then the step is captured once per (model, cache, length bucket) and replayed — the cache lengths live in
     HBM (``kv.device_state``), ``kv.evict_last`` rewinds them with a launch, an eager prefill in between re-uploads them.
     Returns the logits (a fresh tensor per call), or None when this call should run eagerly."""
     st = getattr(kv, "_auto_graph", None)
@@ -247,4 +254,9 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
         kv._decode_graph = g
     else:
         st["tok"].copy_(input_ids)
-    return st["graph"].replay().clone()
+    try:
+        return st["graph"].replay().clone()
+    except RecaptureError as e:     # (the first capture worked, the one for the new length bucket did not: eager from here on)
+        kv._auto_graph_failed, kv._decode_graph, st["graph"] = True, None, None
+        warnings.warn(f"DuoAttention: re-capturing the decode step for a new context length failed ({e}); decoding eagerly.")
+        return None
