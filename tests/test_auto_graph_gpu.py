@@ -429,3 +429,34 @@ def test_every_captured_step_owns_its_split_kv_partials(monkeypatch):
         want = _decode(rm, rc, t, 11, False, monkeypatch, ids[:, 650:661])[3:]
         for s, (a, b) in enumerate(zip(got[i], want)):
             assert torch.equal(a, b), f"model {i}, step {s}"
+
+
+def test_a_failed_recapture_falls_back_to_eager_steps(monkeypatch):
+    """the first capture works, the one for the next length bucket raises (made to, here): nothing was launched, the host
+    counters are restored, the loop goes on eagerly with a warning — and still equals the eager loop bit for bit"""
+    from duo_attn import graph
+
+    ids = torch.randint(0, 211, (1, 100), generator=torch.Generator().manual_seed(19)).to(DEV)
+    model, kv = _setup("llama")
+    ref_model, ref_kv = _setup("llama")
+    with torch.no_grad():
+        for m, c in ((model, kv), (ref_model, ref_kv)):
+            t = m(input_ids=ids[:, :60], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+    orig, n = graph.DecodeStepGraph._capture, []
+
+    def flaky(self):
+        n.append(1)
+        if len(n) > 1:
+            raise RuntimeError("no memory for the capture (simulated)")
+        return orig(self)
+
+    monkeypatch.setattr(graph.DecodeStepGraph, "_capture", flaky)
+    with pytest.warns(UserWarning, match="re-capturing the decode step"):
+        got = _decode(model, kv, t, 12, True, monkeypatch, ids[:, 60:72])          # 60 -> 72 rows: leaves the 64-row bucket at step 5
+    want = _decode(ref_model, ref_kv, t, 12, False, monkeypatch, ids[:, 60:72])
+    assert len(n) == 2 and kv._decode_graph is None and kv._auto_graph_failed
+    for s, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"step {s}"
+    assert kv.kv_seq_len_list == ref_kv.kv_seq_len_list
+    for a, b in zip(_pools(kv), _pools(ref_kv)):
+        assert torch.equal(a, b)
