@@ -79,6 +79,9 @@ class DecodeStepGraph:
         from . import _hip
 
         kv_cache = self.cache
+        # a re-capture releases the previous capture's graph, whose last replay may still be executing: wait for the device
+        # BEFORE the old object goes (torch.cuda.graph() synchronises too, but only after the assignment below dropped it)
+        torch.cuda.synchronize()
         kv_cache.enable_device_state()
         host = (list(kv_cache.kv_seq_len_list), list(kv_cache.streaming_kv_seq_len_list))
         self.plan_key = plan_key(kv_cache)
@@ -234,6 +237,8 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
     st = getattr(kv, "_auto_graph", None)
     sig = _model_signature(model, model.__dict__.pop("_duo_param_ptrs", None))
     if st is None or st["sig"] != sig:
+        if st is not None and st["graph"] is not None:
+            torch.cuda.synchronize()        # the retired step's last replay may still be executing: its graph is released here
         st = {"sig": sig, "calls": 0, "graph": None, "tok": None}
         kv._auto_graph = st
         kv._decode_graph = None
@@ -257,6 +262,7 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
     try:
         return st["graph"].replay().clone()
     except RecaptureError as e:     # (the first capture worked, the one for the new length bucket did not: eager from here on)
+        torch.cuda.synchronize()        # (the old graph may still be executing its last replay when it is released)
         kv._auto_graph_failed, kv._decode_graph, st["graph"] = True, None, None
         warnings.warn(f"DuoAttention: re-capturing the decode step for a new context length failed ({e}); decoding eagerly.")
         return None
