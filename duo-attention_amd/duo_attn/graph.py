@@ -97,6 +97,14 @@ class DecodeStepGraph:
         self.captures += 1
         kv_cache.sync_device_state()
 
+    def __del__(self):
+        # the graph object goes with this one: never while its last replay is still executing
+        try:
+            if torch.cuda.is_available() and torch.cuda.is_initialized():
+                torch.cuda.synchronize()
+        except Exception:       # (interpreter shutdown)
+            pass
+
     def _body(self):
         c = self.cache
         c.use_device_state = True
