@@ -47,6 +47,9 @@
  *   duo_token_linear_args.reserved became `flags` (DUO_LINEAR_NORM_HF), + duo_tuple_decode_prep_bf16 (the tuple-cache
  *   decode step), + duo_rope_hf_inplace_bf16 / duo_rmsnorm_hf_bf16 (its prefill chunks), + duo_decode_layer_batched_dev_bf16
  *   (batched decode step with device-side lengths).
+ * ABI version 5 (round 5, one addition, no signature changed): + duo_decode_plan_bucket; every decode entry point sizes its
+ *   split-KV grid from that bucket of the visible rows (static_kv_cache.py:44-45 keeps the lengths as Python ints, so the
+ *   reference has no captured step to keep consistent — here a captured launch equals the eager launch of its bucket).
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
