@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 import weakref
 from ctypes import POINTER, Structure, byref, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
 from typing import Optional
@@ -503,7 +504,8 @@ def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
     """fp32 scratch for the split-KV partials: one buffer per (device, stream, q-head count), allocated once and
     never replaced or freed — concurrent streams do not share partials, and a captured graph's launches keep
     pointing at live memory whatever other models decode later."""
-    cache = _workspaces if _scratch_scope is None else _scratch_scope
+    scope = _active_scope()
+    cache = _workspaces if scope is None else scope
     key = _stream_key(device) + (int(n_q_heads),)
     ws = cache.get(key)
     if ws is None:
@@ -513,27 +515,41 @@ def decode_workspace(device: torch.device, n_q_heads: int) -> torch.Tensor:
     return ws
 
 
-_scratch_scope = None
+_scope_tls = threading.local()      # the active scratch_scope of THIS thread (None outside one)
+
+
+def _active_scope():
+    return getattr(_scope_tls, "owner", None)
 
 
 class scratch_scope:
-    """While active, the decode scratch (split-KV partials, arrival tickets) comes from ``owner`` — a dict the caller keeps —
-    instead of the per-(device, stream) caches.  A captured decode step uses it (duo_attn/graph.py): every graph captures on
-    torch's one shared capture stream, so graphs of two caches would otherwise bake the SAME partials buffer into their
-    launches and race when replayed on two streams."""
+    """While active ON THIS THREAD, the decode scratch (split-KV partials, arrival tickets) comes from ``owner`` — a dict the
+    caller keeps — instead of the per-(device, stream) caches.  A captured decode step uses it (duo_attn/graph.py): every graph
+    captures on torch's one shared capture stream, so graphs of two caches would otherwise bake the SAME partials buffer into
+    their launches.  Thread-local: an eager decode on another thread (another device, another stream) keeps its own scratch
+    while this thread captures.  What the scope does NOT cover: torch's GEMM workspace (per capture stream) — two captured
+    whole-model steps must not be replayed concurrently on two streams."""
 
     def __init__(self, owner: dict):
         self.owner = owner
 
     def __enter__(self):
-        global _scratch_scope
-        self.prev, _scratch_scope = _scratch_scope, self.owner
+        self.prev, _scope_tls.owner = _active_scope(), self.owner
         return self.owner
 
     def __exit__(self, *exc):
-        global _scratch_scope
-        _scratch_scope = self.prev
+        _scope_tls.owner = self.prev
         return False
+
+
+def prepare_graph_scratch(owner: dict, kv_cache) -> None:
+    """Called by ``DecodeStepGraph.__init__`` OUTSIDE the capture: the arrival tickets of the (opt-in) single-launch decode step
+    exist and are zero before the first launch is recorded, so no memset is part of the graph — a replay can never clear the
+    sticky give-up flag, and ``check_decode_tickets`` never reads uninitialised memory of a captured-but-never-replayed step.
+    (The split-KV partials need no initial value: they are allocated on first use inside the scope.)"""
+    if "tickets" not in owner:
+        t = owner["tickets"] = torch.zeros(DECODE_TICKET_BYTES // 4, dtype=torch.int32, device=kv_cache.device)
+        _graph_tickets.append(weakref.ref(t))
 
 
 def release_workspaces(device=None) -> None:
@@ -556,6 +572,7 @@ def check_decode_tickets(device=None) -> None:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     bad = []
+    _graph_tickets[:] = [r for r in _graph_tickets if r() is not None]
     graph_owned = [((idx, "graph"), t) for t in (r() for r in _graph_tickets) if t is not None and t.device.index == idx]
     for key, t in list(_tickets.items()) + graph_owned:
         if key[0] == idx and int(t.abs().sum()) != 0:
@@ -572,10 +589,13 @@ _one_launch_used = False
 def decode_tickets(device: torch.device) -> torch.Tensor:
     """Arrival tickets of the single-launch decode step (duo_decode_step_bf16): zero-filled once per
     (device, stream); every launch leaves them zeroed."""
-    if _scratch_scope is not None:
-        t = _scratch_scope.get("tickets")
-        if t is None:       # (a captured step: allocated while capturing, so the zero fill is part of the graph — harmless)
-            t = _scratch_scope["tickets"] = torch.zeros(DECODE_TICKET_BYTES // 4, dtype=torch.int32, device=device)
+    scope = _active_scope()
+    if scope is not None:
+        t = scope.get("tickets")
+        if t is None:       # (a scope that was not prepared by prepare_graph_scratch: a direct user outside any capture)
+            if torch.cuda.is_current_stream_capturing():
+                raise DuoHipError("decode tickets requested inside a stream capture without prepare_graph_scratch()")
+            t = scope["tickets"] = torch.zeros(DECODE_TICKET_BYTES // 4, dtype=torch.int32, device=device)
             _graph_tickets.append(weakref.ref(t))
         return t
     key = _stream_key(device)

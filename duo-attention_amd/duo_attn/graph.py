@@ -18,9 +18,18 @@ the 1K grid.
 Two ways in:
 
 * ``DecodeStepGraph(kv_cache, step_fn, evict_after)`` — explicit (``tools/benchmark_static.py --graph``, tests);
-* ``auto_decode_step`` — what the patched ``*ForCausalLM.forward`` does by itself when the call is the reference loop's
-  decode call (one token, implicit positions, a static cache on this GPU, no gradients): the reference's harness runs
-  UNCHANGED and its steps are graph replays after two eager ones.  ``DUO_AUTO_DECODE_GRAPH=0`` keeps every step eager.
+* ``auto_decode_step`` — OPT-IN (``DUO_AUTO_DECODE_GRAPH=1``, or ``duo_attn.graph.AUTO_DECODE_GRAPH = True``): the patched
+  ``*ForCausalLM.forward`` captures the step by itself when the call is the reference loop's decode call (one token,
+  implicit positions, a static cache on this GPU, no gradients): the reference's harness runs UNCHANGED and its steps are
+  graph replays after two eager ones.  OFF by default since round 6: the eager step is GPU-bound on this class of host
+  (4.42 eager vs 4.44 ms/token replayed at 128K, 3.30 vs 3.33 at 32K), so the capture buys nothing there, and one abort
+  inside a round-5 test run of this path was never explained ("graph-captured decode"; the soak record is
+  ``profiles/r6_graph_soak.md``).  Turn it on where the host is the bottleneck: short contexts (<= 8K) or a slow /
+  shared CPU.
+
+A captured graph is never destroyed while its last replay may still be executing and never from inside somebody else's
+stream capture: a retired graph goes to a module-level list with the event recorded after its last replay and is released
+by a later call once that event has completed (``_retire`` / ``_drain_retired``) — no device-wide synchronisation anywhere.
 
 Which counters the device copy currently equals is tracked on the cache (``kv_cache._device_counters``): anything that
 moves the host counters without going through a graph — ``clear()``, an eager prefill, an eager decode step — makes the
@@ -35,7 +44,7 @@ from typing import Callable
 
 import torch
 
-AUTO_DECODE_GRAPH = os.environ.get("DUO_AUTO_DECODE_GRAPH", "1") != "0"
+AUTO_DECODE_GRAPH = os.environ.get("DUO_AUTO_DECODE_GRAPH", "0") == "1"
 _AUTO_WARM_STEPS = 2        # eligible eager decode steps before the capture (kernels, GEMM handles and workspaces exist by then)
 
 
@@ -56,6 +65,30 @@ class RecaptureError(RuntimeError):
     """the step could not be captured again for a new length bucket (``DecodeStepGraph.replay``); no launch was issued"""
 
 
+_retired = []       # (graph object, event after its last replay): released once the event has completed
+
+
+def _drain_retired(block: bool = False) -> None:
+    """release retired graphs whose last replay is over.  Never while this thread is capturing (event queries are not
+    capture-safe, and destroying a graph there would invalidate the capture)."""
+    if not _retired or torch.cuda.is_current_stream_capturing():
+        return
+    keep = []
+    for g, ev in _retired:
+        if ev is None:
+            continue        # never replayed: nothing can be executing
+        if block:
+            ev.synchronize()
+        elif not ev.query():
+            keep.append((g, ev))
+    _retired[:] = keep
+
+
+def _retire(graph, event) -> None:
+    if graph is not None:
+        _retired.append((graph, event))
+
+
 class DecodeStepGraph:
     """``step_fn()`` must run ONE q_len == 1 forward through ``kv_cache`` (the patched model, or any loop
     over ``duo_static_attention_core``) using static input tensors, and may return its output tensor(s).
@@ -65,43 +98,63 @@ class DecodeStepGraph:
     protocol ``kv_cache.evict_last(1)``; 0 = real generation, the cache grows by one row per replay).
     Batch rows: every row of the cache shares the layer's counters (reference static_kv_cache.py:44-45), so a batched
     step is captured the same way (``duo_decode_layer_batched_dev_bf16``).
+
+    Not supported: replaying two captured MODEL steps concurrently on two streams — each graph owns its split-KV scratch
+    (``_hip.scratch_scope``), but torch's GEMM workspace is per capture stream and shared.  Replay them one after the other.
     """
 
     def __init__(self, kv_cache, step_fn: Callable[[], object], evict_after: int = 0):
+        from . import _hip
+
         if kv_cache.kv_seq_len < 1:
             raise ValueError("capture the decode step after the prefill (empty cache)")
         self.cache, self.step_fn, self.evict_after = kv_cache, step_fn, int(evict_after)
-        self._scratch = {}      # this graph's own split-KV partials / tickets (_hip.scratch_scope)
+        # this graph's own split-KV partials / tickets (_hip.scratch_scope): allocated and zeroed HERE, outside the capture,
+        # so that no allocation or memset is baked into the graph (a baked memset would clear the one-launch step's sticky
+        # give-up flag on every replay, and the memory would be uninitialised until the first one)
+        self._scratch = {}
+        _hip.prepare_graph_scratch(self._scratch, kv_cache)
         self.captures = 0
+        self.graph = self.plan_key = self.output = self._last = None
         self._capture()
 
     def _capture(self):
         from . import _hip
 
         kv_cache = self.cache
-        # a re-capture releases the previous capture's graph, whose last replay may still be executing: wait for the device
-        # BEFORE the old object goes (torch.cuda.graph() synchronises too, but only after the assignment below dropped it)
-        torch.cuda.synchronize()
+        _drain_retired()
         kv_cache.enable_device_state()
         host = (list(kv_cache.kv_seq_len_list), list(kv_cache.streaming_kv_seq_len_list))
-        self.plan_key = plan_key(kv_cache)
-        self.graph = torch.cuda.CUDAGraph()
+        new_key = plan_key(kv_cache)
+        new_graph = torch.cuda.CUDAGraph()
+        ok = False
         try:
-            with _hip.scratch_scope(self._scratch), torch.cuda.graph(self.graph):
-                self.output = self._body()
+            # (torch.cuda.graph() synchronises the device on entry: the previous capture's replays are over by the time
+            # the new launches are recorded — the old object itself is only retired below, after the capture succeeded)
+            with _hip.scratch_scope(self._scratch), torch.cuda.graph(new_graph):
+                out = self._body()
+            ok = True
         finally:
             # capture records launches without running them: device state and pools are untouched, only the
             # host mirror moved while the Python code ran
             kv_cache.kv_seq_len_list[:], kv_cache.streaming_kv_seq_len_list[:] = host
             kv_cache.use_device_state = False
+            if not ok:
+                # keep the previous graph and output, but make the next replay() try the capture again instead of
+                # replaying a grid sized for another bucket
+                self.plan_key = None
+                kv_cache.sync_device_state()
+        _retire(self.graph, self._last)
+        self.graph, self.plan_key, self.output, self._last = new_graph, new_key, out, None
         self.captures += 1
         kv_cache.sync_device_state()
 
     def __del__(self):
-        # the graph object goes with this one: never while its last replay is still executing
+        # the graph object outlives this one until its last replay is over (no device-wide wait, nothing while a capture
+        # is in progress on this thread: this destructor can run from the cyclic GC at any point)
         try:
-            if torch.cuda.is_available() and torch.cuda.is_initialized():
-                torch.cuda.synchronize()
+            _retire(self.__dict__.pop("graph", None), self.__dict__.pop("_last", None))
+            _drain_retired()
         except Exception:       # (interpreter shutdown)
             pass
 
@@ -141,6 +194,11 @@ class DecodeStepGraph:
         elif _host_counters(c) != c._device_counters:
             c.sync_device_state()
         self.graph.replay()
+        if self._last is None:
+            self._last = torch.cuda.Event()
+        self._last.record()
+        if _retired:
+            _drain_retired()
         W = c.sink_size + c.recent_size
         for i in range(c.num_layers):       # the host mirror follows: one step, then the eviction
             c.kv_seq_len_list[i] += 1
@@ -245,8 +303,7 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
     st = getattr(kv, "_auto_graph", None)
     sig = _model_signature(model, model.__dict__.pop("_duo_param_ptrs", None))
     if st is None or st["sig"] != sig:
-        if st is not None and st["graph"] is not None:
-            torch.cuda.synchronize()        # the retired step's last replay may still be executing: its graph is released here
+        # (a retired step's graph is released by DecodeStepGraph.__del__ -> _retire once its last replay is over)
         st = {"sig": sig, "calls": 0, "graph": None, "tok": None}
         kv._auto_graph = st
         kv._decode_graph = None
@@ -270,7 +327,6 @@ def auto_decode_step(model, eager_forward, input_ids, kv):
     try:
         return st["graph"].replay().clone()
     except RecaptureError as e:     # (the first capture worked, the one for the new length bucket did not: eager from here on)
-        torch.cuda.synchronize()        # (the old graph may still be executing its last replay when it is released)
         kv._auto_graph_failed, kv._decode_graph, st["graph"] = True, None, None
         warnings.warn(f"DuoAttention: re-capturing the decode step for a new context length failed ({e}); decoding eagerly.")
         return None

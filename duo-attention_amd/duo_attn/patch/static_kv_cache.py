@@ -284,9 +284,10 @@ def duo_attn_static_kv_cache_for_causal_lm_forward(
     **kwargs,
 ):
     # The reference's decode loop (eval/efficiency/benchmark_static.py:96-105) calls this once per token from Python; the
-    # step is ~230 launches.  When the call is exactly that loop's — one token, implicit positions, a static cache on this
-    # GPU, no gradients — it is served by a HIP graph captured on the way (duo_attn/graph.py: auto_decode_step); every
-    # other call, and DUO_AUTO_DECODE_GRAPH=0, runs the body below as it is.
+    # step is ~230 launches.  With DUO_AUTO_DECODE_GRAPH=1 (opt-in: worth it on a slow host or at short contexts), a call
+    # that is exactly that loop's — one token, implicit positions, a static cache on this GPU, no gradients — is served by
+    # a HIP graph captured on the way (duo_attn/graph.py: auto_decode_step); every other call, and the default, runs the
+    # body below as it is.
     from ..graph import auto_decode_eligible, auto_decode_step
 
     if auto_decode_eligible(self, input_ids, position_ids, past_key_values, inputs_embeds, labels, kwargs):

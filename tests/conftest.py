@@ -3,11 +3,10 @@ import sys
 
 import pytest
 
-# The suite runs with the product's defaults — in particular with the automatic HIP-graph capture of the reference's decode
-# loop ON (duo_attn/graph.py), here and in the worker processes the tests spawn: model-level decode, fuzz, sharded and
-# full-size parity runs go through the decode path users get.  A test that observes every decode step from Python (launch
-# counters patched onto the backend) asks for the ``eager_decode_steps`` fixture below; a backend wrapped for recording is
-# never captured in the first place (graph.auto_decode_eligible wants the genuine HipBackend).
+# The suite runs with the product's defaults: since round 6 the automatic HIP-graph capture of the reference's decode loop
+# is OPT-IN (duo_attn/graph.py; DUO_AUTO_DECODE_GRAPH=1), so model-level, fuzz, sharded and full-size runs step eagerly — the
+# path users get.  The capture keeps its own coverage: tests/test_auto_graph_gpu.py and tests/fuzz_model_decode.py switch it
+# on explicitly and compare it with the eager loop bit for bit.  An inherited environment setting must not change that.
 os.environ.pop("DUO_AUTO_DECODE_GRAPH", None)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

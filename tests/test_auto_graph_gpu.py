@@ -463,3 +463,87 @@ def test_a_failed_recapture_falls_back_to_eager_steps(monkeypatch):
     assert kv.kv_seq_len_list == ref_kv.kv_seq_len_list
     for a, b in zip(_pools(kv), _pools(ref_kv)):
         assert torch.equal(a, b)
+
+
+def test_a_direct_graph_user_can_retry_after_a_failed_recapture():
+    """``_capture`` assigns graph / plan_key / output only after the capture succeeded.  A direct
+    ``DecodeStepGraph`` user who catches ``RecaptureError`` keeps the previous output tensor, finds ``plan_key`` reset (so the
+    next ``replay()`` captures again instead of replaying an un-captured graph object), and the retried capture equals the
+    eager loop bit for bit."""
+    from duo_attn.graph import DecodeStepGraph, RecaptureError
+
+    ids = torch.randint(0, 211, (1, 100), generator=torch.Generator().manual_seed(23)).to(DEV)
+    model, kv = _setup("llama")
+    ref_model, ref_kv = _setup("llama")
+    with torch.no_grad():
+        for m, c in ((model, kv), (ref_model, ref_kv)):
+            t = m(input_ids=ids[:, :62], past_key_values=c, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+        for _ in range(2):          # warm: kernels, GEMM handles
+            model(input_ids=t, past_key_values=kv, use_cache=True)
+            kv.evict_last(1)
+    tok = t.clone()
+
+    def step():
+        with torch.no_grad():
+            return model(input_ids=tok, past_key_values=kv, use_cache=True, _duo_no_auto_graph=True).logits
+
+    g = DecodeStepGraph(kv, step, evict_after=0)
+    first_graph, first_out = g.graph, g.output
+    got = [g.replay().clone() for _ in range(2)]            # 62 -> 64 rows: still the first bucket
+    orig, fail = g._body, [True]
+
+    def body():
+        if fail[0]:
+            fail[0] = False
+            raise RuntimeError("simulated capture failure")
+        return orig()
+
+    g._body = body
+    lens = list(kv.kv_seq_len_list)
+    with pytest.raises(RecaptureError):
+        g.replay()                                          # 65 rows: the next bucket; its capture fails
+    assert g.plan_key is None and g.graph is first_graph and g.output is first_out and g.captures == 1
+    assert kv.kv_seq_len_list == lens and not kv.use_device_state
+    got += [g.replay().clone() for _ in range(3)]           # retried: captured, replayed
+    assert g.captures == 2 and g.plan_key is not None and g.graph is not first_graph
+    with torch.no_grad():
+        want = [ref_model(input_ids=t, past_key_values=ref_kv, use_cache=True).logits for _ in range(5)]
+    for s, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"step {s}"
+
+
+def test_retired_graphs_are_released_without_a_device_wide_wait():
+    """a dropped DecodeStepGraph hands its graph object to ``graph._retired`` with the event of its last replay; the list
+    drains once that event has completed — and never from inside a stream capture"""
+    from duo_attn import graph
+    from duo_attn.graph import DecodeStepGraph
+
+    ids = torch.randint(0, 211, (1, 100), generator=torch.Generator().manual_seed(29)).to(DEV)
+    model, kv = _setup("llama")
+    with torch.no_grad():
+        t = model(input_ids=ids[:, :40], past_key_values=kv, use_cache=True).logits[:, -1, :].argmax(-1).unsqueeze(1)
+        model(input_ids=t, past_key_values=kv, use_cache=True)
+        kv.evict_last(1)
+
+    def step():
+        with torch.no_grad():
+            return model(input_ids=t, past_key_values=kv, use_cache=True, _duo_no_auto_graph=True).logits
+
+    graph._drain_retired(block=True)
+    g = DecodeStepGraph(kv, step, evict_after=1)
+    for _ in range(3):
+        g.replay()
+    side = torch.cuda.Stream()
+    other = torch.cuda.CUDAGraph()
+    x = torch.zeros(8, device=DEV)
+    with torch.cuda.graph(other, stream=side):
+        del g                       # destructor inside somebody else's capture: retire only, no query, no wait
+        import gc
+        gc.collect()
+        x += 1
+    assert len(graph._retired) == 1
+    other.replay()
+    torch.cuda.synchronize()
+    assert x.sum().item() == 8      # the foreign capture survived the destructor
+    graph._drain_retired()
+    assert graph._retired == []

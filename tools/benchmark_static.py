@@ -125,8 +125,8 @@ def run(args, quiet=False):
         kv_cache.evict_last(1)
 
     def decode_fn(mode):
-        """"eager": the reference's loop, every step issued from Python (DUO_AUTO_DECODE_GRAPH=0); "loop": the SAME loop as
-        the package runs it by default — after two eager steps the step is captured and replayed behind the unchanged call
+        """"eager": the reference's loop, every step issued from Python (the default); "loop": the SAME loop with
+        DUO_AUTO_DECODE_GRAPH=1 — after two eager steps the step is captured and replayed behind the unchanged call
         (duo_attn.graph.auto_decode_step); "graph": the explicit DecodeStepGraph (evict_last inside the graph)"""
         duo_graph.AUTO_DECODE_GRAPH = mode == "loop"
         kv_cache._auto_graph = None
@@ -170,8 +170,8 @@ def run(args, quiet=False):
         "avg_generation_time_ms": gen_latency, "decode_tok_s": 1e3 / gen_latency,
         "peak_context_memory_MB": ctx_memory, "peak_generation_memory_MB": gen_memory,
         "kv_cache_memory_MB": kv_cache.memory_usage / 1024 / 1024,
-        "decode_mode": {"graph": "hip graph replay (explicit DecodeStepGraph)", "eager": "eager (DUO_AUTO_DECODE_GRAPH=0)",
-                        "loop": "the reference's unchanged loop (auto-captured HIP graph behind model(...))"}[main_mode],
+        "decode_mode": {"graph": "hip graph replay (explicit DecodeStepGraph)", "eager": "eager (the default: every step issued from Python)",
+                        "loop": "the reference's unchanged loop, DUO_AUTO_DECODE_GRAPH=1 (auto-captured HIP graph behind model(...))"}[main_mode],
     }
     if unfused_latency is not None:
         res["avg_generation_time_module_by_module_ms"] = unfused_latency
@@ -410,7 +410,7 @@ def parse(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="decode through duo_attn.graph.DecodeStepGraph (one captured step incl. evict_last, replayed)")
     ap.add_argument("--all_decode_modes", action="store_true",
-                    help="also time the decode loop eagerly (DUO_AUTO_DECODE_GRAPH=0) and as the reference's unchanged loop "
+                    help="also time the decode loop eagerly (the default) and with DUO_AUTO_DECODE_GRAPH=1 as the reference's unchanged loop "
                          "(auto-captured graph), next to the mode selected")
     ap.add_argument("--also_tuple", action="store_true",
                     help="also run the protocol through the tuple cache (enable_duo_attention_eval)")
