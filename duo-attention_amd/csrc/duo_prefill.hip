@@ -16,32 +16,41 @@
 //
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "duo_prefill_common.h"
 #include "duo_prefill_w64.h"
 
 namespace {
 
-// Combine the `ksplit` partials of one (q tile, q head): out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
-// Block = (q tile, q head of the retrieval class) in the prefill kernel's block order; thread = 32 rows x 8
-// column groups of 16 dims per pass, 8 passes.
+// Combine the ks[c] partials of one (q tile, q head): out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
+// Block = one split item, class 0's first, in the canonical item order of prefill_map_block (q-tile rank, kv head, q head
+// of the group); thread = 32 rows x 8 column groups of 16 dims per pass, 8 passes.
 template <bool F16>
-__global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillParams P) {
-    const DuoClassDev C = P.cls[0];
+__global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillParams P, int n_merge0) {
+    int j = blockIdx.x;
+    const int ci = j < n_merge0 ? 0 : 1;
+    if (ci) j -= n_merge0;
+    const DuoClassDev &C = ci ? P.cls[1] : P.cls[0];
+    const int ks = ci ? P.ks[1] : P.ks[0];
     const int nq_c = C.n_kv_heads * P.group;
-    const int b = blockIdx.x;
-    const int tile = P.n_qtiles - 1 - b / nq_c;
-    const int p = b % nq_c;
-    const int kvh = p % C.n_kv_heads;
-    const int g = p / C.n_kv_heads;
+    const int rank = j / nq_c;
+    const int tile = P.n_qtiles - 1 - rank;
+    const int p = j - rank * nq_c;
+    const int kvh = p / P.group;
+    const int g = p - kvh * P.group;
     const int qh = C.q_head_offset + kvh * P.group + g;
-    const int ks = P.ksplit;
-    const int j = threadIdx.x & 7;
+    const int64_t part0 = (int64_t)(ci ? P.pbase[1] : P.pbase[0]) + (int64_t)j * ks + (int64_t)blockIdx.y * P.nparts;
+    const int jd = threadIdx.x & 7;
     for (int pass = 0; pass < 8; ++pass) {
         const int r = pass * 32 + (threadIdx.x >> 3);
         const int q = tile * QBLK + r;
         if (q >= P.S) continue;
-        const int64_t row0 = ((int64_t)b * ks + (int64_t)blockIdx.y * P.nblk_full) * QBLK + r;     // split s: + s * QBLK
+        const int64_t row0 = part0 * QBLK + r;     // piece s: + s * QBLK
         float M = -INFINITY;
         for (int s = 0; s < ks; ++s) M = fmaxf(M, P.ws_ml[(row0 + (int64_t)s * QBLK) * 2]);
         float L = 0.f;
@@ -51,15 +60,15 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
         for (int s = 0; s < ks; ++s) {
             const int64_t row = row0 + (int64_t)s * QBLK;
             const float m = P.ws_ml[row * 2], l = P.ws_ml[row * 2 + 1];
-            if (m == -INFINITY) continue;      // this split saw no key of the row: nothing to add
+            if (m == -INFINITY) continue;      // this piece saw no key of the row: nothing to add
             const float w = fast_exp2((m - M) * P.scale_log2e);
             L = fmaf(l, w, L);
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(P.ws_o + row * DUO_HEAD_DIM + 16 * j);
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(P.ws_o + row * DUO_HEAD_DIM + 16 * jd);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = acc[i] + src[i] * w;
         }
         const float inv = 1.f / L;
-        bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * j;
+        bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * jd;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 w2;
@@ -76,33 +85,249 @@ static uint32_t g_debug_flags = 0;
 extern "C" void duo_set_debug_flags(uint32_t flags) { g_debug_flags = flags; }
 extern "C" uint32_t duo_get_debug_flags(void) { return g_debug_flags; }
 
-// Key-range splits of the retrieval class.  One workgroup per CU is resident (96 KiB of LDS), so a launch
-// whose long workgroups (retrieval q heads x q tiles) are fewer than the CUs — small chunks, layers with
-// one or two retrieval kv heads — or not a multiple of them leaves CUs idle for the whole launch while
-// the streaming-head workgroups are short.  With k splits the long work becomes L0*k workgroups of 1/k the
-// length: pick the k that minimises rounds(L0*k) / k, with a small charge per split for the merge pass.
+// ------------------------------------------------------------------------------------------------------------------
+// Launch planner: key-range splits per head class.
+//
+// One workgroup per CU is resident (96 KiB of LDS), the dispatcher hands the next block id to the first CU that frees up,
+// and the blocks of a launch are far from equal: retrieval-class workgroups walk the whole pool (hundreds to thousands of
+// 64-key tiles), streaming-class ones the window plus the chunk's own rows (6 ... 262 tiles).  A launch whose long
+// workgroups are fewer than the CUs, or not a multiple of them — small chunks, ROW BLOCKS of the layer pipeline, layers
+// with one to three retrieval kv heads — leaves CUs idle while the last round drains, and the short workgroups that
+// backfill behind 256 equal long ones run on however few CUs are free first.  Rounds 1-5 chose the retrieval class's
+// split count k from rounds(long * k) / k; that ignores the streaming class and the q tiles' different lengths, and it
+// measured 0.935 / 0.872 / 0.748 of the whole-chunk rate on 4096- / 2048- / 1024-row blocks (profiles/r5_scaling_model.md).
+//
+// Now the launch is REPLAYED on paper for every candidate (k0, k1): list scheduling of the blocks, in block order, on
+// 256 CUs, a block costing t_fix + tiles * t_tile, plus the merge pass (t_merge + partials * t_part) when anything is
+// split — the model that reproduces those three measured figures to 1 % (tools/prefill_plan_model.py) — and the cheapest
+// candidate wins.  Both classes can be split (a streaming head's 262-tile workgroups halve), the count goes up to 16, and
+// the XCD-aware block order now covers split launches too (one key-range piece of one kv head = one K/V stream).
+// Plans are memoised by launch shape: one replay per distinct (head counts, past, rows) — the 32 layers of a chunk share
+// seven or eight of them.
+// ------------------------------------------------------------------------------------------------------------------
 constexpr int64_t kPrefillPartialBytes = (int64_t)QBLK * (DUO_HEAD_DIM + 2) * sizeof(float);
-static int prefill_choose_ksplit(int long_wgs, int min_tiles, int64_t workspace_bytes) {
-    static const int forced = [] {
-        const char *e = getenv("DUO_PREFILL_KSPLIT");   // tuning / test knob: force a split count
-        return e ? atoi(e) : 0;
+constexpr int kPrefillMaxSplit = 16;
+constexpr int kPrefillCUs = 256;
+
+namespace {
+struct PlanCost {
+    double t_tile, t_fix, t_merge, t_part, t_pad;     // microseconds
+};
+static const PlanCost &plan_cost() {
+    // defaults: fitted to same-box probes of this kernel (profiles/r6_prefill_plan.md); DUO_PREFILL_PLAN_COST overrides
+    static const PlanCost c = [] {
+        PlanCost v{1.73, 6.0, 6.0, 0.05, 1.0};
+        if (const char *e = getenv("DUO_PREFILL_PLAN_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad);
+        return v;
     }();
-    if (long_wgs <= 0 || workspace_bytes <= 0) return 1;
-    const int kmax = (int)std::min<int64_t>(8, std::min<int64_t>(min_tiles, workspace_bytes / (kPrefillPartialBytes * long_wgs)));
-    if (g_debug_flags & 256u) return 1;      // debug bit 8: no key-range split
-    if (forced > 0) return std::max(1, std::min(forced, kmax));
-    if ((g_debug_flags >> 12) & 15u) return std::max(1, std::min((int)((g_debug_flags >> 12) & 15u), kmax));   // bits 12-15: tests force a count
-    int best = 1;
-    double best_cost = 1e30;
-    for (int k = 1; k <= kmax; ++k) {
-        const double rounds = (double)((long_wgs * k + 255) / 256);
-        const double cost = rounds / k + 0.03 * (k - 1);
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = k; }
+    return c;
+}
+
+struct PlanShape {
+    int32_t nkv[2], group, nq, S, lenA[2], lenB[2], max_parts, xmap1;
+    uint32_t force;
+    bool operator==(const PlanShape &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct PlanShapeHash {
+    size_t operator()(const PlanShape &k) const {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&k);
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < sizeof(PlanShape) / 4; ++i) h = (h ^ w[i]) * 1099511628211ull;
+        return (size_t)h;
+    }
+};
+struct PrefillPlan {
+    int ks[2];
+    double est_us, est_unsplit_us;
+};
+
+// tiles of class c's (q tile of rank r): segment A + the causal tiles of segment B up to the tile's last row
+static inline int plan_tiles(const PlanShape &K, int c, int rank) {
+    const int tile = K.nq - 1 - rank;
+    const int last_q = std::min(tile * QBLK + QBLK - 1, K.S - 1);
+    const int nA = (K.lenA[c] + KVBLK - 1) / KVBLK;
+    return nA + (last_q + (K.lenB[c] - K.S)) / KVBLK + 1;
+}
+
+// fills the order-related fields of P for the split counts (k0, k1); returns the number of blocks of the launch
+static int plan_layout(PrefillParams &P, const PlanShape &K, int k0, int k1, bool xmap0, bool xmap1) {
+    const int ks[2] = {k0, k1};
+    int nblk_c[2] = {0, 0}, parts = 0;
+    for (int c = 0; c < 2; ++c) {
+        P.ks[c] = ks[c];
+        P.xmap_rows[c] = P.xmap_q[c] = 0;
+        P.pbase[c] = parts;
+        if (K.nkv[c] <= 0) continue;
+        const int items = K.nkv[c] * K.group * K.nq;
+        if (ks[c] > 1) parts += items * ks[c];
+        nblk_c[c] = items * ks[c];
+        if (c == 0 ? xmap0 : xmap1) {
+            const int row_items = K.nkv[c] * ks[c] * K.group;
+            int rows = 1;
+            while ((rows * row_items) % 8 != 0) rows *= 2;       // 1, 2, 4 or 8 rows: the first multiple of 8 workgroups
+            const int periods = (K.nq + rows - 1) / rows;
+            P.xmap_rows[c] = rows;
+            P.xmap_q[c] = rows * row_items / 8;
+            nblk_c[c] = periods * rows * row_items;               // the padded last period
+        } else if (c == 0) {
+            nblk_c[0] = (nblk_c[0] + 7) & ~7;                     // class 1's block ids keep their XCD (b % 8); extra blocks map past n_qtiles
+        }
+    }
+    P.nparts = parts;
+    P.nblk_full = nblk_c[0];
+    return nblk_c[0] + nblk_c[1];
+}
+
+static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool xmap1, const int *tiles /* [2][nq] */) {
+    PrefillParams P{};
+    P.group = K.group;
+    P.n_qtiles = K.nq;
+    P.cls[0].n_kv_heads = K.nkv[0];
+    P.cls[1].n_kv_heads = K.nkv[1];
+    const int nblk = plan_layout(P, K, k0, k1, xmap0, xmap1);
+    const PlanCost &C = plan_cost();
+    // min-heap of the CUs' free times
+    double heap[kPrefillCUs];
+    for (int i = 0; i < kPrefillCUs; ++i) heap[i] = 0.0;
+    double end = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const PrefillItem I = prefill_map_block(P, b);
+        double cost = C.t_pad;
+        if (I.tile >= 0) {
+            const int nT = tiles[I.ci * K.nq + (K.nq - 1 - I.tile)];
+            const int n = (int)((int64_t)(I.split + 1) * nT / I.ks) - (int)((int64_t)I.split * nT / I.ks);
+            cost = C.t_fix + C.t_tile * n;
+        }
+        // replace the root (earliest free CU) and sift down
+        const double t = heap[0] + cost;
+        end = std::max(end, t);
+        int i = 0;
+        for (;;) {
+            int l = 2 * i + 1, r = l + 1, m = i;
+            double mv = t;
+            if (l < kPrefillCUs && heap[l] < mv) { m = l; mv = heap[l]; }
+            if (r < kPrefillCUs && heap[r] < mv) { m = r; mv = heap[r]; }
+            if (m == i) break;
+            heap[i] = heap[m];
+            i = m;
+        }
+        heap[i] = t;
+    }
+    if (P.nparts > 0) end += C.t_merge + C.t_part * P.nparts;
+    return end;
+}
+
+static PrefillPlan plan_compute(const PlanShape &K, bool xmap0) {
+    PrefillPlan best{{1, 1}, 0.0, 0.0};
+    std::vector<int> tiles(2 * (size_t)K.nq, 0);
+    int kmax[2] = {1, 1};
+    for (int c = 0; c < 2; ++c) {
+        if (K.nkv[c] <= 0) continue;
+        int mn = 1 << 30;
+        for (int r = 0; r < K.nq; ++r) {
+            tiles[c * K.nq + r] = plan_tiles(K, c, r);
+            mn = std::min(mn, tiles[c * K.nq + r]);
+        }
+        kmax[c] = std::max(1, std::min(kPrefillMaxSplit, mn));     // every piece walks at least one tile
+    }
+    const int items[2] = {K.nkv[0] * K.group * K.nq, K.nkv[1] * K.group * K.nq};
+    auto fits = [&](int k0, int k1) {
+        const int64_t parts = (k0 > 1 ? (int64_t)items[0] * k0 : 0) + (k1 > 1 ? (int64_t)items[1] * k1 : 0);
+        return parts <= K.max_parts;
+    };
+    const int f0 = (int)(K.force & 0xffu), f1 = (int)((K.force >> 8) & 0xffu);
+    if (K.force & 0x10000u) return best;                      // no split at all
+    if (f0 || f1) {                                            // forced counts (tests, tuning): clamp to what is legal
+        int k0 = f0 ? std::min(f0, kmax[0]) : 1, k1 = f1 ? std::min(f1, kmax[1]) : 1;
+        while (k0 > 1 && !fits(k0, k1)) --k0;
+        while (k1 > 1 && !fits(k0, k1)) --k1;
+        best.ks[0] = k0;
+        best.ks[1] = k1;
+        best.est_unsplit_us = plan_replay(K, 1, 1, xmap0, K.xmap1 != 0, tiles.data());
+        best.est_us = (k0 == 1 && k1 == 1) ? best.est_unsplit_us : plan_replay(K, k0, k1, xmap0, K.xmap1 != 0, tiles.data());
+        return best;
+    }
+    best.est_unsplit_us = best.est_us = plan_replay(K, 1, 1, xmap0, K.xmap1 != 0, tiles.data());
+    static const int cand0[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16}, cand1[] = {1, 2, 3, 4};
+    for (int k0 : cand0) {
+        if (k0 > kmax[0]) break;
+        for (int k1 : cand1) {
+            if (k1 > kmax[1]) break;
+            if (k0 == 1 && k1 == 1) continue;
+            if (!fits(k0, k1)) continue;
+            // more than 16 rounds of workgroups: the last round's quantisation is below what another split costs (and the
+            // replay stays cheap)
+            if ((int64_t)items[0] * k0 + (int64_t)items[1] * k1 > 16 * kPrefillCUs) continue;
+            const double t = plan_replay(K, k0, k1, xmap0, K.xmap1 != 0, tiles.data());
+            if (t < best.est_us * 0.995) {      // a split must buy at least half a per cent
+                best.est_us = t;
+                best.ks[0] = k0;
+                best.ks[1] = k1;
+            }
+        }
     }
     return best;
 }
 
-extern "C" int64_t duo_attn_prefill_workspace_bytes(void) { return 1024 * kPrefillPartialBytes; }
+static PrefillPlan plan_lookup(const PlanShape &K, bool xmap0) {
+    static std::mutex mu;
+    static std::unordered_map<PlanShape, PrefillPlan, PlanShapeHash> memo;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = memo.find(K);
+        if (it != memo.end()) return it->second;
+    }
+    const PrefillPlan p = plan_compute(K, xmap0);
+    std::lock_guard<std::mutex> g(mu);
+    if (memo.size() > 65536) memo.clear();
+    memo.emplace(K, p);
+    return p;
+}
+}  // namespace
+
+// the plan of the last prefill launch of this thread (tests, tools/debug probes): {k0, k1, estimated us, estimated us unsplit}
+static thread_local double g_last_plan[4] = {1, 1, 0, 0};
+extern "C" void duo_debug_prefill_last_plan(double *out4) {
+    for (int i = 0; i < 4; ++i) out4[i] = g_last_plan[i];
+}
+// Host-only: the plan the launcher would choose for a launch shape, and (blocks != NULL) the work of every block id of
+// that launch — {class, q tile or -1, kv head, q head of the group, piece, partial slot} — as the kernels map it.  No GPU
+// needed: tests/test_prefill_plan.py checks on the CPU that every (class, q tile, q head, piece) is covered exactly once.
+// shape = {n_kv_heads of class 0, of class 1, group, n_tokens, lenA0, lenB0, lenA1, lenB1, max partials, xmap (bit 0: class
+// 0, bit 1: class 1)}; force: bits 0-7 / 8-15 forced piece counts, bit 16 no split.  out = {k0, k1, blocks, partials,
+// blocks of class 0}.  Returns the number of blocks (also when `blocks` is too small to hold them).
+extern "C" int32_t duo_debug_prefill_plan(const int32_t *shape, uint32_t force, int32_t *out5, double *est2,
+                                          int32_t *blocks, int32_t blocks_cap) {
+    if (!shape || !out5) return DUO_EINVAL;
+    PlanShape K;
+    memset(&K, 0, sizeof(K));
+    K.nkv[0] = shape[0]; K.nkv[1] = shape[1]; K.group = shape[2]; K.S = shape[3];
+    K.lenA[0] = K.nkv[0] > 0 ? shape[4] : 0; K.lenB[0] = K.nkv[0] > 0 ? shape[5] : 0;
+    K.lenA[1] = K.nkv[1] > 0 ? shape[6] : 0; K.lenB[1] = K.nkv[1] > 0 ? shape[7] : 0;
+    K.max_parts = shape[8];
+    K.nq = (K.S + QBLK - 1) / QBLK;
+    const bool xmap0 = shape[9] & 1, xmap1 = (shape[9] & 2) != 0;
+    K.xmap1 = xmap1;
+    K.force = K.max_parts <= 0 ? 0x10000u : force;
+    if (K.group <= 0 || K.S <= 0 || K.nkv[0] < 0 || K.nkv[1] < 0) return DUO_EINVAL;
+    const PrefillPlan plan = plan_compute(K, xmap0);
+    PrefillParams P{};
+    P.group = K.group;
+    P.n_qtiles = K.nq;
+    P.cls[0].n_kv_heads = K.nkv[0];
+    P.cls[1].n_kv_heads = K.nkv[1];
+    const int nblk = plan_layout(P, K, plan.ks[0], plan.ks[1], xmap0, xmap1);
+    out5[0] = plan.ks[0]; out5[1] = plan.ks[1]; out5[2] = nblk; out5[3] = P.nparts; out5[4] = P.nblk_full;
+    if (est2) { est2[0] = plan.est_us; est2[1] = plan.est_unsplit_us; }
+    for (int b = 0; blocks && b < nblk && b < blocks_cap; ++b) {
+        const PrefillItem I = prefill_map_block(P, b);
+        int32_t *o = blocks + 6 * (int64_t)b;
+        o[0] = I.ci; o[1] = I.tile; o[2] = I.kvh; o[3] = I.g; o[4] = I.split; o[5] = I.part;
+    }
+    return nblk;
+}
+
+extern "C" int64_t duo_attn_prefill_workspace_bytes(void) { return 2048 * kPrefillPartialBytes; }
 
 template <bool F16>
 static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_stride,
@@ -143,77 +368,98 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         }
         nblk += C.n_kv_heads * group * P.n_qtiles;
     }
-    // split the retrieval class when that fills the chip better (needs the caller's workspace)
-    const int long_wgs = P.cls[0].n_kv_heads * group * P.n_qtiles;
-    P.ksplit = 1;
-    P.ws_o = nullptr;
-    P.ws_ml = nullptr;
-    if (workspace && long_wgs > 0) {
-        const int min_tiles = (P.cls[0].a.len + KVBLK - 1) / KVBLK + 1;   // tiles of the first q tile
-        P.ksplit = prefill_choose_ksplit(long_wgs, min_tiles, workspace_bytes / n_batch);   // every batch row has its own partials
-        if (P.ksplit > 1) {
-            P.ws_o = (float *)workspace;
-            P.ws_ml = P.ws_o + (int64_t)n_batch * long_wgs * P.ksplit * QBLK * DUO_HEAD_DIM;
-            nblk += long_wgs * (P.ksplit - 1);
-        }
-    }
     if ((q_token_stride | q_head_stride) & 7) return DUO_EINVAL;
     if ((out_token_stride | out_head_stride) & 3) return DUO_EINVAL;
     if (nblk == 0) return 0;
-    P.nblk_full = long_wgs * P.ksplit;
-    P.xmap_rows = P.xmap_q = 0;
 
     hipStream_t st = (hipStream_t)stream;
     const bool tr = !(g_debug_flags & 1u);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) return DUO_EINVAL;
     // 4-wave x 64-row kernel (duo_prefill_w64.h): the default for bf16 and fp16 with the
-    // transposed-V LDS layout; the gather debug path runs on the 8-wave kernel above.  DUO_PREFILL_W64=0 (or debug
+    // transposed-V LDS layout; the gather debug path runs on the 8-wave kernel.  DUO_PREFILL_W64=0 (or debug
     // flag bit 7) keeps the 8-wave kernel everywhere (same-box A/B, tests of both kernels).
     static const bool want_w64 = [] { const char *e = getenv("DUO_PREFILL_W64"); return !e || atoi(e) != 0; }();
+    const bool w64_ok = want_w64 && tr && !(g_debug_flags & 128u);
+    // XCD-aware block order (DUO_PREFILL_XMAP=0 / debug bit 10: plain order; DUO_PREFILL_XMAP1=0: plain order for the
+    // streaming class only)
+    static const bool want_xmap = [] { const char *e = getenv("DUO_PREFILL_XMAP"); return !e || atoi(e) != 0; }();
+    static const bool want_xmap1 = [] { const char *e = getenv("DUO_PREFILL_XMAP1"); return !e || atoi(e) != 0; }();
+    const bool xmap0 = w64_ok && want_xmap && !(g_debug_flags & 1024u);
+    const bool xmap1 = xmap0 && want_xmap1;
+
+    // ---- plan: key-range splits per class (needs the caller's workspace) ----------------------------------------------
+    PlanShape K;
+    memset(&K, 0, sizeof(K));
+    for (int c = 0; c < 2; ++c) {
+        K.nkv[c] = P.cls[c].n_kv_heads;
+        K.lenA[c] = K.nkv[c] > 0 ? P.cls[c].a.len : 0;
+        K.lenB[c] = K.nkv[c] > 0 ? P.cls[c].b.len : 0;
+    }
+    K.group = group;
+    K.nq = P.n_qtiles;
+    K.S = n_tokens;
+    K.xmap1 = xmap1;
+    K.max_parts = workspace ? (int32_t)std::min<int64_t>(workspace_bytes / n_batch / kPrefillPartialBytes, 1 << 20) : 0;   // every batch row has its own partials
     {
-        bool w64_ok = want_w64 && tr && !(g_debug_flags & 128u);
-        // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
-        // included: +9 ... +14 %, profiles/r2_prefill_w64.md; debug bit 8 = never split the key range, so tests reach it
-        // on short launches too)
-        if (w64_ok) {
-            static std::atomic<bool> w64_attr[64][2];
-            const void *wfn = F16 ? (const void *)duo_prefill_w64_f16_kernel : (const void *)duo_prefill_w64_kernel;
-            if (dev >= 64 || !w64_attr[dev][F16].load(std::memory_order_acquire)) {
-                hipError_t e = hipFuncSetAttribute(wfn,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-                if (e != hipSuccess) return (int)e;
-                if (dev < 64) w64_attr[dev][F16].store(true, std::memory_order_release);
+        static const int forced0 = [] { const char *e = getenv("DUO_PREFILL_KSPLIT"); return e ? atoi(e) : 0; }();    // tuning / test knobs: force a split count
+        static const int forced1 = [] { const char *e = getenv("DUO_PREFILL_KSPLIT1"); return e ? atoi(e) : 0; }();
+        static const bool legacy = [] { const char *e = getenv("DUO_PREFILL_PLANNER"); return e && atoi(e) == 0; }();
+        int f0 = forced0 > 0 ? forced0 : (int)((g_debug_flags >> 12) & 15u);     // debug bits 12-15 / 16-19: tests force a count
+        int f1 = forced1 > 0 ? forced1 : (int)((g_debug_flags >> 16) & 15u);
+        if (legacy && !f0 && !f1) {
+            // the round-1..5 policy (same-box A/B): retrieval class only, k <= 8, rounds(long * k) / k + 0.03 (k - 1)
+            const int long_wgs = K.nkv[0] * group * K.nq;
+            f0 = 1;
+            if (long_wgs > 0 && K.max_parts > 0) {
+                const int kmax = (int)std::min<int64_t>(8, std::min<int64_t>(plan_tiles(K, 0, K.nq - 1), K.max_parts / long_wgs));
+                double best_cost = 1e30;
+                for (int k = 1; k <= kmax; ++k) {
+                    const double cost = (double)((long_wgs * k + 255) / 256) / k + 0.03 * (k - 1);
+                    if (cost < best_cost - 1e-9) { best_cost = cost; f0 = k; }
+                }
             }
-            // XCD-aware order of the retrieval class (unsplit launches; DUO_PREFILL_XMAP=0 / debug bit 10: plain order)
-            static const bool want_xmap = [] { const char *e = getenv("DUO_PREFILL_XMAP"); return !e || atoi(e) != 0; }();
-            if (want_xmap && !(g_debug_flags & 1024u) && P.ksplit == 1 && long_wgs > 0) {
-                const int row_items = P.cls[0].n_kv_heads * group;
-                int rows = 1;
-                while ((rows * row_items) % 8 != 0) rows *= 2;       // 1, 2, 4 or 8 rows: the first multiple of 8 workgroups
-                const int periods = (P.n_qtiles + rows - 1) / rows;
-                P.xmap_rows = rows;
-                P.xmap_q = rows * row_items / 8;
-                nblk += periods * rows * row_items - P.nblk_full;     // the padded last period
-                P.nblk_full = periods * rows * row_items;
-            }
-            if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
-            else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
-            DUO_HIP_CHECK_LAUNCH();
-            if (P.ksplit > 1) {
-                hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs, n_batch), dim3(256), 0, st, P);
-                DUO_HIP_CHECK_LAUNCH();
-            }
-            return 0;
         }
+        K.force = (uint32_t)std::min(f0, 255) | ((uint32_t)std::min(f1, 255) << 8);
+        if ((g_debug_flags & 256u) || K.max_parts <= 0) K.force = 0x10000u;      // debug bit 8: no key-range split
+    }
+    const PrefillPlan plan = plan_lookup(K, xmap0);
+    g_last_plan[0] = plan.ks[0]; g_last_plan[1] = plan.ks[1]; g_last_plan[2] = plan.est_us; g_last_plan[3] = plan.est_unsplit_us;
+    nblk = plan_layout(P, K, plan.ks[0], plan.ks[1], xmap0, xmap1);
+    P.ws_o = nullptr;
+    P.ws_ml = nullptr;
+    if (P.nparts > 0) {
+        P.ws_o = (float *)workspace;
+        P.ws_ml = P.ws_o + (int64_t)n_batch * P.nparts * QBLK * DUO_HEAD_DIM;
+    }
+    const int n_merge0 = P.ks[0] > 1 ? K.nkv[0] * group * K.nq : 0, n_merge1 = P.ks[1] > 1 ? K.nkv[1] * group * K.nq : 0;
+
+    if (w64_ok) {
+        // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
+        // included: +9 ... +14 %, profiles/r2_prefill_w64.md)
+        static std::atomic<bool> w64_attr[64][2];
+        const void *wfn = F16 ? (const void *)duo_prefill_w64_f16_kernel : (const void *)duo_prefill_w64_kernel;
+        if (dev >= 64 || !w64_attr[dev][F16].load(std::memory_order_acquire)) {
+            hipError_t e = hipFuncSetAttribute(wfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+            if (e != hipSuccess) return (int)e;
+            if (dev < 64) w64_attr[dev][F16].store(true, std::memory_order_release);
+        }
+        if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
+        else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
+        DUO_HIP_CHECK_LAUNCH();
+        if (n_merge0 + n_merge1 > 0) {
+            hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(n_merge0 + n_merge1, n_batch), dim3(256), 0, st, P, n_merge0);
+            DUO_HIP_CHECK_LAUNCH();
+        }
+        return 0;
     }
     {       // debug / cross-check paths: the 8-wave x 32-row kernel (duo_prefill_w32_debug.hip)
         const int rc = duo_prefill_w32_launch(&P, tr, F16, nblk, n_batch, dev, st);
         if (rc) return rc;
     }
     DUO_HIP_CHECK_LAUNCH();
-    if (P.ksplit > 1) {
-        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(long_wgs, n_batch), dim3(256), 0, st, P);
+    if (n_merge0 + n_merge1 > 0) {
+        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(n_merge0 + n_merge1, n_batch), dim3(256), 0, st, P, n_merge0);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;

@@ -24,23 +24,77 @@ struct PrefillParams {
     int32_t S;
     int32_t group;
     int32_t n_qtiles;
-    int32_t nblk_full;     // cls[0] q heads * n_qtiles
+    int32_t nblk_full;     // workgroups of class 0 (its key-range pieces and the padding of its last XCD period included)
     DuoClassDev cls[2];
     float scale_log2e;
     uint32_t flags;
-    // key-range splits of the retrieval class (class 0): each (q tile, q head) is covered by `ksplit`
-    // workgroups that walk disjoint ranges of its K/V tiles and leave un-normalised partials (O, m, l) in
-    // the workspace for duo_prefill_merge_kernel.  1 = no split (the workgroup writes `out` itself).
-    int32_t ksplit;
-    float *ws_o;     // [block][256 rows][128] fp32
-    float *ws_ml;    // [block][256 rows][2]   (row max in score units, row sum)
-    // XCD-aware block order of the retrieval class (4-wave kernel, unsplit launches; see duo_prefill_w64_kernel.inc):
-    // q-tile rows per period and workgroups per XCD per period; xmap_q == 0: plain q-tile-major order
-    int32_t xmap_rows, xmap_q;
+    // key-range splits, per head class: each (q tile, q head) of class c is covered by ks[c] workgroups that walk
+    // disjoint ranges of its K/V tiles and leave un-normalised partials (O, m, l) in the workspace for
+    // duo_prefill_merge_kernel.  1 = no split (the workgroup writes `out` itself).  Chosen per launch by the planner in
+    // duo_prefill.hip (a list-scheduling replay of the launch on the chip's 256 CUs).
+    int32_t ks[2];
+    int32_t pbase[2];      // first partial of class c (partials of one batch row; unused when ks[c] == 1)
+    int32_t nparts;        // partials per batch row
+    float *ws_o;     // [partial][256 rows][128] fp32
+    float *ws_ml;    // [partial][256 rows][2]   (row max in score units, row sum)
+    // XCD-aware block order of class c (4-wave kernel; see prefill_map_block): q-tile rows per period and workgroups per
+    // XCD per period; xmap_q[c] == 0: plain q-tile-major order
+    int32_t xmap_rows[2], xmap_q[2];
     // batched launch: grid.y = batch row; q / out rows of a batch row are q_bs / o_bs elements apart, the segments carry
-    // their own batch strides, every row has nblk_full partials of its own in the workspace
+    // their own batch strides, every row has nparts partials of its own in the workspace
     int64_t q_bs, o_bs;
 };
+
+// block -> (class, q tile, kv head, q head of the group, key-range piece).  One place for both prefill kernels and the
+// merge kernel's inverse (prefill_item_of).
+//
+// Plain order (xmap_q == 0): pieces of one (q tile, q head) are adjacent block ids, q heads next (kv head fastest: group
+// mates sit n_kv_heads items apart), q tiles heaviest (latest) first.
+// XCD-aware order (xmap_q > 0): workgroup b runs on XCD b % 8 (round-robin dispatch; class 0 starts at block 0 and is
+// padded to a multiple of 8 blocks, so the same holds for class 1), and each XCD has its own L2, so one K/V stream — a kv
+// head, or with key-range splits ONE PIECE of a kv head: a "virtual head" vh = kvh * ks + piece — should be read by as
+// few XCDs as possible, for every head count, not only the divisors of 8.  A period = xmap_rows q-tile rows = 8 * xmap_q
+// workgroups (the smallest whole number of rows that deals every XCD the same count); inside a period the workgroups are
+// laid out VIRTUAL-HEAD-major and XCD x takes the contiguous positions [x * xmap_q, (x + 1) * xmap_q): one or two streams
+// per XCD, every XCD the same work per period, periods heaviest (latest q tiles) first.  Workgroups of a padded last
+// period (n_qtiles not a multiple of xmap_rows) have no tile: `tile` < 0, and they leave.
+struct PrefillItem {
+    int ci, tile, kvh, g, split, ks;
+    int part;       // partial slot of this workgroup inside one batch row's partials (valid when ks > 1)
+};
+__host__ __device__ __forceinline__ PrefillItem prefill_map_block(const PrefillParams &P, int b) {
+    PrefillItem I;
+    I.ci = b < P.nblk_full ? 0 : 1;
+    if (I.ci) b -= P.nblk_full;
+    const int nkv = I.ci ? P.cls[1].n_kv_heads : P.cls[0].n_kv_heads;
+    const int xq = I.ci ? P.xmap_q[1] : P.xmap_q[0], xrows = I.ci ? P.xmap_rows[1] : P.xmap_rows[0];
+    I.ks = I.ci ? P.ks[1] : P.ks[0];
+    const int nq_c = nkv * P.group;
+    int rank;
+    if (xq > 0) {
+        const int x = b & 7, r = b >> 3;
+        const int per = r / xq, j = r - per * xq;
+        const int w = x * xq + j;
+        const int per_head = xrows * P.group;
+        const int vh = w / per_head;
+        const int e = w - vh * per_head;
+        const int row = e / P.group;
+        I.g = e - row * P.group;
+        I.kvh = vh / I.ks;
+        I.split = vh - I.kvh * I.ks;
+        rank = per * xrows + row;
+    } else {
+        I.split = b % I.ks;
+        b /= I.ks;
+        rank = b / nq_c;
+        const int p = b - rank * nq_c;
+        I.kvh = p % nkv;                   // group mates sit n_kv_heads items apart
+        I.g = p / nkv;
+    }
+    I.tile = rank < P.n_qtiles ? P.n_qtiles - 1 - rank : -1;
+    I.part = (I.ci ? P.pbase[1] : P.pbase[0]) + ((rank * nkv + I.kvh) * P.group + I.g) * I.ks + I.split;
+    return I;
+}
 
 typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;

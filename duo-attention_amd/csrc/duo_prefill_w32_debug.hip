@@ -45,24 +45,18 @@ __global__ __launch_bounds__(512) void duo_prefill_kernel(const PrefillParams P)
     const int hi = lane >> 5;
     const int lane15 = lane & 15;
 
-    // ---- block -> (class, q tile, kv head, q head) --------------------------
-    int b = blockIdx.x;
-    const int ci = b < P.nblk_full ? 0 : 1;
-    if (ci) b -= P.nblk_full;
+    // ---- block -> (class, q tile, kv head, q head, key-range piece): prefill_map_block (duo_prefill_common.h) ----
+    const PrefillItem I = prefill_map_block(P, blockIdx.x);
+    if (I.tile < 0) return;           // padding of the last XCD period
+    const int ci = I.ci;
     const int by = blockIdx.y;        // batch row
     DuoClassDev Crow = duo_select(P.cls[0], P.cls[1], ci != 0);
     duo_class_batch_row(Crow, by);
     const DuoClassDev C = Crow;
-    // key-range split (retrieval class only): the splits of one (q tile, q head) are adjacent block ids
-    const int ks = ci == 0 ? P.ksplit : 1;
-    const int split = b % ks;
-    const int part_id = b + by * P.nblk_full;   // index of this workgroup's partial in the workspace
-    b /= ks;
-    const int nq_c = C.n_kv_heads * P.group;
-    const int tile = P.n_qtiles - 1 - b / nq_c;   // heaviest (latest) tiles first
-    const int p = b % nq_c;
-    const int kvh = p % C.n_kv_heads;             // group mates sit 8 blocks apart -> same XCD
-    const int g = p / C.n_kv_heads;
+    const int ks = I.ks;
+    const int split = I.split;
+    const int part_id = I.part + by * P.nparts;   // index of this workgroup's partial in the workspace
+    const int tile = I.tile, kvh = I.kvh, g = I.g;
     const int qh = C.q_head_offset + kvh * P.group + g;
 
     const int S = P.S;

@@ -18,7 +18,7 @@ import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_PKG_DIR, "..", "lib", "libduoattn_hip.so"))
-ABI_VERSION = 5
+ABI_VERSION = 6
 HEAD_DIM = 128
 
 
@@ -133,6 +133,9 @@ _SIGNATURES = {
     "duo_error_string": (c_char_p, [ctypes.c_int]),
     "duo_set_debug_flags": (None, [c_uint32]),
     "duo_get_debug_flags": (c_uint32, []),
+    "duo_debug_prefill_last_plan": (None, [POINTER(ctypes.c_double)]),
+    "duo_debug_prefill_plan": (c_int32, [POINTER(c_int32), c_uint32, POINTER(c_int32), POINTER(ctypes.c_double),
+                                         POINTER(c_int32), c_int32]),
     "duo_rope_inplace_bf16": (
         ctypes.c_int,
         [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int64,
@@ -1203,3 +1206,32 @@ def attn_decode_int4_batched(q: torch.Tensor, out: torch.Tensor, group: int, ful
 
 def set_debug_flags(flags: int):
     load_library().duo_set_debug_flags(int(flags) | _ENV_DEBUG_FLAGS)
+
+
+def last_prefill_plan():
+    """(key-range pieces of the retrieval class, of the streaming class, estimated microseconds, estimated microseconds
+    unsplit) of this thread's last prefill launch — the launcher's plan (csrc/duo_prefill.hip), for tests and probes."""
+    out = (ctypes.c_double * 4)()
+    load_library().duo_debug_prefill_last_plan(out)
+    return int(out[0]), int(out[1]), float(out[2]), float(out[3])
+
+
+def prefill_plan(nkv0, nkv1, group, n_tokens, lenA0, lenB0, lenA1, lenB1, max_parts=2048, xmap=3, force=0, with_blocks=False):
+    """host-only: the launcher's plan for a prefill launch shape (``duo_debug_prefill_plan``): dict with k0, k1, blocks,
+    partials, blocks0, est_us, est_unsplit_us and — ``with_blocks`` — an int32 array [blocks, 6] of
+    (class, q tile | -1, kv head, q head of the group, piece, partial slot) per block id"""
+    import numpy as np
+
+    lib = load_library()
+    shape = (c_int32 * 10)(nkv0, nkv1, group, n_tokens, lenA0, lenB0, lenA1, lenB1, max_parts, xmap)
+    out, est = (c_int32 * 5)(), (ctypes.c_double * 2)()
+    n = lib.duo_debug_prefill_plan(shape, force, out, est, None, 0)
+    if n < 0:
+        raise DuoHipError(f"duo_debug_prefill_plan: {n}")
+    res = {"k0": out[0], "k1": out[1], "blocks": out[2], "partials": out[3], "blocks0": out[4], "est_us": est[0],
+           "est_unsplit_us": est[1]}
+    if with_blocks:
+        arr = np.zeros((max(n, 1), 6), dtype=np.int32)
+        lib.duo_debug_prefill_plan(shape, force, out, est, arr.ctypes.data_as(POINTER(c_int32)), n)
+        res["map"] = arr[:n]
+    return res

@@ -50,6 +50,10 @@
  * ABI version 5 (round 5, one addition, no signature changed): + duo_decode_plan_bucket; every decode entry point sizes its
  *   split-KV grid from that bucket of the visible rows (static_kv_cache.py:44-45 keeps the lengths as Python ints, so the
  *   reference has no captured step to keep consistent — here a captured launch equals the eager launch of its bucket).
+ * ABI version 6 (round 6, two additions, no signature changed): + duo_debug_prefill_last_plan, duo_debug_prefill_plan; the prefill entry points choose
+ *   key-range splits for BOTH head classes (up to 16 pieces) by replaying the launch on the chip's 256 CUs, and
+ *   duo_attn_prefill_workspace_bytes() doubled (2048 partials).  Results of a launch may be split — summed — differently than
+ *   by a v5 build; outputs stay inside the same bar.
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -66,7 +70,7 @@
 extern "C" {
 #endif
 
-#define DUO_ABI_VERSION 5
+#define DUO_ABI_VERSION 6
 
 /* argument errors (negative so they never collide with hipError_t) */
 #define DUO_EINVAL   (-1)  /* bad pointer / size / stride                     */
@@ -120,13 +124,26 @@ const char *duo_error_string(int code);
  * bit 5 / bit 6: INT4 / bf16 decode consume their loads without the arithmetic (output
  *        invalid: the memory-side ceiling of the launch);
  * bit 7: bf16 prefill stays on the 8-wave x 32-row kernel (the 4-wave x 64-row kernel is the default where it
- *        applies);  bit 8: no key-range split of the prefill launch;  bits 12-15: force that many key-range splits
- *        (capped by the workspace and the tile count);  bit 9: decode scan on the long-prologue kernel
+ *        applies);  bit 8: no key-range split of the prefill launch;  bits 12-15 / bits 16-19: force that many key-range
+ *        splits of the retrieval / the streaming class (capped by the workspace and the tile count);  bit 9: decode scan on the long-prologue kernel
  *        (duo_decode_split_kernel) instead of the short-prologue one;  bit 10: prefill in the plain q-tile-major block
  *        order instead of the XCD-aware one;  bit 11: INT4 decode on the dequantising kernel whatever `fused` asks for.
  *        Measurement / test aids only. */
 void duo_set_debug_flags(uint32_t flags);
 uint32_t duo_get_debug_flags(void);
+/* The plan of the calling thread's last prefill launch (tests, probes): out4 = {key-range pieces of the retrieval class, of
+ * the streaming class, the planner's estimate of the launch in microseconds, its estimate without any split} — the
+ * flash_attn_func call sites this replaces (llama.py:366-372, :392-421) have no such choice to report. */
+void duo_debug_prefill_last_plan(double *out4);
+/* Host-only (no GPU, no launch): the plan for a launch shape and the work of every block id of that launch.
+ * shape = {n_kv_heads of the retrieval class, of the streaming class, group, n_tokens, lenA / lenB of the retrieval class,
+ * lenA / lenB of the streaming class, partials the workspace holds, order (bit 0 / 1: XCD-aware order of class 0 / 1)};
+ * force: bits 0-7 / 8-15 forced piece counts, bit 16 no split; out5 = {pieces of class 0, of class 1, blocks, partials,
+ * blocks of class 0}; est2 (may be NULL) = estimated microseconds as planned / unsplit; blocks (may be NULL): six int32
+ * per block id {class, q tile or -1 for padding, kv head, q head of the group, piece, partial slot}.  Returns the number
+ * of blocks, or a negative DUO_E* code. */
+int32_t duo_debug_prefill_plan(const int32_t *shape10, uint32_t force, int32_t *out5, double *est2, int32_t *blocks,
+                               int32_t blocks_cap);
 
 /* ---- RoPE (NeoX / rotate-half, interleave=False) in place on q and k -------
  * q: [n_tokens, n_q_heads, 128], k: [n_tokens, n_kv_heads, 128];

@@ -440,6 +440,53 @@ def test_prefill_forced_key_range_splits(S, lenA, ksplit, eight_wave):
     attn_close(out, ref[0], f"forced {ksplit} splits S={S} lenA={lenA}", bud[0])
 
 
+@pytest.mark.parametrize("flags", [0, 128, 1024], ids=["w4x64", "w8x32", "plain-order"])
+@pytest.mark.parametrize("k0,k1", [(2, 2), (5, 3), (1, 4), (16, 1), (3, 2)])
+@pytest.mark.parametrize("S,group,nf,ns,lenA", [(700, 4, 3, 5, 3000), (520, 2, 1, 2, 1500), (300, 3, 2, 0, 2000)])
+def test_prefill_key_range_splits_of_both_head_classes(S, group, nf, ns, lenA, k0, k1, flags):
+    """Round 6: the launcher may cut BOTH classes over key ranges (debug bits 12-15 / 16-19 force the counts), up to 16 pieces,
+    in the XCD-aware block order (virtual heads = kv head x piece) or the plain one (bit 10), on either kernel: ragged head
+    counts, a streaming window next to a long pool, pieces that begin inside the window, on its partial last tile or inside
+    the chunk's own tiles — merged partials against the oracle."""
+    h = _hip()
+    h.set_debug_flags((k0 << 12) | (k1 << 16) | flags)
+    try:
+        out, ref, bud = _attention_case(S, group, nf, ns, lenA, 330, True, seed=S + 7 * k0 + k1)
+        torch.cuda.synchronize()
+        plan = h.last_prefill_plan()
+    finally:
+        h.set_debug_flags(0)
+    assert plan[0] == (k0 if nf else 1) and plan[1] == (k1 if ns else 1), plan
+    attn_close(out, ref, f"pieces ({k0}, {k1}) S={S} nf={nf} ns={ns} flags={flags}", bud)
+
+
+def test_prefill_row_block_launch_is_planned_and_matches():
+    """the layer pipeline's launch shape (queries = the LAST rows of segment B, duo_static_attention_row_block): the planner
+    splits both classes by itself (no forced count) and the result equals the oracle's attention over pool ++ chunk rows"""
+    from duo_attn.backend import HipBackend
+
+    h = _hip()
+    g = torch.Generator().manual_seed(11)
+    S, r1, group, nf, ns, lenA = 512, 1536, 4, 1, 1, 9000
+    q = _rand((S, (nf + ns) * group, D), g)
+    kb, vb = _rand((r1, nf + ns, D), g), _rand((r1, nf + ns, D), g)
+    ka, va = _rand((lenA, nf, D), g), _rand((lenA, nf, D), g)
+    sk, sv = _rand((300, ns, D), g), _rand((300, ns, D), g)
+    dev = [t.to(DEV) for t in (q, ka, va, kb, vb, sk, sv)]
+    qd, kad, vad, kbd, vbd, skd, svd = dev
+    out = torch.full(q.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    HipBackend().attention(qd, out, group, (nf, 0, (kad, vad), (kbd[:, :nf], vbd[:, :nf])),
+                           (ns, nf * group, (skd, svd), (kbd[:, nf:], vbd[:, nf:])), D ** -0.5)
+    torch.cuda.synchronize()
+    plan = h.last_prefill_plan()
+    assert plan[0] > 1 and plan[2] < plan[3], plan        # 8 long workgroups on 256 CUs: split, and estimated cheaper
+    kw = dict(round_p=False, out_dtype=torch.float32, return_budget=True)
+    for lo, hi, kk, vv in ((0, nf * group, torch.cat([ka, kb[:, :nf]]), torch.cat([va, vb[:, :nf]])),
+                           (nf * group, (nf + ns) * group, torch.cat([sk, kb[:, nf:]]), torch.cat([sv, vb[:, nf:]]))):
+        ref, bud = flash_attn_func_ref(q[None, :, lo:hi], kk[None], vv[None], **kw)
+        attn_close(out[:, lo:hi], ref[0], f"row block, heads {lo}:{hi}", bud[0])
+
+
 def test_prefill_without_transpose_read_matches():
     """8-wave kernel: ds_read_b64_tr_b16 path == scalar LDS gather path (debug flag bit 0), bit for bit."""
     h = _hip()
