@@ -28,11 +28,16 @@
 namespace {
 
 // Combine the ks[c] partials of one (q tile, q head): out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
-// Block = one split item, class 0's first, in the canonical item order of prefill_map_block (q-tile rank, kv head, q head
-// of the group); thread = 32 rows x 8 column groups of 16 dims per pass, 8 passes.
+// Block = (split item, 32-row slice of its 256 rows): items of class 0 first, in the canonical item order of
+// prefill_map_block (q-tile rank, kv head, q head of the group); thread = one row x one group of 16 dims.
+// (Rounds 1-5 ran one block per item that walked its 8 row slices and its pieces one after the other — sixteen to eighty
+// DEPENDENT memory round trips per block on a grid of a few dozen blocks: 50-70 us per launch whatever the byte count,
+// profiles/r6_prefill_plan.md.  Here the grid is 8x larger, every (m, l) pair of the row is requested up front and the
+// accumulator rows follow four pieces at a time.)
 template <bool F16>
 __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillParams P, int n_merge0) {
-    int j = blockIdx.x;
+    int j = blockIdx.x >> 3;
+    const int pass = blockIdx.x & 7;
     const int ci = j < n_merge0 ? 0 : 1;
     if (ci) j -= n_merge0;
     const DuoClassDev &C = ci ? P.cls[1] : P.cls[0];
@@ -46,36 +51,58 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
     const int qh = C.q_head_offset + kvh * P.group + g;
     const int64_t part0 = (int64_t)(ci ? P.pbase[1] : P.pbase[0]) + (int64_t)j * ks + (int64_t)blockIdx.y * P.nparts;
     const int jd = threadIdx.x & 7;
-    for (int pass = 0; pass < 8; ++pass) {
-        const int r = pass * 32 + (threadIdx.x >> 3);
-        const int q = tile * QBLK + r;
-        if (q >= P.S) continue;
-        const int64_t row0 = part0 * QBLK + r;     // piece s: + s * QBLK
-        float M = -INFINITY;
-        for (int s = 0; s < ks; ++s) M = fmaxf(M, P.ws_ml[(row0 + (int64_t)s * QBLK) * 2]);
-        float L = 0.f;
-        f32x4 acc[4];
+    const int r = pass * 32 + (threadIdx.x >> 3);
+    const int q = tile * QBLK + r;
+    if (q >= P.S) return;
+    const int64_t row0 = part0 * QBLK + r;     // piece s: + s * QBLK
+    // every piece's (m, l) of this row: independent 8-byte loads, then the weights
+    constexpr int KMAX = 16;
+    f32x2 ml[KMAX];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < ks; ++s) {
-            const int64_t row = row0 + (int64_t)s * QBLK;
-            const float m = P.ws_ml[row * 2], l = P.ws_ml[row * 2 + 1];
-            if (m == -INFINITY) continue;      // this piece saw no key of the row: nothing to add
-            const float w = fast_exp2((m - M) * P.scale_log2e);
-            L = fmaf(l, w, L);
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(P.ws_o + row * DUO_HEAD_DIM + 16 * jd);
+    for (int s = 0; s < KMAX; ++s)
+        ml[s] = s < ks ? *reinterpret_cast<const f32x2 *>(P.ws_ml + (row0 + (int64_t)s * QBLK) * 2) : f32x2{-INFINITY, 0.f};
+    float M = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + src[i] * w;
+    for (int s = 0; s < KMAX; ++s) M = fmaxf(M, ml[s].x);
+    float L = 0.f;
+    float w[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        // a piece that saw no key of the row (m = -inf, l = 0) has weight 0; a row no piece saw cannot exist (key 0 of the
+        // chunk's own rows is visible to every query)
+        w[s] = ml[s].x == -INFINITY ? 0.f : fast_exp2((ml[s].x - M) * P.scale_log2e);
+        L = fmaf(ml[s].y, w[s], L);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *src0 = P.ws_o + row0 * DUO_HEAD_DIM + 16 * jd;
+#pragma unroll
+    for (int s0 = 0; s0 < KMAX; s0 += 4) {
+        if (s0 >= ks) break;
+        f32x4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u < ks ? s0 + u : s0;       // past the end: re-read a valid piece with weight 0
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(src0 + (int64_t)s * QBLK * DUO_HEAD_DIM);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[u][i] = __builtin_nontemporal_load(src + i);
         }
-        const float inv = 1.f / L;
-        bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * jd;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x2 w2;
-            w2.x = cvt_pk16<F16>(acc[i].x * inv, acc[i].y * inv);
-            w2.y = cvt_pk16<F16>(acc[i].z * inv, acc[i].w * inv);
-            *reinterpret_cast<u32x2 *>(op + 4 * i) = w2;
+        for (int u = 0; u < 4; ++u) {
+            const float wu = s0 + u < ks ? w[s0 + u] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + v[u][i] * wu;
         }
+    }
+    const float inv = 1.f / L;
+    bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * jd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x2 w2;
+        w2.x = cvt_pk16<F16>(acc[i].x * inv, acc[i].y * inv);
+        w2.y = cvt_pk16<F16>(acc[i].z * inv, acc[i].w * inv);
+        *reinterpret_cast<u32x2 *>(op + 4 * i) = w2;
     }
 }
 
@@ -112,12 +139,17 @@ constexpr int kPrefillCUs = 256;
 namespace {
 struct PlanCost {
     double t_tile, t_fix, t_merge, t_part, t_pad;     // microseconds
+    double c0;      // cost of a unit of work with (nearly) all CUs idle, relative to the full chip (tail of a launch)
 };
 static const PlanCost &plan_cost() {
     // defaults: fitted to same-box probes of this kernel (profiles/r6_prefill_plan.md); DUO_PREFILL_PLAN_COST overrides
     static const PlanCost c = [] {
-        PlanCost v{1.73, 6.0, 6.0, 0.05, 1.0};
-        if (const char *e = getenv("DUO_PREFILL_PLAN_COST")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad);
+        // t_fix is what a workgroup costs beyond its bulk tiles: prologue (Q fragments, two tiles in flight), the handful of
+        // tiles in the general (masked / run-boundary) form, epilogue; c0: fewer active CUs clock higher and share the fabric
+        // with fewer others — a lone 1800-tile workgroup walks a tile in 1.2 us, 256 of them in 1.6
+        PlanCost v{1.59, 22.0, 20.0, 0.05, 1.0, 0.63};
+        if (const char *e = getenv("DUO_PREFILL_PLAN_COST"))
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad, &v.c0);
         return v;
     }();
     return c;
@@ -189,7 +221,7 @@ static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool x
     // min-heap of the CUs' free times
     double heap[kPrefillCUs];
     for (int i = 0; i < kPrefillCUs; ++i) heap[i] = 0.0;
-    double end = 0.0;
+    double last_start = 0.0;
     for (int b = 0; b < nblk; ++b) {
         const PrefillItem I = prefill_map_block(P, b);
         double cost = C.t_pad;
@@ -199,8 +231,8 @@ static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool x
             cost = C.t_fix + C.t_tile * n;
         }
         // replace the root (earliest free CU) and sift down
+        last_start = heap[0];
         const double t = heap[0] + cost;
-        end = std::max(end, t);
         int i = 0;
         for (;;) {
             int l = 2 * i + 1, r = l + 1, m = i;
@@ -212,6 +244,16 @@ static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool x
             i = m;
         }
         heap[i] = t;
+    }
+    // While blocks are waiting every CU is busy and a unit of work costs 1; behind the start of the last block the busy
+    // CUs drain one by one, and with `a` of 256 busy a unit costs c0 + (1 - c0) a / 256.
+    std::sort(heap, heap + kPrefillCUs);
+    double end = last_start, prev = last_start;
+    int first = 0;
+    while (first < kPrefillCUs && heap[first] <= last_start) ++first;      // CUs already idle when the last block started
+    for (int i = first, a = kPrefillCUs - first; i < kPrefillCUs; ++i, --a) {
+        end += (heap[i] - prev) * (C.c0 + (1.0 - C.c0) * a / kPrefillCUs);
+        prev = heap[i];
     }
     if (P.nparts > 0) end += C.t_merge + C.t_part * P.nparts;
     return end;
@@ -448,7 +490,7 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
         DUO_HIP_CHECK_LAUNCH();
         if (n_merge0 + n_merge1 > 0) {
-            hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(n_merge0 + n_merge1, n_batch), dim3(256), 0, st, P, n_merge0);
+            hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(8 * (n_merge0 + n_merge1), n_batch), dim3(256), 0, st, P, n_merge0);
             DUO_HIP_CHECK_LAUNCH();
         }
         return 0;
@@ -459,7 +501,7 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     }
     DUO_HIP_CHECK_LAUNCH();
     if (n_merge0 + n_merge1 > 0) {
-        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(n_merge0 + n_merge1, n_batch), dim3(256), 0, st, P, n_merge0);
+        hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(8 * (n_merge0 + n_merge1), n_batch), dim3(256), 0, st, P, n_merge0);
         DUO_HIP_CHECK_LAUNCH();
     }
     return 0;

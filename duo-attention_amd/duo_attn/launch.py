@@ -59,3 +59,107 @@ def self_launch(script: str, argv: Sequence[str], nproc: int, visible: Optional[
     cmd = torchrun_command(script, argv, nproc)
     print(f"[duo_attn.launch] no rank environment: starting {nproc} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# to_device(model, [gpu ids], enable_tp / enable_pp) from ONE python process, as the reference's harnesses call it
+# ----------------------------------------------------------------------------------------------------------------------
+SELF_LAUNCHED_ENV = "DUO_ATTN_SELF_LAUNCHED"      # set for ranks started by relaunch_under_torchrun()
+
+
+def original_command(orig_argv: Optional[Sequence[str]] = None) -> List[str]:
+    """What follows the interpreter (and its own options) on the command line this process was started with, in the form
+    ``torch.distributed.run`` takes: ``[script, args...]`` or ``["-m", module, args...]``.  ``python -c`` / an interactive
+    session cannot be started again: ValueError."""
+    a = list(sys.orig_argv if orig_argv is None else orig_argv)[1:]
+    i = 0
+    while i < len(a):
+        t = a[i]
+        if t == "-m":
+            if i + 1 >= len(a):
+                break
+            return ["-m", *a[i + 1:]]
+        if t == "-c" or t == "-":
+            break
+        if t in ("-X", "-W"):           # interpreter options with a value
+            i += 2
+            continue
+        if t.startswith("-"):
+            i += 1
+            continue
+        return [os.path.abspath(t), *a[i + 1:]]
+    raise ValueError("this process was not started from a script or a module (python -c / interactive): it cannot be started "
+                     "again as one rank per GPU — launch it with torch.distributed.run")
+
+
+def relaunch_under_torchrun(nproc: int, visible: Optional[int] = None) -> int:
+    """Start the command line of THIS process again as ``nproc`` ranks under torch.distributed.run (rendezvous on 127.0.0.1)
+    and return the launcher's exit code.  The ranks see ``DUO_ATTN_SELF_LAUNCHED=1``."""
+    check_visible_gpus(nproc, visible)
+    target = original_command()
+    env = dict(os.environ)
+    env[SELF_LAUNCHED_ENV] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), *target]
+    print(f"[duo_attn.launch] to_device() got {nproc} devices in a single process: one rank per GPU — starting this command "
+          f"again as {nproc} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def quiet_this_rank() -> None:
+    """Ranks other than 0 of a self-launched harness compute the same tokens as rank 0 (tensor parallelism: identical logits
+    after the all-reduce; layer pipeline: the decode logits are broadcast) and would write the same result files and print
+    the same lines: their stdout goes to os.devnull and every file they open FOR WRITING is os.devnull, so rank 0 alone
+    writes results — without an edit to the harness."""
+    import builtins
+
+    sys.stdout = open(os.devnull, "w")
+    real_open = builtins.open
+
+    def rank_open(file, mode="r", *a, **kw):
+        if isinstance(mode, str) and any(c in mode for c in "wax+") and not isinstance(file, int):
+            return real_open(os.devnull, mode.replace("x", "w"), *a, **kw)
+        return real_open(file, mode, *a, **kw)
+
+    builtins.open = rank_open
+
+
+def ensure_ranks(n_devices: int, what: str) -> None:
+    """Called by ``duo_attn.utils.to_device`` with a device list longer than one and no process group.
+
+    * started by torch.distributed.run (rank environment present): initialise the group — RCCL ("nccl") with one GPU per rank,
+      gloo in the shared-GPU rehearsal mode (``DUO_BENCH_DEBUG_SHARED_GPU=1``) or without a GPU;
+    * a plain ``python harness.py`` — how the reference's scripts/niah.sh and scripts/longbench.sh start their harnesses, which
+      then hand every visible GPU to ``to_device(..., enable_tp=True)`` inside that one process (eval/needle/
+      needle_in_haystack.py:213-214, eval/LongBench/pred.py:237-243): the command line is started again as one rank per
+      GPU and THIS process exits with the ranks' exit code — everything the harness did before the call (argument parsing,
+      loading the checkpoint) is repeated by every rank, everything after it is done by the ranks only."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return
+    if not launched_by_torchrun():
+        if os.environ.get(SELF_LAUNCHED_ENV) == "1":
+            raise RuntimeError("a self-launched rank without a rank environment")
+        try:
+            rc = relaunch_under_torchrun(n_devices)
+        except ValueError as e:
+            raise RuntimeError(f"{what} = one process per GPU: {e}") from e
+        sys.exit(rc)
+    world = int(os.environ["WORLD_SIZE"])
+    if world != n_devices:
+        raise ValueError(f"{n_devices} devices for {world} ranks")
+    shared = os.environ.get(SHARED_GPU_ENV) == "1" or not torch.cuda.is_available()
+    if shared:
+        dist.init_process_group("gloo")
+    else:
+        local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if os.environ.get(SELF_LAUNCHED_ENV) == "1" and dist.get_rank() != 0:
+        quiet_this_rank()

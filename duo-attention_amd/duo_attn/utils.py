@@ -166,16 +166,17 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
             # heads evenly over the ranks when the model does not carry the pattern itself.
             import torch.distributed as dist
 
-            if not dist.is_initialized():
-                raise RuntimeError(
-                    "Tensor parallelism = one process per GPU: launch with torch.distributed.run "
-                    "(--nproc-per-node = number of devices); each rank then calls to_device(model, devices, enable_tp=True)."
-                )
+            from .launch import SHARED_GPU_ENV, ensure_ranks
+
+            # no process group yet: a rank of torch.distributed.run initialises it here; a plain `python harness.py` (the
+            # reference's own launch shape, scripts/niah.sh:17) is started again as one rank per device and never returns
+            ensure_ranks(len(device), "Tensor parallelism")
             if dist.get_world_size() != len(device):
                 raise ValueError(f"{len(device)} devices for {dist.get_world_size()} ranks")
             from .tp import shard_model_for_tp
 
-            dev = device[dist.get_rank()]
+            # (shared-GPU rehearsal: every rank on the first device, gloo between them — not a measurement mode)
+            dev = device[0 if os.environ.get(SHARED_GPU_ENV) == "1" else dist.get_rank()]
             dev = dev if isinstance(dev, str) else f"cuda:{dev}"
             if dev.startswith("cuda"):
                 torch.cuda.set_device(dev)       # launches go to the CURRENT device's stream (duo_attn/_hip.py)
@@ -201,17 +202,17 @@ def to_device(model, device, enable_tp=False, enable_pp=False, reverse_device_ma
         if enable_pp:
             import torch.distributed as dist
 
-            if not dist.is_initialized():
-                raise RuntimeError(
-                    "Layer pipeline = one process per GPU: launch with torch.distributed.run "
-                    "(--nproc-per-node = number of devices); each rank then calls to_device(model, devices, enable_pp=True)."
-                )
+            from .launch import SHARED_GPU_ENV, ensure_ranks
+
+            ensure_ranks(len(device), "Layer pipeline")
             if dist.get_world_size() != len(device):
                 raise ValueError(f"{len(device)} devices for {dist.get_world_size()} ranks")
             from .pipeline import shard_model_for_pp
 
-            dev = device[dist.get_rank()]
-            shard_model_for_pp(model, dev if isinstance(dev, str) else f"cuda:{dev}", handoff=pp_handoff)
+            shared = os.environ.get(SHARED_GPU_ENV) == "1"
+            dev = device[0 if shared else dist.get_rank()]
+            shard_model_for_pp(model, dev if isinstance(dev, str) else f"cuda:{dev}",
+                               handoff="cpu" if shared and pp_handoff is None else pp_handoff)
             return model
         raise ValueError("a device list needs enable_pp (or enable_tp)")
     return model.to(device)

@@ -47,7 +47,7 @@ def build_inputs(work):
     return mdir, pdir
 
 
-def cuda_shim():
+def cuda_shim(ndev=1):
     """the harness's hard-coded device string and torch.cuda timing calls, on a machine without a GPU"""
     import torch
 
@@ -78,7 +78,8 @@ def cuda_shim():
     torch.cuda.synchronize = lambda *a, **k: None
     torch.cuda.reset_peak_memory_stats = lambda *a, **k: None
     torch.cuda.max_memory_allocated = lambda *a, **k: 0
-    torch.cuda.device_count = lambda: 1         # (the needle harness hands every visible GPU to to_device(..., enable_tp=True))
+    torch.cuda.device_count = lambda: ndev      # (the needle harness hands every visible GPU to to_device(..., enable_tp=True))
+    torch.cuda.set_device = lambda *a, **k: None
 
 
 def readme_quick_start(work):
@@ -136,9 +137,14 @@ def needle_in_a_haystack(work):
     ten-line module written into the temp directory (the score of a random model is meaningless either way)."""
     import numpy as np
 
-    mdir, pdir = _char_model(work, "tiny-llama"), os.path.join(work, "pattern")
+    # (a run with two "GPUs" is started again by to_device() as two ranks of torch.distributed.run, which execute this very
+    #  function: the inputs exist by then — the first process wrote them before it reached to_device — and are not rewritten)
+    ranks_of_a_relaunch = os.environ.get("DUO_ATTN_SELF_LAUNCHED") == "1"
+    mdir, pdir = os.path.join(work, "tiny-llama") if ranks_of_a_relaunch else _char_model(work, "tiny-llama"), os.path.join(work, "pattern")
     for d in (pdir, os.path.join(work, "PaulGrahamEssays"), os.path.join(work, "rouge_score")):
         os.makedirs(d, exist_ok=True)
+    if ranks_of_a_relaunch:
+        return _needle_run(work, mdir, pdir)
     np.savetxt(os.path.join(pdir, "full_attention_heads.tsv"), np.array([[0.9, 0.1], [0.2, 0.7], [0.95, 0.6]]), delimiter="\t")
     with open(os.path.join(pdir, "config.json"), "w") as f:
         json.dump({"sink_size": 64, "recent_size": 256}, f)
@@ -151,6 +157,10 @@ def needle_in_a_haystack(work):
                 "class RougeScorer:\n    def __init__(self, kinds, use_stemmer=False):\n        self.kinds = kinds\n"
                 "    def score(self, target, prediction):\n        a, b = set(target.split()), set(prediction.split())\n"
                 "        f = 2 * len(a & b) / max(1, len(a) + len(b))\n        return {k: Score(f, f, f) for k in self.kinds}\n")
+    return _needle_run(work, mdir, pdir)
+
+
+def _needle_run(work, mdir, pdir):
     sys.path.insert(0, work)
     os.chdir(work)
     sys.argv = ["needle_in_haystack.py", "-s", "300", "-e", "700", "--model_path", mdir, "--attn_load_dir", pdir, "--sink_size", "8",
@@ -238,17 +248,20 @@ def main():
     # the reference's root is NOT on the path, so `import duo_attn` cannot reach the reference's package
     for p in (os.path.join(REF, "eval", "efficiency"), ROOT, os.path.join(ROOT, "duo-attention_amd")):
         sys.path.insert(0, p)
-    mdir, pdir = build_inputs(work)
+    relaunched = os.environ.get("DUO_ATTN_SELF_LAUNCHED") == "1"
+    mdir, pdir = (os.path.join(work, "model"), os.path.join(work, "pattern")) if relaunched else build_inputs(work)
     import duo_attn
     from duo_attn import backend
     from oracle.duo_oracle import OracleBackend
 
     assert os.path.realpath(duo_attn.__file__).startswith(os.path.realpath(ROOT)), duo_attn.__file__
     backend._set_backend_for_testing(OracleBackend())
-    cuda_shim()
+    cuda_shim(2 if script == "needle-tp2" else 1)
     if script == "README":
         return readme_quick_start(work)
-    if script == "needle":
+    if script in ("needle", "needle-tp2"):
+        # "needle-tp2": the harness sees TWO devices and calls to_device(model, [0, 1], enable_tp=True) inside this one
+        # process, as scripts/niah.sh starts it (python eval/needle/needle_in_haystack.py ...)
         return needle_in_a_haystack(work)
     if script.startswith("longbench:"):
         return longbench_pred(work, script.split(":", 1)[1])

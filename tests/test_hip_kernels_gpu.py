@@ -441,7 +441,7 @@ def test_prefill_forced_key_range_splits(S, lenA, ksplit, eight_wave):
 
 
 @pytest.mark.parametrize("flags", [0, 128, 1024], ids=["w4x64", "w8x32", "plain-order"])
-@pytest.mark.parametrize("k0,k1", [(2, 2), (5, 3), (1, 4), (16, 1), (3, 2)])
+@pytest.mark.parametrize("k0,k1", [(2, 2), (5, 3), (1, 4), (15, 1), (3, 2)])
 @pytest.mark.parametrize("S,group,nf,ns,lenA", [(700, 4, 3, 5, 3000), (520, 2, 1, 2, 1500), (300, 3, 2, 0, 2000)])
 def test_prefill_key_range_splits_of_both_head_classes(S, group, nf, ns, lenA, k0, k1, flags):
     """Round 6: the launcher may cut BOTH classes over key ranges (debug bits 12-15 / 16-19 force the counts), up to 16 pieces,

@@ -91,3 +91,19 @@ def test_reference_longbench_pred_runs_unchanged(method, file, tmp_path):
     assert res == {"file": file, "records": "3", "fields ok": "True"}
     assert out.count("Prediction:") == 3
     assert ("Enabling DuoAttention evaluation using sink size 8 and recent size 24" in out) == (method == "duo_attn")
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="the reference is only present in the build container")
+def test_reference_needle_harness_with_two_devices_starts_its_own_ranks(tmp_path):
+    """The reference starts its accuracy harnesses as ONE python process (scripts/niah.sh:17, scripts/longbench.sh) that hands
+    every visible GPU to ``to_device(model, device_list, enable_tp=True)`` (eval/needle/needle_in_haystack.py:213-214).  Here that
+    call — a device list longer than one, no process group, no rank environment — starts the SAME command line again as one
+    rank per device under torch.distributed.run (duo_attn/launch.py: ensure_ranks), the ranks initialise their group inside
+    to_device (gloo here: no GPU) and shard the already-patched model head-parallel, and rank 0 alone prints and writes: the
+    four result files of two context lengths x two depths are read back, identical in form to the one-device run's."""
+    res, out = _run("needle-tp2", tmp_path)
+    assert res == {"results": "4", "lengths": "[450, 600]", "depths": "[0.0, 100.0]", "fields ok": "True"}, res
+    assert out.count("RESULT ") == 1                     # rank 1 is silent
+    import glob
+    files = sorted(glob.glob(os.path.join(str(tmp_path), "results", "tiny-llama", "*_results.json")))
+    assert len(files) == 4 and all(json.load(open(f))["model_response"] is not None for f in files)
