@@ -623,6 +623,18 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
     const f16x8_t ones = as_f16x8(ones_w);
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[4 * 8192];
+    // four-wave form: the Q^T fragments (16 registers) live in LDS and are re-read per tile — they are only needed while
+    // S is formed, and 128 registers do not hold them through the V half of the tile body as well
+    // (one copy per workgroup: the four waves hold the same fragments — same kv head, same q heads, same lane layout)
+    __shared__ __attribute__((aligned(16))) uint8_t lds_q[MINW == 4 ? 4096 : 16];
+    const uint32_t qaddr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)lds_q + lane * 16;
+    if constexpr (MINW == 4) {
+        if (wave == 0) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) *(lds_u32x4 *)(uintptr_t)(qaddr + kb * 1024) = *reinterpret_cast<const u32x4 *>(&qB[kb]);
+        }
+        __syncthreads();
+    }
     // V^ tile of this wave: [32 keys][16 chunks of 16 B], chunk c of key k stored at slot c ^ (k & 15)
     const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t *)lds + wave * 8192;
     uint32_t wa[4];
@@ -658,6 +670,22 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
         return (gbyte_t *)(((uint64_t)hi << 32) | lo);
     };
+    auto load_k_at = [&](int t, I4Tile &T, uint32_t &q0, uint32_t &q1, uint32_t &s0, uint32_t &s1) __attribute__((always_inline)) {
+        gbyte_t *kq_t = ubase(kq + (int64_t)t * ts * 64), *ks_t = ubase(ksz + (int64_t)t * ts * 4);
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(s0), "+v"(s1));
+        T.kw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + q0));
+        T.kw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(kq_t + q1));
+        T.ks[0] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(ks_t + s0));
+        T.ks[1] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(ks_t + s1));
+    };
+    auto load_v_at = [&](int t, I4Tile &T, uint32_t &q0, uint32_t &q1, uint32_t &s0, uint32_t &s1) __attribute__((always_inline)) {
+        gbyte_t *vq_t = ubase(vq + (int64_t)t * ts * 64), *vs_t = ubase(vsz + (int64_t)t * ts * 4);
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(s0), "+v"(s1));
+        T.vw[0] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + q0));
+        T.vw[1] = __builtin_nontemporal_load(reinterpret_cast<gu32x4_t *>(vq_t + q1));
+        T.vs[0] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(vs_t + s0));
+        T.vs[1] = __builtin_nontemporal_load(reinterpret_cast<gu32_t *>(vs_t + s1));
+    };
     auto load_at = [&](int t, I4Tile &T, uint32_t &q0, uint32_t &q1, uint32_t &s0, uint32_t &s1) __attribute__((always_inline)) {
         gbyte_t *kq_t = ubase(kq + (int64_t)t * ts * 64), *vq_t = ubase(vq + (int64_t)t * ts * 64);
         gbyte_t *ks_t = ubase(ksz + (int64_t)t * ts * 4), *vs_t = ubase(vsz + (int64_t)t * ts * 4);
@@ -680,18 +708,40 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
         uint32_t s0 = (uint32_t)r0 * sz_b, s1 = (uint32_t)r1 * sz_b;
         load_at(t, T, q0, q1, s0, s1);
     };
+    // SPLIT form (four waves per SIMD): the K half and the V half of a tile are fetched separately into ONE tile buffer —
+    // tile t + 32 if it lies in the range (rows past the range re-read its last row), else the range's last tile again
+    // (never consumed), so the number of loads in flight is the same on every path
+    auto load_half = [&](int tn, I4Tile &T, auto k_tag) __attribute__((always_inline)) {
+        constexpr bool KH = decltype(k_tag)::value;
+        const int t = tn < w1 ? tn : w0 + (((w1 - 1 - w0) >> 5) << 5);
+        if (t + 32 <= w1) {
+            if constexpr (KH) load_k_at(t, T, qo0, qo1, so0, so1);
+            else load_v_at(t, T, qo0, qo1, so0, so1);
+        } else {
+            const int last = w1 - 1 - t;
+            const int r0 = min(r, last), r1 = min(16 + r, last);
+            uint32_t q0 = (uint32_t)r0 * row_b + g * 16, q1 = (uint32_t)r1 * row_b + g * 16;
+            uint32_t s0 = (uint32_t)r0 * sz_b, s1 = (uint32_t)r1 * sz_b;
+            if constexpr (KH) load_k_at(t, T, q0, q1, s0, s1);
+            else load_v_at(t, T, q0, q1, s0, s1);
+        }
+    };
 
-    // Tile body.  FAST: the exact-fma dequantisation (all row scales of the tile in range — the caller has
-    // voted); otherwise subtract-multiply-add.  TAIL: partial tile, keys past the range masked.
-    auto process = [&](const I4Tile &T, int t, auto fast_tag, auto tail_tag) __attribute__((always_inline)) {
+    // K half of the tile body: S^T = K^ . Q^T.  FAST: the exact-fma dequantisation (every K row scale of the tile in range —
+    // the caller has voted); otherwise subtract-multiply-add.
+    auto process_k = [&](const I4Tile &T, f32x4 (&S)[2], auto fast_tag) __attribute__((always_inline)) {
         constexpr bool FAST = decltype(fast_tag)::value;
-        constexpr bool TAIL = decltype(tail_tag)::value;
-        if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic
-            m_ref += __uint_as_float((T.kw[0].x ^ T.kw[1].y ^ T.vw[0].z ^ T.vw[1].w ^ T.ks[0] ^ T.ks[1] ^ T.vs[0] ^ T.vs[1]) & 1u);
-            return;
+        f16x8_t qk[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if constexpr (MINW == 4) {      // (volatile: re-read per tile, never hoisted back into registers)
+                const u32x4 w = *(volatile lds_u32x4 *)(uintptr_t)(qaddr + kb * 1024);
+                qk[kb] = as_f16x8(w);
+            } else {
+                qk[kb] = qB[kb];
+            }
         }
         // ---- S^T = K^ . Q^T ------------------------------------------------------------------
-        f32x4 S[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             S[h] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -701,13 +751,17 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             for (int kb = 0; kb < 4; ++kb) {
 #if DUO_I4_PROBE & 2     // ablation build (tools/debug/int4_ablation.sh): K words to the MFMA without dequantisation
                 const u32x4 raw = {kw[kb] & 0x3bff3bffu, (kw[kb] >> 1) & 0x3bff3bffu, R.s[0] != R.z[1] ? kw[kb] & 0x33ff33ffu : 0u, 0u};
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(raw), qB[kb], S[h], 0, 0, 0);
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(raw), qk[kb], S[h], 0, 0, 0);
 #else
-                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST, FUSED>(kw[kb], R, m0, m4, magic)), qB[kb],
+                S[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(dq8<FAST, FUSED>(kw[kb], R, m0, m4, magic)), qk[kb],
                                                               S[h], 0, 0, 0);
 #endif
             }
         }
+    };
+    // V half: V^ -> LDS, softmax of S against the reference maximum, O += P . V^.  TAIL: partial tile, keys past the range masked.
+    auto v_to_lds = [&](const I4Tile &T, auto fast_tag) __attribute__((always_inline)) {
+        constexpr bool FAST = decltype(fast_tag)::value;
         // ---- V^ -> LDS (issued early: the writes drain while the softmax runs) -----------------
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -724,14 +778,21 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
 #endif
             }
         }
-
+    };
+    // tail: std::true_type / std::false_type (a compile-time choice), or a bool decided per tile (four-wave form: ONE copy of
+    // this body in the loop — with one copy per case the accumulators are shuffled between registers where the cases meet)
+    auto softmax_pv = [&](const I4Tile &T, int t, const f32x4 (&S)[2], auto tail) __attribute__((always_inline)) {
+        (void)T;
+        bool is_tail;
+        if constexpr (std::is_same<decltype(tail), bool>::value) is_tail = tail;
+        else is_tail = decltype(tail)::value;
         // ---- softmax against the reference maximum ---------------------------------------------
         float sv[8];
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) sv[4 * h + e] = S[h][e];
-        if constexpr (TAIL) {   // keys past the range score -inf
+        if (is_tail) {   // keys past the range score -inf
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -790,7 +851,9 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
 #endif
 #define DUO_I4_TR_BATCH(buf, nb0)                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
-        const uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                     \
+        uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                           \
+        if constexpr (MINW == 4) /* recomputed at every use: eight hoisted copies would be eight registers too many */ \
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_) : "v"(ra), "v"((uint32_t)(((nb0) + i_) << 5)));           \
         DUO_I4_TR_READ(buf[2 * i_], a_, 0);                                         \
         DUO_I4_TR_READ(buf[2 * i_ + 1], a_, 4096);                                  \
     }
@@ -818,6 +881,61 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
 #undef DUO_I4_PV
 #undef DUO_I4_WAIT
     };
+    // Whole tile (two- and three-wave forms: both halves of a tile arrive together and share one vote).
+    auto process = [&](const I4Tile &T, int t, auto fast_tag, auto tail_tag) __attribute__((always_inline)) {
+        if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic
+            m_ref += __uint_as_float((T.kw[0].x ^ T.kw[1].y ^ T.vw[0].z ^ T.vw[1].w ^ T.ks[0] ^ T.ks[1] ^ T.vs[0] ^ T.vs[1]) & 1u);
+            return;
+        }
+        f32x4 S[2];
+        process_k(T, S, fast_tag);
+        v_to_lds(T, fast_tag);
+        softmax_pv(T, t, S, tail_tag);
+    };
+    // FOUR waves per SIMD (MINW == 4: 128 registers per wave): ONE tile buffer, refilled half by half — the K half of tile
+    // t + 32 is requested as soon as S(t) has consumed K(t), the V half as soon as P.V(t) has consumed V(t) — so four loads
+    // are in flight at every use and every wait is vmcnt(4).  A wave has half a tile of fetch lead instead of a whole one;
+    // the fourth wave of the SIMD covers the difference (round 6: the three-wave form keeps two tile buffers = 144 VGPRs;
+    // the 16 registers above 128 were exactly one half-tile).  The scale vote is taken per half (K scales before S, V
+    // scales before the LDS write), so a tile whose rows fail it takes the exact form for that half only — no reload.
+    if constexpr (MINW == 4) {
+        if (w0 < w1) {
+            using T_ = std::true_type;
+            using F_ = std::false_type;
+            I4Tile X;
+            load_half(w0, X, T_{});
+            load_half(w0, X, F_{});
+            if (P.flags & 32u) {   // debug: consume the loads, skip the arithmetic (a loop of its own: a second path through
+                                   // the main loop would make the tile registers meet through copies, i.e. through vmcnt(0))
+                for (int t = w0; t < w1; t += 32) {
+                    m_ref += __uint_as_float((X.kw[0].x ^ X.kw[1].y ^ X.ks[0] ^ X.ks[1]) & 1u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(t + 32, X, T_{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    m_ref += __uint_as_float((X.vw[0].z ^ X.vw[1].w ^ X.vs[0] ^ X.vs[1]) & 1u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(t + 32, X, F_{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int t = w0; t < w1; t += 32) {
+                    const bool tail = t + 32 > w1;
+                    f32x4 S[2];
+                    if (MODE == 1 && __all(scales_in_fma_range(X.ks[0], X.ks[1], X.ks[0], X.ks[1]))) process_k(X, S, T_{});
+                    else process_k(X, S, F_{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(t + 32, X, T_{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (MODE == 1 && __all(scales_in_fma_range(X.vs[0], X.vs[1], X.vs[0], X.vs[1]))) v_to_lds(X, T_{});
+                    else v_to_lds(X, F_{});
+                    softmax_pv(X, t, S, tail);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_half(t + 32, X, F_{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    } else {
     // Main loop over the full tiles: straight-line code with a fixed number of loads in flight (the next
     // tile's 8 loads are issued, unconditionally, before the current tile is touched; after the last full
     // tile the prefetch re-reads it) so every wait is vmcnt(8), never vmcnt(0).  It runs the FAST body and
@@ -860,6 +978,7 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_mfma_kernel(const I
             }
             t += 32;
         }
+    }
     }
 
     // ---- combine the 4 waves through LDS ------------------------------------------------------
@@ -1241,7 +1360,9 @@ __global__ __launch_bounds__(256, MINW) void duo_int4_decode_fold_kernel(const I
         __builtin_amdgcn_sched_barrier(0);
 #define DUO_I4_TR_BATCH(buf, nb0)                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                              \
-        const uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                     \
+        uint32_t a_ = ra ^ (uint32_t)(((nb0) + i_) << 5);                           \
+        if constexpr (MINW == 4) /* recomputed at every use: eight hoisted copies would be eight registers too many */ \
+            asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_) : "v"(ra), "v"((uint32_t)(((nb0) + i_) << 5)));           \
         DUO_I4_TR_READ(buf[2 * i_], a_, 0);                                         \
         DUO_I4_TR_READ(buf[2 * i_ + 1], a_, 4096);                                  \
     }

@@ -570,6 +570,11 @@ extern "C" int duo_attn_prefill_ws_f16(const void *q, int64_t q_token_stride, in
                               group, full, stream_cls, scale, head_dim, workspace, workspace_bytes, stream);
 }
 
+#ifdef W64_WGTIME      /* measurement builds only (tools/debug/w64_wgtime.py): the life of every workgroup of the last bf16 launch */
+extern "C" int duo_debug_w64_wgtime(unsigned long long *host_out, int n_blocks) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w64_wgtime), sizeof(unsigned long long) * 8 * (size_t)std::min(n_blocks, 8192));
+}
+#endif
 #ifdef W64_TIMING      /* measurement builds only (tools/debug): per-phase cycle sums of the last w64 launch */
 extern "C" int duo_debug_w64_timing(uint32_t *host_out) {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(w64_timing), 8 * sizeof(uint32_t));

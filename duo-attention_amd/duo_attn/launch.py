@@ -113,8 +113,8 @@ def relaunch_under_torchrun(nproc: int, visible: Optional[int] = None) -> int:
 def quiet_this_rank() -> None:
     """Ranks other than 0 of a self-launched harness compute the same tokens as rank 0 (tensor parallelism: identical logits
     after the all-reduce; layer pipeline: the decode logits are broadcast) and would write the same result files and print
-    the same lines: their stdout goes to os.devnull and every file they open FOR WRITING is os.devnull, so rank 0 alone
-    writes results — without an edit to the harness."""
+    the same lines: their stdout goes to os.devnull, every file they open FOR WRITING is os.devnull and they create no
+    directories, so rank 0 alone writes results — without an edit to the harness."""
     import builtins
 
     sys.stdout = open(os.devnull, "w")
@@ -126,6 +126,51 @@ def quiet_this_rank() -> None:
         return real_open(file, mode, *a, **kw)
 
     builtins.open = rank_open
+    # ... and they create no directories (`if not os.path.exists(d): os.makedirs(d)` on two ranks at once is a race)
+    os.makedirs = lambda *a, **kw: None
+    os.mkdir = lambda *a, **kw: None
+
+
+class _AtomicWrite:
+    """file object of ``open(path, "w")`` on rank 0 of a self-launched harness: the bytes go to a temporary file next to
+    ``path`` that replaces it on close — another rank that lists the directory and reads every result file it finds (the
+    needle harness's ``result_exists``, eval/needle/needle_in_haystack.py:380-397) never sees a half-written one."""
+
+    def __init__(self, real_open, path, mode, a, kw):
+        self._path = os.fspath(path)
+        self._tmp = f"{self._path}.tmp-rank0-{os.getpid()}"
+        self._f = real_open(self._tmp, mode, *a, **kw)
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __iter__(self):
+        return iter(self._f)
+
+    def close(self):
+        if not self._f.closed:
+            self._f.close()
+            os.replace(self._tmp, self._path)
+
+
+def atomic_writes_on_this_rank() -> None:
+    import builtins
+
+    real_open = builtins.open
+
+    def rank0_open(file, mode="r", *a, **kw):
+        if mode in ("w", "wt", "wb") and isinstance(file, (str, os.PathLike)) and os.fspath(file) != os.devnull:
+            return _AtomicWrite(real_open, file, mode, a, kw)
+        return real_open(file, mode, *a, **kw)
+
+    builtins.open = rank0_open
 
 
 def ensure_ranks(n_devices: int, what: str) -> None:
@@ -161,5 +206,8 @@ def ensure_ranks(n_devices: int, what: str) -> None:
         local = int(os.environ.get("LOCAL_RANK", os.environ["RANK"]))
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if os.environ.get(SELF_LAUNCHED_ENV) == "1" and dist.get_rank() != 0:
-        quiet_this_rank()
+    if os.environ.get(SELF_LAUNCHED_ENV) == "1":
+        if dist.get_rank() != 0:
+            quiet_this_rank()
+        else:
+            atomic_writes_on_this_rank()

@@ -30,7 +30,15 @@ def heads_from_counts(counts, num_kv_heads):
 PARITY_LOG = {}
 
 
-def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: torch.Tensor = None):
+def with_rounded(budget: torch.Tensor, ref_rounded: torch.Tensor) -> torch.Tensor:
+    """attach the REFERENCE ARITHMETIC's own result on the same inputs (P rounded to the element type before P.V, output
+    rounded to the element type — what FA2 computes; the oracle's ``round_p=True`` form) to the budget tensor an
+    ``attn_close`` call receives: the call then also holds the kernel to that arithmetic's own noise"""
+    budget.ref_rounded = ref_rounded
+    return budget
+
+
+def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: torch.Tensor = None, ref_rounded: torch.Tensor = None):
     """Parity bar for bf16 attention outputs against the EXACT-P fp32 oracle.
 
     north_star asks for 1e-3 relative.  Two roundings that the reference's own kernel (FA2) also
@@ -42,6 +50,13 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
     Elementwise:  |ours - ref| <= 1e-3*|ref| + 2^-8*|ref| + 2^-8*budget + 1e-3*rms(ref)
     Statistical:  rms(ours - ref) <= 2.5e-3 * rms(ref)   (random rounding noise sits near 1.2e-3;
                   a wrong mask bit or a mis-scaled tile is orders of magnitude above it).
+    Against the reference arithmetic itself (round 6; ``ref_rounded`` or ``helpers.with_rounded(budget, ...)``): the absolute
+    bar above was calibrated on N(0, 1) data, where the noise of the reference's OWN arithmetic — P rounded to bf16 before
+    P.V, bf16 output — is 2.33e-3 of rms; on other data that noise moves (2.55e-3 on low-variance scores, profiles/
+    r5_fuzz.md), and a kernel 5 % noisier than the reference would still pass.  So where the rounded form is available:
+                  rms(ours - ref) <= (1.03 + 3 / sqrt(n)) * rms(ref_rounded - ref)
+    (two independent draws of the same noise over n elements differ by ~1 / sqrt(n) in rms); when that holds and every
+    element passed, the absolute bar may be crossed by the same margin the reference arithmetic crosses it.
     """
     o = ours.float().cpu()
     r = ref_exact.float().cpu()
@@ -53,6 +68,13 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
     if budget is not None:
         tol = tol + (2.0 ** -8) * budget.float().cpu()
     err_rms = (o - r).pow(2).mean().sqrt()
+    if ref_rounded is None and budget is not None:
+        ref_rounded = getattr(budget, "ref_rounded", None)
+    ref_noise = None
+    if ref_rounded is not None:
+        rr = ref_rounded.float().cpu()
+        assert rr.shape == r.shape, (rr.shape, r.shape)
+        ref_noise = (rr - r).pow(2).mean().sqrt()
     if what and o.numel():
         PARITY_LOG[what] = {
             "n": int(o.numel()),
@@ -64,12 +86,43 @@ def attn_close(ours: torch.Tensor, ref_exact: torch.Tensor, what="", budget: tor
             "worst_err_over_elementwise_tol": float((err / tol.clamp_min(1e-30)).max()),
             "p_rounding_budget": budget is not None,
         }
+        if ref_noise is not None:
+            PARITY_LOG[what]["rms_err_of_reference_arithmetic"] = float(ref_noise)
+            PARITY_LOG[what]["rms_err_over_reference_arithmetic"] = float(err_rms / ref_noise) if float(ref_noise) > 0 else 0.0
     bad = err > tol
     assert not bad.any(), (
         f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; max err {err.max():.3e} "
         f"at ref {r.flatten()[err.argmax()]:.3e}, rms {rms:.3e}"
     )
+    if ref_noise is not None and float(ref_noise) > 0:
+        lim = (1.03 + 3.0 / max(1, o.numel()) ** 0.5) * ref_noise
+        assert err_rms <= lim, (f"{what}: rms err {err_rms:.3e} is more than 3 % above the reference arithmetic's own "
+                                f"{ref_noise:.3e} on the same inputs (rms(ref) {rms:.3e})")
+        # the reference arithmetic may itself sit past the absolute bar on this data: the kernel is held to IT
+        assert err_rms <= max(2.5e-3 * rms, lim), f"{what}: rms err {err_rms:.3e} vs rms(ref) {rms:.3e}"
+        return
     assert err_rms <= 2.5e-3 * rms, f"{what}: rms err {err_rms:.3e} vs rms(ref) {rms:.3e}"
+
+
+def rel_close(got, want, bar, what):
+    """model-level comparison (logits, cache rows) in relative L2; the MEASURED figure goes to the parity report
+    (``model: ...`` entries) and, one line per call, to gpurun_out/model_rel.log (worker processes included), so the bars
+    can be kept at about twice what is measured instead of at a round number"""
+    import os
+
+    g, w = got.float().cpu(), want.float().cpu()
+    assert g.shape == w.shape, (what, g.shape, w.shape)
+    rel = float((g - w).norm() / w.norm().clamp_min(1e-30))
+    PARITY_LOG["model: " + what] = {"rel_l2": rel, "bar": bar, "n": int(g.numel())}
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        try:
+            with open(os.path.join(d, "model_rel.log"), "a") as f:
+                f.write(f"{rel:.4e}\t{bar:.1e}\t{what}\n")
+        except OSError:
+            pass
+    assert rel < bar, f"{what}: relative L2 {rel:.3e} >= {bar:.1e}"
+    return rel
 
 
 # ----------------------------------------------------------------------------------------------------------------------

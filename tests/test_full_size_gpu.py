@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import attn_close
+from helpers import attn_close, with_rounded
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -38,12 +38,16 @@ def _pool(n_heads, rows, g, dtype=torch.bfloat16):
 
 def _ref_rows(q_rows, K, V, vis, scale):
     """q_rows [n, G, D], K/V [T, D] (one kv head), vis [n] = number of visible keys (prefix) per row.
-    Returns (out [n, G, D] fp32, budget [n, G, D] = sum_j p_j |v_j|)."""
+    Returns (out [n, G, D] fp32, budget [n, G, D] = sum_j p_j |v_j|, the same rows in the REFERENCE's arithmetic — FA2:
+    exp(s - max) rounded to the element type before P.V, normalised by the unrounded sum, output rounded — for
+    helpers.with_rounded)."""
     s = torch.einsum("ngd,td->ngt", q_rows.float(), K.float()) * scale
     t = torch.arange(K.shape[0], device=K.device)
     s.masked_fill_(t[None, None, :] >= vis[:, None, None], float("-inf"))
     p = torch.softmax(s, dim=-1)
-    return torch.einsum("ngt,td->ngd", p, V.float()), torch.einsum("ngt,td->ngd", p, V.float().abs())
+    e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+    rounded = (torch.einsum("ngt,td->ngd", e.to(K.dtype).float(), V.float()) / e.sum(dim=-1, keepdim=True)).to(K.dtype).float()
+    return torch.einsum("ngt,td->ngd", p, V.float()), torch.einsum("ngt,td->ngd", p, V.float().abs()), rounded
 
 
 def _check_prefill(S, past, nf, ns, G, W, g, n_sample=48, first_chunk=False):
@@ -57,11 +61,12 @@ def _check_prefill(S, past, nf, ns, G, W, g, n_sample=48, first_chunk=False):
     rows[0], rows[1] = 0, S - 1
     ref = torch.empty(n_sample, Hq, D, device=DEV)
     bud = torch.empty_like(ref)
+    rnd = torch.empty_like(ref)
     if first_chunk:
         be.attention(q, out, G, (nkv, 0, None, (kn, vn)), None, scale)
         for h in range(nkv):
-            r, b = _ref_rows(q[rows, h * G:(h + 1) * G], kn[:, h], vn[:, h], rows + 1, scale)
-            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G] = r, b
+            r, b, rr = _ref_rows(q[rows, h * G:(h + 1) * G], kn[:, h], vn[:, h], rows + 1, scale)
+            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G], rnd[:, h * G:(h + 1) * G] = r, b, rr
     else:
         fk, fv = _pool(max(nf, 1), past + S, g), _pool(max(nf, 1), past + S, g)
         sk, sv = _pool(max(ns, 1), W, g), _pool(max(ns, 1), W, g)
@@ -71,16 +76,16 @@ def _check_prefill(S, past, nf, ns, G, W, g, n_sample=48, first_chunk=False):
         stream = (ns, nf * G, (sk[:, :ns], sv[:, :ns]), (kn[:, nf:], vn[:, nf:])) if ns else None
         be.attention(q, out, G, full, stream, scale)
         for h in range(nf):          # retrieval head: keys {0 .. past + row}
-            r, b = _ref_rows(q[rows, h * G:(h + 1) * G], fk[:, h], fv[:, h], past + rows + 1, scale)
-            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G] = r, b
+            r, b, rr = _ref_rows(q[rows, h * G:(h + 1) * G], fk[:, h], fv[:, h], past + rows + 1, scale)
+            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G], rnd[:, h * G:(h + 1) * G] = r, b, rr
         for j in range(ns):          # streaming head: Pool(past) U {past .. past + row}
             h = nf + j
             K = torch.cat([sk[:, j], kn[:, h]], 0)
             V = torch.cat([sv[:, j], vn[:, h]], 0)
-            r, b = _ref_rows(q[rows, h * G:(h + 1) * G], K, V, W + rows + 1, scale)
-            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G] = r, b
+            r, b, rr = _ref_rows(q[rows, h * G:(h + 1) * G], K, V, W + rows + 1, scale)
+            ref[:, h * G:(h + 1) * G], bud[:, h * G:(h + 1) * G], rnd[:, h * G:(h + 1) * G] = r, b, rr
     torch.cuda.synchronize()
-    attn_close(out[rows], ref, f"prefill S={S} past={past} nf={nf} ns={ns}", bud)
+    attn_close(out[rows], ref, f"prefill S={S} past={past} nf={nf} ns={ns}", with_rounded(bud, rnd))
     return q, out
 
 
@@ -241,7 +246,7 @@ def test_cfg5_int4_decode_3m_tokens(mode):
         for j in range(n_h):
             h = cls_off + j
             K, V = dequant(kq_[:, j], ksz_[:, j]), dequant(vq_[:, j], vsz_[:, j])
-            r, b = _ref_rows(q[None, h * G:(h + 1) * G], K, V, one * T, scale)
+            r, b, _ = _ref_rows(q[None, h * G:(h + 1) * G], K, V, one * T, scale)
             ref[h * G:(h + 1) * G], bud[h * G:(h + 1) * G] = r[0], b[0]
             del K, V
     o, r = out.float(), ref

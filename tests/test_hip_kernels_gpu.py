@@ -11,7 +11,7 @@ import itertools
 import pytest
 import torch
 
-from helpers import ShapeModel, attn_close, heads_from_counts
+from helpers import ShapeModel, attn_close, heads_from_counts, with_rounded
 from oracle.duo_oracle import (
     StaticCacheRef,
     flash_attn_func_ref,
@@ -168,6 +168,7 @@ def _attention_case(S, group, nf, ns, lenA_full, lenA_stream, head_major, seed, 
     P.V like FA2 does and gets the matching error budget (helpers.attn_close); the scalar-FMA decode
     kernel keeps P in fp32 (never less accurate than FA2) and gets none."""
     kw = dict(round_p=False, out_dtype=torch.float32, return_budget=True)
+    rkw = dict(round_p=True, out_dtype=torch.bfloat16)       # the reference's own arithmetic (FA2): helpers.with_rounded
     from duo_attn.backend import HipBackend
 
     g = torch.Generator().manual_seed(seed)
@@ -180,10 +181,11 @@ def _attention_case(S, group, nf, ns, lenA_full, lenA_stream, head_major, seed, 
     scale = D ** -0.5
     ref = torch.empty(S, Hq, D, dtype=torch.float32)
     bud = torch.empty(S, Hq, D, dtype=torch.float32)
+    rnd = torch.empty(S, Hq, D, dtype=torch.float32)
     if first_chunk:
         be.attention(qd, out, group, (nf + ns, 0, None, (knd, vnd)), None, scale)
         r, b = flash_attn_func_ref(q[None], k_new[None], v_new[None], **kw)
-        return out, r[0], b[0]
+        return out, r[0], with_rounded(b[0], flash_attn_func_ref(q[None], k_new[None], v_new[None], **rkw)[0])
     full = stream = None
     if nf:
         fk, fv, fkd, fvd = _make_pool(lenA_full, nf, g, head_major)
@@ -192,6 +194,8 @@ def _attention_case(S, group, nf, ns, lenA_full, lenA_stream, head_major, seed, 
         vv = torch.cat([fv, v_new[:, :nf]], 0)
         r, b = flash_attn_func_ref(q[None, :, :nf * group], kk[None], vv[None], **kw)
         ref[:, :nf * group], bud[:, :nf * group] = r[0], b[0]
+        if S > 1:
+            rnd[:, :nf * group] = flash_attn_func_ref(q[None, :, :nf * group], kk[None], vv[None], **rkw)[0]
     if ns:
         sk, sv, skd, svd = _make_pool(lenA_stream, ns, g, head_major)
         stream = (ns, nf * group, (skd, svd) if lenA_stream else None, (knd[:, nf:], vnd[:, nf:]))
@@ -199,8 +203,10 @@ def _attention_case(S, group, nf, ns, lenA_full, lenA_stream, head_major, seed, 
         vv = torch.cat([sv, v_new[:, nf:]], 0)
         r, b = flash_attn_func_ref(q[None, :, nf * group:], kk[None], vv[None], **kw)
         ref[:, nf * group:], bud[:, nf * group:] = r[0], b[0]
+        if S > 1:
+            rnd[:, nf * group:] = flash_attn_func_ref(q[None, :, nf * group:], kk[None], vv[None], **rkw)[0]
     be.attention(qd, out, group, full, stream, scale)
-    return out, ref, (bud if S > 1 else None)
+    return out, ref, (with_rounded(bud, rnd) if S > 1 else None)
 
 
 DECODE_CASES = [

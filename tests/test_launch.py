@@ -142,3 +142,104 @@ def test_benchmark_static_starts_its_own_ranks(mode):
     assert "2 ranks (gloo" in res["mode"] and res["prefill_tok_s"] > 0 and res["avg_generation_time_ms"] > 0
     assert len(res["stages" if mode == "--pp" else "ranks"]) == 2
     assert "starting 2 ranks" in r.stderr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 6: to_device(model, [gpu ids], enable_tp=True) inside ONE python process — how the reference's
+# scripts/niah.sh and scripts/longbench.sh start their harnesses — starts its own ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def test_original_command_line_is_recovered_for_the_relaunch():
+    from duo_attn import launch
+
+    py = sys.executable
+    assert launch.original_command([py, "eval/needle/needle_in_haystack.py", "-s", "300"]) == \
+        [os.path.abspath("eval/needle/needle_in_haystack.py"), "-s", "300"]
+    assert launch.original_command([py, "-u", "-X", "faulthandler", "-W", "ignore", "x.py", "-m", "keep"]) == \
+        [os.path.abspath("x.py"), "-m", "keep"]
+    assert launch.original_command([py, "-m", "pkg.tool", "--flag"]) == ["-m", "pkg.tool", "--flag"]
+    for bad in ([py, "-c", "print(1)"], [py], [py, "-"]):
+        with pytest.raises(ValueError, match="torch.distributed.run"):
+            launch.original_command(bad)
+
+
+def test_to_device_with_a_device_list_starts_its_own_ranks(tmp_path):
+    """a plain ``python script.py`` that calls ``to_device(model, [0, 1], enable_tp=True)`` with no process group and no rank
+    environment (reference eval/needle/needle_in_haystack.py:213-214): the command line is started again as two ranks, the
+    ranks initialise their group inside to_device (gloo: no GPU here), rank 0 alone prints and writes, and its result file
+    is never visible half-written; the first process exits with the ranks' exit code"""
+    script = tmp_path / "harness.py"
+    script.write_text(textwrap.dedent(f"""
+        import json, os, sys
+        for p in ({ROOT!r}, {os.path.join(ROOT, "duo-attention_amd")!r}, {os.path.join(ROOT, "tests")!r}):
+            sys.path.insert(0, p)
+        import numpy as np, torch
+        import torch.distributed as dist
+        from transformers import LlamaConfig, LlamaForCausalLM
+        from duo_attn import backend
+        from duo_attn.patch import enable_duo_attention_eval
+        from duo_attn.utils import to_device
+        from oracle.duo_oracle import OracleBackend
+        backend._set_backend_for_testing(OracleBackend())
+        orig_to = torch.nn.Module.to
+        torch.nn.Module.to = lambda self, *a, **k: orig_to(self, *[("cpu" if isinstance(x, str) and x.startswith("cuda") else x) for x in a], **k)
+        torch.cuda.set_device = lambda *a, **k: None
+        torch.manual_seed(3)
+        cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          head_dim=128, vocab_size=64, max_position_embeddings=512, rope_theta=10000.0, tie_word_embeddings=False)
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+        print("loading done, world:", os.environ.get("WORLD_SIZE", "none"), flush=True)
+        enable_duo_attention_eval(model, np.array([[1.0, 0.0], [0.0, 1.0]]), 4, 12)       # the harness's order: patch, then shard
+        model = to_device(model, [0, 1], enable_tp=True)
+        assert dist.is_initialized() and dist.get_world_size() == 2
+        ids = torch.randint(0, 64, (1, 40), generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            out = model(input_ids=ids[:, :30], past_key_values=None, use_cache=True)
+            toks = []
+            for t in range(30, 36):
+                out = model(input_ids=ids[:, t:t + 1], past_key_values=out.past_key_values, use_cache=True)
+                toks.append(int(out.logits[0, -1].argmax()))
+        os.makedirs(sys.argv[1], exist_ok=True)
+        with open(os.path.join(sys.argv[1], "result.json"), "w") as f:
+            json.dump({{"rank": dist.get_rank(), "tokens": toks}}, f)
+        print("RESULT", json.dumps(toks), flush=True)
+    """))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PYTHONPATH")}
+    env["DUO_BENCH_DEBUG_SHARED_GPU"] = "1"       # (no second GPU to count: the rehearsal mode skips the visible-GPU check)
+    out_dir = tmp_path / "out"
+    r = subprocess.run([sys.executable, str(script), str(out_dir)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "starting this command again as 2 ranks" in r.stderr
+    # the first process and both ranks load the model; only rank 0 of the ranks speaks after to_device
+    assert r.stdout.count("loading done, world: none") == 1 and r.stdout.count("loading done, world: 2") == 2
+    assert r.stdout.count("RESULT") == 1
+    res = json.load(open(out_dir / "result.json"))
+    assert res["rank"] == 0 and len(res["tokens"]) == 6
+    assert not [f for f in os.listdir(out_dir) if "tmp-rank0" in f]
+    # ... and the tokens are the single-process model's
+    single = subprocess.run([sys.executable, "-c", textwrap.dedent(f"""
+        import sys
+        for p in ({ROOT!r}, {os.path.join(ROOT, "duo-attention_amd")!r}):
+            sys.path.insert(0, p)
+        import numpy as np, torch, json
+        from transformers import LlamaConfig, LlamaForCausalLM
+        from duo_attn import backend
+        from duo_attn.patch import enable_duo_attention_eval
+        from oracle.duo_oracle import OracleBackend
+        backend._set_backend_for_testing(OracleBackend())
+        torch.manual_seed(3)
+        cfg = LlamaConfig(hidden_size=512, intermediate_size=256, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                          head_dim=128, vocab_size=64, max_position_embeddings=512, rope_theta=10000.0, tie_word_embeddings=False)
+        model = LlamaForCausalLM(cfg).to(torch.bfloat16).eval()
+        enable_duo_attention_eval(model, np.array([[1.0, 0.0], [0.0, 1.0]]), 4, 12)
+        ids = torch.randint(0, 64, (1, 40), generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            out = model(input_ids=ids[:, :30], past_key_values=None, use_cache=True)
+            toks = []
+            for t in range(30, 36):
+                out = model(input_ids=ids[:, t:t + 1], past_key_values=out.past_key_values, use_cache=True)
+                toks.append(int(out.logits[0, -1].argmax()))
+        print("RESULT", json.dumps(toks))
+    """)], capture_output=True, text=True, timeout=600, env=env)
+    assert single.returncode == 0, single.stderr[-2000:]
+    want = json.loads(single.stdout.split("RESULT", 1)[1])
+    assert res["tokens"] == want

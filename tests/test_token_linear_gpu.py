@@ -16,7 +16,12 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import rel_close
 from oracle.duo_oracle import rmsnorm_ref, token_linear_ref
+
+# model-level bars: about twice the measured figure (gpurun_out/model_rel.log)
+BAR_FUSED_VS_MODULES = 2e-2
+BAR_ARGMAX_AGREE = 0.9
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -170,13 +175,13 @@ def test_fused_decode_layer_matches_module_by_module(family, bsz, eager_decode_s
     l_f, n_f, c_f = run(True)
     l_m, n_m, c_m = run(False)
     assert n_f == 10 * 3 * 4 and n_m == 0          # four token-linear launches per layer and step; none module by module
-    rel = ((l_f - l_m).norm() / l_m.norm()).item()
-    assert rel < 2e-2, rel
-    assert (l_f.argmax(-1) == l_m.argmax(-1)).float().mean() >= 0.9
+    rel_close(l_f, l_m, BAR_FUSED_VS_MODULES, "token-linear: fused decode layers vs module by module, logits")
+    agree = (l_f.argmax(-1) == l_m.argmax(-1)).float().mean().item()
+    assert agree >= BAR_ARGMAX_AGREE, agree
     assert c_f.kv_seq_len == c_m.kv_seq_len == 90
     for l in range(3):
         a, b = c_f.full_value_states_list[l][:, :90].float(), c_m.full_value_states_list[l][:, :90].float()
-        assert ((a - b).norm() / b.norm().clamp_min(1e-6)).item() < 2e-2
+        rel_close(a, b, BAR_FUSED_VS_MODULES, f"token-linear: fused vs module by module, layer {l} retrieval V rows")
 
 
 @pytest.mark.parametrize("shape,pad", [((2, 300, 1024), 0), ((1, 16384, 14336), 0), ((5, 7, 72), 8), ((1, 1, 8), 0)])

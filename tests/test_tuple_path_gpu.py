@@ -16,7 +16,11 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import attn_close
+from helpers import attn_close, rel_close
+
+# model-level bars: about twice the measured figure (gpurun_out/model_rel.log)
+BAR_HIP_VS_HF_CPU = 2e-2
+BAR_BATCH_VS_SOLO = 2e-2
 from oracle.duo_oracle import OracleBackend, flash_attn_func_ref, tuple_forward_ref
 from test_golden_and_model_gpu import _rel, tiny
 from test_oracle_golden import _hf_cos_sin, bf16, load, split_hidden
@@ -186,7 +190,7 @@ def test_tuple_model_with_evicting_window_matches_oracle():
                 o = cpu_model(input_ids=ids[:, pos:pos + c].cpu(), past_key_values=past, use_cache=True)
                 past = o.past_key_values
                 pos += c
-                assert _rel(logits[i], o.logits) < 2e-2, (i, _rel(logits[i], o.logits))
+                rel_close(logits[i], o.logits, BAR_HIP_VS_HF_CPU, f"tuple: HIP logits chunk {i} vs HF eager on the CPU")
     finally:
         backend._set_backend_for_testing(None)
     # and it is NOT full attention: the unpatched model's logits differ clearly once the window has evicted
@@ -249,7 +253,7 @@ def test_tuple_model_batch_rows_equal_single_rows():
     both, past_b = run(slice(0, 2))
     for b in range(2):
         solo, past_s = run(slice(b, b + 1))
-        assert _rel(both[b:b + 1], solo) < 2e-2, (b, _rel(both[b:b + 1], solo))
+        rel_close(both[b:b + 1], solo, BAR_BATCH_VS_SOLO, f"tuple: batch row {b} logits vs solo")
         # layer 0's caches only depend on the embeddings and layer 0's projections of the row itself (equal up to the
         # bf16 rounding of a GEMM that may be tiled differently for 2 x 300 rows than for 300)
         fb, sb = past_b[0]

@@ -12,7 +12,7 @@ extra=""   # e.g. EXTRA="-mllvm -amdgpu-kernarg-preload-count=14" (measured: no 
 extra="$EXTRA"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $extra "$@" -c $src/$SRC.hip -o /tmp/ab_$tag/$SRC.o
 objs=""
-for f in duo_decode duo_prefill duo_rope_kv duo_int4 duo_linear; do
+for f in duo_decode duo_prefill duo_prefill_w32_debug duo_rope_kv duo_int4 duo_linear duo_tuple; do
   if [ $f = $SRC ]; then objs="$objs /tmp/ab_$tag/$f.o"; else objs="$objs $src/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/duo-attention_amd/lib/ab/lib_$tag.so $objs

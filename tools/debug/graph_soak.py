@@ -199,7 +199,9 @@ class Soak:
             for i in range(2):
                 self.twin_kv.clear()
                 self.prefill(self.twin, self.twin_kv, 0, 650 + 10 * i)
-                self.same(got[i], self.decode(self.twin, self.twin_kv, toks[i], 12, False, True), f"f{i}")
+                # (the three warm-up steps first: a step + evict_last(1) on a saturated streaming window leaves it one row
+                #  short, so the first step after a prefill is not the steady state)
+                self.same(got[i], self.decode(self.twin, self.twin_kv, toks[i], 15, False, True)[3:], f"f{i}")
 
     def scen_g(self, check):
         """a direct DecodeStepGraph: the re-capture for the next bucket fails once (simulated), is retried, succeeds"""
