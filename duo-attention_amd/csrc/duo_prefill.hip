@@ -54,56 +54,8 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
     const int r = pass * 32 + (threadIdx.x >> 3);
     const int q = tile * QBLK + r;
     if (q >= P.S) return;
-    const int64_t row0 = part0 * QBLK + r;     // piece s: + s * QBLK
-    // every piece's (m, l) of this row: independent 8-byte loads, then the weights
-    constexpr int KMAX = 16;
-    f32x2 ml[KMAX];
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s)
-        ml[s] = s < ks ? *reinterpret_cast<const f32x2 *>(P.ws_ml + (row0 + (int64_t)s * QBLK) * 2) : f32x2{-INFINITY, 0.f};
-    float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) M = fmaxf(M, ml[s].x);
-    float L = 0.f;
-    float w[KMAX];
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-        // a piece that saw no key of the row (m = -inf, l = 0) has weight 0; a row no piece saw cannot exist (key 0 of the
-        // chunk's own rows is visible to every query)
-        w[s] = ml[s].x == -INFINITY ? 0.f : fast_exp2((ml[s].x - M) * P.scale_log2e);
-        L = fmaf(ml[s].y, w[s], L);
-    }
-    f32x4 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *src0 = P.ws_o + row0 * DUO_HEAD_DIM + 16 * jd;
-#pragma unroll
-    for (int s0 = 0; s0 < KMAX; s0 += 4) {
-        if (s0 >= ks) break;
-        f32x4 v[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int s = s0 + u < ks ? s0 + u : s0;       // past the end: re-read a valid piece with weight 0
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(src0 + (int64_t)s * QBLK * DUO_HEAD_DIM);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[u][i] = __builtin_nontemporal_load(src + i);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float wu = s0 + u < ks ? w[s0 + u] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + v[u][i] * wu;
-        }
-    }
-    const float inv = 1.f / L;
-    bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs + 16 * jd;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        u32x2 w2;
-        w2.x = cvt_pk16<F16>(acc[i].x * inv, acc[i].y * inv);
-        w2.y = cvt_pk16<F16>(acc[i].z * inv, acc[i].w * inv);
-        *reinterpret_cast<u32x2 *>(op + 4 * i) = w2;
-    }
+    bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs;
+    prefill_merge_row<F16, false>(P, ks, part0 * QBLK + r, op, jd);
 }
 
 }  // namespace
@@ -140,6 +92,7 @@ namespace {
 struct PlanCost {
     double t_tile, t_fix, t_merge, t_part, t_pad;     // microseconds
     double c0;      // cost of a unit of work with (nearly) all CUs idle, relative to the full chip (tail of a launch)
+    double t_merge_in;      // what a split launch costs beyond its blocks when the last arrival of an item merges it in the kernel
 };
 static const PlanCost &plan_cost() {
     // defaults: fitted to same-box probes of this kernel (profiles/r6_prefill_plan.md); DUO_PREFILL_PLAN_COST overrides
@@ -147,16 +100,18 @@ static const PlanCost &plan_cost() {
         // t_fix is what a workgroup costs beyond its bulk tiles: prologue (Q fragments, two tiles in flight), the handful of
         // tiles in the general (masked / run-boundary) form, epilogue; c0: fewer active CUs clock higher and share the fabric
         // with fewer others — a lone 1800-tile workgroup walks a tile in 1.2 us, 256 of them in 1.6
-        PlanCost v{1.59, 22.0, 20.0, 0.05, 1.0, 0.63};
+        // (fit over 280 timed launches, tools/prefill_plan_model.py fit: rms 3.7 %; t_merge = the merge launch incl. the
+        //  kernel boundary in front of it; t_merge_in = the in-kernel form: the last item's merge on one workgroup)
+        PlanCost v{1.62, 26.5, 41.0, 0.0, 1.0, 0.62, 15.0};
         if (const char *e = getenv("DUO_PREFILL_PLAN_COST"))
-            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad, &v.c0);
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad, &v.c0, &v.t_merge_in);
         return v;
     }();
     return c;
 }
 
 struct PlanShape {
-    int32_t nkv[2], group, nq, S, lenA[2], lenB[2], max_parts, xmap1;
+    int32_t nkv[2], group, nq, S, lenA[2], lenB[2], max_parts, xmap1, inkernel;
     uint32_t force;
     bool operator==(const PlanShape &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
@@ -255,7 +210,7 @@ static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool x
         end += (heap[i] - prev) * (C.c0 + (1.0 - C.c0) * a / kPrefillCUs);
         prev = heap[i];
     }
-    if (P.nparts > 0) end += C.t_merge + C.t_part * P.nparts;
+    if (P.nparts > 0) end += (K.inkernel ? C.t_merge_in : C.t_merge) + C.t_part * P.nparts;
     return end;
 }
 
@@ -350,6 +305,7 @@ extern "C" int32_t duo_debug_prefill_plan(const int32_t *shape, uint32_t force, 
     K.nq = (K.S + QBLK - 1) / QBLK;
     const bool xmap0 = shape[9] & 1, xmap1 = (shape[9] & 2) != 0;
     K.xmap1 = xmap1;
+    K.inkernel = 1;
     K.force = K.max_parts <= 0 ? 0x10000u : force;
     if (K.group <= 0 || K.S <= 0 || K.nkv[0] < 0 || K.nkv[1] < 0) return DUO_EINVAL;
     const PrefillPlan plan = plan_compute(K, xmap0);
@@ -370,6 +326,27 @@ extern "C" int32_t duo_debug_prefill_plan(const int32_t *shape, uint32_t force, 
 }
 
 extern "C" int64_t duo_attn_prefill_workspace_bytes(void) { return 2048 * kPrefillPartialBytes; }
+
+// Arrival counters of the in-kernel merge: owned by the library, one 64 KiB block per caller workspace (the workspace is what
+// two concurrent launches must not share, so its address is the right key), zero-filled once — every launch leaves its
+// counters zero.  NULL (-> the launch pair with duo_prefill_merge_kernel) while the stream is being captured and the block
+// does not exist yet, after 256 distinct workspaces, or when the allocation fails.
+constexpr int kPrefillTicketWords = 16384;
+static int32_t *prefill_tickets_for(void *workspace, hipStream_t st) {
+    static std::mutex mu;
+    static std::unordered_map<void *, int32_t *> blocks;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = blocks.find(workspace);
+    if (it != blocks.end()) return it->second;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (blocks.size() >= 256) return nullptr;
+    int32_t *p = nullptr;
+    if (hipMalloc((void **)&p, kPrefillTicketWords * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemset(p, 0, kPrefillTicketWords * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+    blocks.emplace(workspace, p);
+    return p;
+}
 
 template <bool F16>
 static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_stride,
@@ -442,6 +419,11 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     K.nq = P.n_qtiles;
     K.S = n_tokens;
     K.xmap1 = xmap1;
+    // in-kernel merge (the last arrival of a split item merges it: no second launch) — the 4-wave kernel only;
+    // DUO_PREFILL_INKERNEL_MERGE=0 / debug bit 20: the launch pair of rounds 1-5 (same-box A/B, tests of both forms)
+    static const bool want_inkernel = [] { const char *e = getenv("DUO_PREFILL_INKERNEL_MERGE"); return !e || atoi(e) != 0; }();
+    int32_t *tickets = (w64_ok && want_inkernel && workspace && !(g_debug_flags & (1u << 20))) ? prefill_tickets_for(workspace, st) : nullptr;
+    K.inkernel = tickets != nullptr;
     K.max_parts = workspace ? (int32_t)std::min<int64_t>(workspace_bytes / n_batch / kPrefillPartialBytes, 1 << 20) : 0;   // every batch row has its own partials
     {
         static const int forced0 = [] { const char *e = getenv("DUO_PREFILL_KSPLIT"); return e ? atoi(e) : 0; }();    // tuning / test knobs: force a split count
@@ -475,6 +457,11 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         P.ws_ml = P.ws_o + (int64_t)n_batch * P.nparts * QBLK * DUO_HEAD_DIM;
     }
     const int n_merge0 = P.ks[0] > 1 ? K.nkv[0] * group * K.nq : 0, n_merge1 = P.ks[1] > 1 ? K.nkv[1] * group * K.nq : 0;
+    P.tbase[0] = 0;
+    P.tbase[1] = n_merge0;
+    P.n_tickets = n_merge0 + n_merge1;
+    if ((int64_t)P.n_tickets * n_batch > kPrefillTicketWords) tickets = nullptr;     // (plan costed for the other form: still correct)
+    P.tickets = P.n_tickets > 0 ? tickets : nullptr;
 
     if (w64_ok) {
         // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
@@ -489,12 +476,13 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
         else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
         DUO_HIP_CHECK_LAUNCH();
-        if (n_merge0 + n_merge1 > 0) {
+        if (n_merge0 + n_merge1 > 0 && P.tickets == nullptr) {
             hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(8 * (n_merge0 + n_merge1), n_batch), dim3(256), 0, st, P, n_merge0);
             DUO_HIP_CHECK_LAUNCH();
         }
         return 0;
     }
+    P.tickets = nullptr;        // (the 8-wave debug kernel writes plain partials: always the launch pair)
     {       // debug / cross-check paths: the 8-wave x 32-row kernel (duo_prefill_w32_debug.hip)
         const int rc = duo_prefill_w32_launch(&P, tr, F16, nblk, n_batch, dev, st);
         if (rc) return rc;

@@ -37,6 +37,13 @@ struct PrefillParams {
     int32_t nparts;        // partials per batch row
     float *ws_o;     // [partial][256 rows][128] fp32
     float *ws_ml;    // [partial][256 rows][2]   (row max in score units, row sum)
+    // In-kernel merge (round 6): one arrival counter per split item (class 0's items first, then class 1's; one set per batch
+    // row).  The pieces of an item publish their partials write-through, drain, and take a ticket; the LAST arrival merges
+    // the item and writes `out` — no second launch.  All zero on entry, all zero again on exit.  NULL: partials are merged
+    // by duo_prefill_merge_kernel (the launch pair of rounds 1-5; debug / A-B).
+    int32_t *tickets;
+    int32_t tbase[2];      // first counter of class c
+    int32_t n_tickets;     // counters per batch row
     // XCD-aware block order of class c (4-wave kernel; see prefill_map_block): q-tile rows per period and workgroups per
     // XCD per period; xmap_q[c] == 0: plain q-tile-major order
     int32_t xmap_rows[2], xmap_q[2];
@@ -61,6 +68,7 @@ struct PrefillParams {
 struct PrefillItem {
     int ci, tile, kvh, g, split, ks;
     int part;       // partial slot of this workgroup inside one batch row's partials (valid when ks > 1)
+    int item;       // canonical index of the (q tile, q head) inside its class: (rank * n_kv_heads + kvh) * group + g
 };
 __host__ __device__ __forceinline__ PrefillItem prefill_map_block(const PrefillParams &P, int b) {
     PrefillItem I;
@@ -92,7 +100,8 @@ __host__ __device__ __forceinline__ PrefillItem prefill_map_block(const PrefillP
         I.g = p / nkv;
     }
     I.tile = rank < P.n_qtiles ? P.n_qtiles - 1 - rank : -1;
-    I.part = (I.ci ? P.pbase[1] : P.pbase[0]) + ((rank * nkv + I.kvh) * P.group + I.g) * I.ks + I.split;
+    I.item = (rank * nkv + I.kvh) * P.group + I.g;
+    I.part = (I.ci ? P.pbase[1] : P.pbase[0]) + I.item * I.ks + I.split;
     return I;
 }
 
@@ -128,6 +137,90 @@ __device__ __forceinline__ f32x16 mfma32x32x16(const bf16x8 &a, const bf16x8 &b,
                                                       *reinterpret_cast<const f16x8_mfma *>(&b), c, 0, 0, 0);
     else
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// Partials handed to ANOTHER workgroup of the same launch (in-kernel merge): write-through stores and loads that are served
+// by memory, never by an XCD's possibly stale L2 (MI355X inter-workgroup hand-off, the form the single-launch decode step
+// uses: no release fence = no L2 write-back per workgroup; the consumer needs no acquire fence either).
+__device__ __forceinline__ void st16_wt(float *p, const f32x4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st8_wt(float *p, float a, float b) {
+    const f32x2 v = {a, b};
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld16_sc1(const float *p) {     // (asm load: the caller waits — s_waitcnt vmcnt — before use)
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ f32x2 ld8_sc1(const float *p) {
+    f32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// One output row slice of a split item: combine its ks partials — out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
+// row0: index of the row in piece 0's partial (piece s: + s * QBLK rows); jd: which group of 16 dims.  SC1: the partials were
+// published by other workgroups of THIS launch (see st16_wt): sc1 loads with explicit waits; otherwise plain loads.
+// Every piece's (m, l) is requested up front, the accumulator rows follow four pieces at a time.
+template <bool F16, bool SC1>
+__device__ __forceinline__ void prefill_merge_row(const PrefillParams &P, int ks, int64_t row0, bf16_t *op, int jd) {
+    constexpr int KMAX = 16;
+    f32x2 ml[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        const float *mp = P.ws_ml + (row0 + (int64_t)(s < ks ? s : 0) * QBLK) * 2;
+        if constexpr (SC1) ml[s] = ld8_sc1(mp);
+        else ml[s] = *reinterpret_cast<const f32x2 *>(mp);
+    }
+    if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) M = fmaxf(M, s < ks ? ml[s].x : -INFINITY);
+    float L = 0.f;
+    float w[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) {
+        // a piece that saw no key of the row (m = -inf, l = 0) has weight 0; a row no piece saw cannot exist (the row's own
+        // key is visible to it)
+        w[s] = (s >= ks || ml[s].x == -INFINITY) ? 0.f : fast_exp2((ml[s].x - M) * P.scale_log2e);
+        L = fmaf(ml[s].y, w[s], L);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *src0 = P.ws_o + row0 * DUO_HEAD_DIM + 16 * jd;
+#pragma unroll
+    for (int s0 = 0; s0 < KMAX; s0 += 4) {
+        if (s0 >= ks) break;
+        f32x4 v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = s0 + u < ks ? s0 + u : s0;       // past the end: re-read a valid piece with weight 0
+            const float *src = src0 + (int64_t)s * QBLK * DUO_HEAD_DIM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (SC1) v[u][i] = ld16_sc1(src + 4 * i);
+                else v[u][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + i);
+            }
+        }
+        if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float wu = s0 + u < ks ? w[s0 + u] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = acc[i] + v[u][i] * wu;
+        }
+    }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32x2 w2;
+        w2.x = cvt_pk16<F16>(acc[i].x * inv, acc[i].y * inv);
+        w2.y = cvt_pk16<F16>(acc[i].z * inv, acc[i].w * inv);
+        *reinterpret_cast<u32x2 *>(op + 16 * jd + 4 * i) = w2;
+    }
 }
 
 __device__ __forceinline__ uint32_t lds_addr(const void *p) {
