@@ -258,6 +258,42 @@ def kernel_rooflines(hp: HotPath, counts_local, n_rep=3):
     return prefill, decode
 
 
+def decode_graph_leg(hp: HotPath, counts_local, n=40):
+    """The same decode step (every local layer through duo_static_attention_core, then evict_last(1)) captured once in a
+    HIP graph and replayed: the GPU-side cost of the step with no host in the loop.  At 128K the eager loop of the timed
+    region is GPU-bound and the two figures agree; at <= 64K it is host-bound (its time does not depend on the context) and
+    this is what the kernels cost.  Extra information, outside the timed region."""
+    from duo_attn.graph import DecodeStepGraph
+
+    cache = hp.cache
+    for li in range(len(counts_local)):     # (the timed jobs left the cache at the full context; contents do not matter here)
+        cache.kv_seq_len_list[li] = hp.ctx
+        cache.streaming_kv_seq_len_list[li] = min(hp.ctx, SINK + RECENT)
+
+    def step():
+        for li in range(len(counts_local)):
+            hp.layer_core(li, 1, hp.ctx, hp.q_1, hp.k_1, hp.v_1)
+
+    for _ in range(2):
+        step()
+        cache.evict_last(1)
+    g = DecodeStepGraph(cache, step, evict_after=1)
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    by = float(sum(decode_bytes(counts_local, hp.ctx)))
+    return {"ms_per_token": ms, "achieved": by / (ms * 1e-3) / 1e9, "unit": "GB/s", "frac": by / (ms * 1e-3) / HBM_PEAK,
+            "what": "the decode step of the timed region as ONE captured HIP graph (duo_attn.graph.DecodeStepGraph, evict_last(1) "
+                    "inside): GPU-side cost, no host in the loop"}
+
+
 def cpu_baseline(counts, ctx, chunk, n_decode):
     """Oracle (torch CPU restatement of the reference semantics, fp32 math) timed on this host's
     cores on a bounded sample, scaled to the job by algorithmic work."""
@@ -1001,6 +1037,10 @@ def main():
                 "algorithmic_flops_per_launch": pre["flops"] / pre["launches"]}
         step_bytes = float(sum(decode_bytes(counts[lr[0]:lr[1]], args.ctx)))
         t_tok = t_dec / args.decode_tokens
+        try:
+            graph_dec = decode_graph_leg(hp, counts[lr[0]:lr[1]]) if world == 1 else None
+        except Exception as e:      # extra information: never at the price of the bench line
+            graph_dec = {"error": f"{type(e).__name__}: {e}"}
         roof_dec = {"kernel": "duo_decode_scan_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
                     "unit": "GB/s", "frac": td / HBM_PEAK,
                     "traffic": traffic.get("duo_decode_scan_kernel"), "traffic_source": traffic_source,
@@ -1009,7 +1049,8 @@ def main():
                     # the whole decode step of the timed job (per layer: scan with RoPE + append folded in, then the merge launch)
                     "whole_step": {"algorithmic_bytes_per_token": step_bytes, "ms_per_token": t_tok * 1e3,
                                    "achieved": step_bytes / t_tok / 1e9, "frac": step_bytes / t_tok / HBM_PEAK,
-                                   "launches_per_token": 2 * (lr[1] - lr[0])}}
+                                   "launches_per_token": 2 * (lr[1] - lr[0])},
+                    "captured_step": graph_dec}
     def all_ranks_sum(x):
         t = torch.tensor([float(x)], device=handoff, dtype=torch.float64)
         if world > 1:

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void duo_prefill_merge_kernel(const PrefillPar
     const int q = tile * QBLK + r;
     if (q >= P.S) return;
     bf16_t *op = P.out + (int64_t)blockIdx.y * P.o_bs + (int64_t)q * P.o_ts + (int64_t)qh * P.o_hs;
-    prefill_merge_row<F16, false>(P, ks, part0 * QBLK + r, op, jd);
+    prefill_merge_row<F16>(P, ks, part0 * QBLK + r, op, jd);
 }
 
 }  // namespace
@@ -92,7 +92,6 @@ namespace {
 struct PlanCost {
     double t_tile, t_fix, t_merge, t_part, t_pad;     // microseconds
     double c0;      // cost of a unit of work with (nearly) all CUs idle, relative to the full chip (tail of a launch)
-    double t_merge_in;      // what a split launch costs beyond its blocks when the last arrival of an item merges it in the kernel
 };
 static const PlanCost &plan_cost() {
     // defaults: fitted to same-box probes of this kernel (profiles/r6_prefill_plan.md); DUO_PREFILL_PLAN_COST overrides
@@ -101,17 +100,17 @@ static const PlanCost &plan_cost() {
         // tiles in the general (masked / run-boundary) form, epilogue; c0: fewer active CUs clock higher and share the fabric
         // with fewer others — a lone 1800-tile workgroup walks a tile in 1.2 us, 256 of them in 1.6
         // (fit over 280 timed launches, tools/prefill_plan_model.py fit: rms 3.7 %; t_merge = the merge launch incl. the
-        //  kernel boundary in front of it; t_merge_in = the in-kernel form: the last item's merge on one workgroup)
-        PlanCost v{1.62, 26.5, 41.0, 0.0, 1.0, 0.62, 15.0};
+        //  kernel boundary in front of it and the partial stores of the last round)
+        PlanCost v{1.62, 26.5, 41.0, 0.0, 1.0, 0.62};
         if (const char *e = getenv("DUO_PREFILL_PLAN_COST"))
-            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad, &v.c0, &v.t_merge_in);
+            sscanf(e, "%lf,%lf,%lf,%lf,%lf,%lf", &v.t_tile, &v.t_fix, &v.t_merge, &v.t_part, &v.t_pad, &v.c0);
         return v;
     }();
     return c;
 }
 
 struct PlanShape {
-    int32_t nkv[2], group, nq, S, lenA[2], lenB[2], max_parts, xmap1, inkernel;
+    int32_t nkv[2], group, nq, S, lenA[2], lenB[2], max_parts, xmap1;
     uint32_t force;
     bool operator==(const PlanShape &o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
 };
@@ -210,7 +209,7 @@ static double plan_replay(const PlanShape &K, int k0, int k1, bool xmap0, bool x
         end += (heap[i] - prev) * (C.c0 + (1.0 - C.c0) * a / kPrefillCUs);
         prev = heap[i];
     }
-    if (P.nparts > 0) end += (K.inkernel ? C.t_merge_in : C.t_merge) + C.t_part * P.nparts;
+    if (P.nparts > 0) end += C.t_merge + C.t_part * P.nparts;
     return end;
 }
 
@@ -305,7 +304,6 @@ extern "C" int32_t duo_debug_prefill_plan(const int32_t *shape, uint32_t force, 
     K.nq = (K.S + QBLK - 1) / QBLK;
     const bool xmap0 = shape[9] & 1, xmap1 = (shape[9] & 2) != 0;
     K.xmap1 = xmap1;
-    K.inkernel = 1;
     K.force = K.max_parts <= 0 ? 0x10000u : force;
     if (K.group <= 0 || K.S <= 0 || K.nkv[0] < 0 || K.nkv[1] < 0) return DUO_EINVAL;
     const PrefillPlan plan = plan_compute(K, xmap0);
@@ -326,27 +324,6 @@ extern "C" int32_t duo_debug_prefill_plan(const int32_t *shape, uint32_t force, 
 }
 
 extern "C" int64_t duo_attn_prefill_workspace_bytes(void) { return 2048 * kPrefillPartialBytes; }
-
-// Arrival counters of the in-kernel merge: owned by the library, one 64 KiB block per caller workspace (the workspace is what
-// two concurrent launches must not share, so its address is the right key), zero-filled once — every launch leaves its
-// counters zero.  NULL (-> the launch pair with duo_prefill_merge_kernel) while the stream is being captured and the block
-// does not exist yet, after 256 distinct workspaces, or when the allocation fails.
-constexpr int kPrefillTicketWords = 16384;
-static int32_t *prefill_tickets_for(void *workspace, hipStream_t st) {
-    static std::mutex mu;
-    static std::unordered_map<void *, int32_t *> blocks;
-    std::lock_guard<std::mutex> g(mu);
-    auto it = blocks.find(workspace);
-    if (it != blocks.end()) return it->second;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    if (blocks.size() >= 256) return nullptr;
-    int32_t *p = nullptr;
-    if (hipMalloc((void **)&p, kPrefillTicketWords * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (hipMemset(p, 0, kPrefillTicketWords * sizeof(int32_t)) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
-    blocks.emplace(workspace, p);
-    return p;
-}
 
 template <bool F16>
 static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_stride,
@@ -419,11 +396,6 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
     K.nq = P.n_qtiles;
     K.S = n_tokens;
     K.xmap1 = xmap1;
-    // in-kernel merge (the last arrival of a split item merges it: no second launch) — the 4-wave kernel only;
-    // DUO_PREFILL_INKERNEL_MERGE=0 / debug bit 20: the launch pair of rounds 1-5 (same-box A/B, tests of both forms)
-    static const bool want_inkernel = [] { const char *e = getenv("DUO_PREFILL_INKERNEL_MERGE"); return !e || atoi(e) != 0; }();
-    int32_t *tickets = (w64_ok && want_inkernel && workspace && !(g_debug_flags & (1u << 20))) ? prefill_tickets_for(workspace, st) : nullptr;
-    K.inkernel = tickets != nullptr;
     K.max_parts = workspace ? (int32_t)std::min<int64_t>(workspace_bytes / n_batch / kPrefillPartialBytes, 1 << 20) : 0;   // every batch row has its own partials
     {
         static const int forced0 = [] { const char *e = getenv("DUO_PREFILL_KSPLIT"); return e ? atoi(e) : 0; }();    // tuning / test knobs: force a split count
@@ -457,11 +429,6 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         P.ws_ml = P.ws_o + (int64_t)n_batch * P.nparts * QBLK * DUO_HEAD_DIM;
     }
     const int n_merge0 = P.ks[0] > 1 ? K.nkv[0] * group * K.nq : 0, n_merge1 = P.ks[1] > 1 ? K.nkv[1] * group * K.nq : 0;
-    P.tbase[0] = 0;
-    P.tbase[1] = n_merge0;
-    P.n_tickets = n_merge0 + n_merge1;
-    if ((int64_t)P.n_tickets * n_batch > kPrefillTicketWords) tickets = nullptr;     // (plan costed for the other form: still correct)
-    P.tickets = P.n_tickets > 0 ? tickets : nullptr;
 
     if (w64_ok) {
         // (with the generated bulk schedule it wins on every launch shape, first chunks and streaming-only launches
@@ -476,13 +443,12 @@ static int prefill_impl(const void *q, int64_t q_token_stride, int64_t q_head_st
         if constexpr (F16) hipLaunchKernelGGL(duo_prefill_w64_f16_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
         else hipLaunchKernelGGL(duo_prefill_w64_kernel, dim3(nblk, n_batch), dim3(256), LDS_BYTES, st, P);
         DUO_HIP_CHECK_LAUNCH();
-        if (n_merge0 + n_merge1 > 0 && P.tickets == nullptr) {
+        if (n_merge0 + n_merge1 > 0) {
             hipLaunchKernelGGL((duo_prefill_merge_kernel<F16>), dim3(8 * (n_merge0 + n_merge1), n_batch), dim3(256), 0, st, P, n_merge0);
             DUO_HIP_CHECK_LAUNCH();
         }
         return 0;
     }
-    P.tickets = nullptr;        // (the 8-wave debug kernel writes plain partials: always the launch pair)
     {       // debug / cross-check paths: the 8-wave x 32-row kernel (duo_prefill_w32_debug.hip)
         const int rc = duo_prefill_w32_launch(&P, tr, F16, nblk, n_batch, dev, st);
         if (rc) return rc;

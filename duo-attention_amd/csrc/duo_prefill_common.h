@@ -37,13 +37,6 @@ struct PrefillParams {
     int32_t nparts;        // partials per batch row
     float *ws_o;     // [partial][256 rows][128] fp32
     float *ws_ml;    // [partial][256 rows][2]   (row max in score units, row sum)
-    // In-kernel merge (round 6): one arrival counter per split item (class 0's items first, then class 1's; one set per batch
-    // row).  The pieces of an item publish their partials write-through, drain, and take a ticket; the LAST arrival merges
-    // the item and writes `out` — no second launch.  All zero on entry, all zero again on exit.  NULL: partials are merged
-    // by duo_prefill_merge_kernel (the launch pair of rounds 1-5; debug / A-B).
-    int32_t *tickets;
-    int32_t tbase[2];      // first counter of class c
-    int32_t n_tickets;     // counters per batch row
     // XCD-aware block order of class c (4-wave kernel; see prefill_map_block): q-tile rows per period and workgroups per
     // XCD per period; xmap_q[c] == 0: plain q-tile-major order
     int32_t xmap_rows[2], xmap_q[2];
@@ -139,42 +132,18 @@ __device__ __forceinline__ f32x16 mfma32x32x16(const bf16x8 &a, const bf16x8 &b,
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// Partials handed to ANOTHER workgroup of the same launch (in-kernel merge): write-through stores and loads that are served
-// by memory, never by an XCD's possibly stale L2 (MI355X inter-workgroup hand-off, the form the single-launch decode step
-// uses: no release fence = no L2 write-back per workgroup; the consumer needs no acquire fence either).
-__device__ __forceinline__ void st16_wt(float *p, const f32x4 &v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void st8_wt(float *p, float a, float b) {
-    const f32x2 v = {a, b};
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4 ld16_sc1(const float *p) {     // (asm load: the caller waits — s_waitcnt vmcnt — before use)
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ f32x2 ld8_sc1(const float *p) {
-    f32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 // One output row slice of a split item: combine its ks partials — out = sum_s 2^((m_s - M) c) O_s / sum_s 2^((m_s - M) c) l_s.
-// row0: index of the row in piece 0's partial (piece s: + s * QBLK rows); jd: which group of 16 dims.  SC1: the partials were
-// published by other workgroups of THIS launch (see st16_wt): sc1 loads with explicit waits; otherwise plain loads.
+// row0: index of the row in piece 0's partial (piece s: + s * QBLK rows); jd: which group of 16 dims.
 // Every piece's (m, l) is requested up front, the accumulator rows follow four pieces at a time.
-template <bool F16, bool SC1>
+template <bool F16>
 __device__ __forceinline__ void prefill_merge_row(const PrefillParams &P, int ks, int64_t row0, bf16_t *op, int jd) {
     constexpr int KMAX = 16;
     f32x2 ml[KMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) {
         const float *mp = P.ws_ml + (row0 + (int64_t)(s < ks ? s : 0) * QBLK) * 2;
-        if constexpr (SC1) ml[s] = ld8_sc1(mp);
-        else ml[s] = *reinterpret_cast<const f32x2 *>(mp);
+        ml[s] = *reinterpret_cast<const f32x2 *>(mp);
     }
-    if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float M = -INFINITY;
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) M = fmaxf(M, s < ks ? ml[s].x : -INFINITY);
@@ -200,12 +169,8 @@ __device__ __forceinline__ void prefill_merge_row(const PrefillParams &P, int ks
             const int s = s0 + u < ks ? s0 + u : s0;       // past the end: re-read a valid piece with weight 0
             const float *src = src0 + (int64_t)s * QBLK * DUO_HEAD_DIM;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if constexpr (SC1) v[u][i] = ld16_sc1(src + 4 * i);
-                else v[u][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + i);
-            }
+            for (int i = 0; i < 4; ++i) v[u][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(src) + i);
         }
-        if constexpr (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float wu = s0 + u < ks ? w[s0 + u] : 0.f;

@@ -696,24 +696,37 @@ def _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, st
     return a
 
 
-# The single-launch step (duo_decode_step_bf16) is bit-identical to the two-launch form but measured 2-3 % SLOWER per
-# decode step on MI355X (profiles/r2_decode_one_launch.md): publishing partials to other workgroups of the same
-# launch costs more than the kernel boundary it removes.  Two launches stay the default; DUO_DECODE_ONE_LAUNCH=1
-# (or two_launch=False) selects the single launch.
-_TWO_LAUNCH_DEFAULT = os.environ.get("DUO_DECODE_ONE_LAUNCH", "0") != "1"
+# The single-launch step (duo_decode_step_bf16) is bit-identical to the two-launch form.  Which one is faster depends on the
+# context (round 6, GPU-side time of the 32-layer step as a captured graph, profiles/r6_decode_short.md): at <= 16K cached
+# rows a layer's scan is 10 us and the second launch with the kernel boundary in front of it is a fifth of the step — ONE
+# launch is 10-18 % faster (0.41 vs 0.49 ms/token at 4K, 0.50 vs 0.55 at 16K) and saves a launch on the host-bound eager loop
+# as well; at 32K they are equal; from 64K on publishing partials to other workgroups of the same launch costs more than the
+# boundary it removes (round 2: +1.3 us per layer at 128K, profiles/r2_decode_one_launch.md).  So the form follows the length:
+# one launch up to ONE_LAUNCH_MAX_ROWS cached rows — a bucket boundary of the split-KV planner, so a captured step and the
+# eager step of the same length always agree on the form — two above.  DUO_DECODE_ONE_LAUNCH=1 / 0 forces one / two.
+ONE_LAUNCH_MAX_ROWS = 16384
+_ONE_LAUNCH_ENV = os.environ.get("DUO_DECODE_ONE_LAUNCH")
+
+
+def _two_launch(full_len: int, str_len: int, two_launch) -> bool:
+    if two_launch is not None:
+        return bool(two_launch)
+    if _ONE_LAUNCH_ENV in ("0", "1"):
+        return _ONE_LAUNCH_ENV == "0"
+    return max(int(full_len), int(str_len)) + 1 > ONE_LAUNCH_MAX_ROWS
 
 
 def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
-                 rope_scale, rope_theta, scale, two_launch: bool = _TWO_LAUNCH_DEFAULT) -> int:
-    """Fused decode step of one layer (one batch row): scan + epilogue launch pair (default), or everything in
-    ONE launch (``two_launch=False``, see the note above).  q/out [Hq, D]; k/v [Hkv, D] new rows; full_k/full_v [T, nf, D]
+                 rope_scale, rope_theta, scale, two_launch: Optional[bool] = None) -> int:
+    """Fused decode step of one layer (one batch row): scan + epilogue launch pair, or everything in ONE launch
+    (``two_launch``: None = by context length, see the note above).  q/out [Hq, D]; k/v [Hkv, D] new rows; full_k/full_v [T, nf, D]
     and str_k/str_v [W, ns, D] pool views.  Returns the new streaming length."""
     lib = load_library()
     a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, str_len, sink, recent, pos,
                            rope_scale, rope_theta, scale)
     ws = decode_workspace(q.device, q.shape[0])
     new_len = c_int32(0)
-    if two_launch:
+    if _two_launch(full_len, str_len, two_launch):
         _check(lib.duo_decode_layer_bf16(byref(a), byref(new_len), ws.data_ptr(), ws.numel() * 4, _stream_ptr()),
                "duo_decode_layer_bf16")
     else:
@@ -726,7 +739,7 @@ def decode_layer(q, k, v, out, n_full, full_k, full_v, full_len, str_k, str_v, s
 
 def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink, recent,
                      plan_pos, rope_scale, rope_theta, scale, dev_state: torch.Tensor,
-                     two_launch: bool = _TWO_LAUNCH_DEFAULT) -> None:
+                     two_launch: Optional[bool] = None) -> None:
     """The same step with lengths / position read from ``dev_state`` (int32 [4] on the GPU:
     full_len, str_len, pos, pad) — graph-capturable; the ``plan_*`` values only size the grid."""
     lib = load_library()
@@ -734,7 +747,7 @@ def decode_layer_dev(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k,
     a = _decode_layer_args(q, k, v, out, n_full, full_k, full_v, plan_full_len, str_k, str_v, plan_str_len, sink,
                            recent, plan_pos, rope_scale, rope_theta, scale)
     ws = decode_workspace(q.device, q.shape[0])
-    if two_launch:
+    if _two_launch(plan_full_len, plan_str_len, two_launch):
         _check(lib.duo_decode_layer_dev_bf16(byref(a), dev_state.data_ptr(), ws.data_ptr(), ws.numel() * 4,
                                              _stream_ptr()), "duo_decode_layer_dev_bf16")
     else:

@@ -195,6 +195,8 @@ def ensure_ranks(n_devices: int, what: str) -> None:
             rc = relaunch_under_torchrun(n_devices)
         except ValueError as e:
             raise RuntimeError(f"{what} = one process per GPU: {e}") from e
+        except SystemExit as e:        # (check_visible_gpus: fewer GPUs than devices asked for)
+            raise RuntimeError(f"{what} = one process per GPU: {e}") from None
         sys.exit(rc)
     world = int(os.environ["WORLD_SIZE"])
     if world != n_devices:

@@ -52,9 +52,7 @@
  *   reference has no captured step to keep consistent — here a captured launch equals the eager launch of its bucket).
  * ABI version 6 (round 6, two additions, no signature changed): + duo_debug_prefill_last_plan, duo_debug_prefill_plan; the prefill entry points choose
  *   key-range splits for BOTH head classes (up to 16 pieces) by replaying the launch on the chip's 256 CUs, and
- *   duo_attn_prefill_workspace_bytes() doubled (2048 partials); a split launch merges its partials inside the kernel (the last
- *   piece of a (q tile, q head) to arrive combines them; arrival counters are library-owned, keyed by the workspace address).
- *   Results of a launch may be split — summed — differently than by a v5 build; outputs stay inside the same bar.
+ *   duo_attn_prefill_workspace_bytes() doubled (2048 partials).  Results of a launch may be split — summed — differently than by a v5 build; outputs stay inside the same bar.
  *
  * Attention semantics (flash-attn 2.6.3 flash_attn_func, causal=True,
  * bottom-right aligned): a query at row i of the S new rows sees every key of
@@ -126,8 +124,7 @@ const char *duo_error_string(int code);
  *        invalid: the memory-side ceiling of the launch);
  * bit 7: bf16 prefill stays on the 8-wave x 32-row kernel (the 4-wave x 64-row kernel is the default where it
  *        applies);  bit 8: no key-range split of the prefill launch;  bits 12-15 / bits 16-19: force that many key-range
- *        splits of the retrieval / the streaming class (capped by the workspace and the tile count);  bit 20: split prefill
- *        launches merge their partials in a second launch (duo_prefill_merge_kernel) instead of in the kernel;  bit 9: decode scan on the long-prologue kernel
+ *        splits of the retrieval / the streaming class (capped by the workspace and the tile count);  bit 9: decode scan on the long-prologue kernel
  *        (duo_decode_split_kernel) instead of the short-prologue one;  bit 10: prefill in the plain q-tile-major block
  *        order instead of the XCD-aware one;  bit 11: INT4 decode on the dequantising kernel whatever `fused` asks for.
  *        Measurement / test aids only. */
