@@ -374,7 +374,7 @@ def test_forward_hooks_keep_firing(monkeypatch):
     # one layer ran module by module while hooked: logits within the projections' summation-order noise of the unhooked model
     want = _decode(ref_model, ref_kv, t, 6, False, monkeypatch, ids[:, 40:46]) + _decode(ref_model, ref_kv, t, 6, False, monkeypatch, ids[:, 44:50])
     for a, b in zip(got, want):
-        rel_close(a, b, 2e-2, "auto-graph: one hooked layer module by module vs the fused model, logits")
+        rel_close(a, b, 8e-3, "auto-graph: one hooked layer module by module vs the fused model, logits")     # (measured: 1.7e-3 ... 3.6e-3)
 
 
 def test_forward_hooks_fire_on_the_tuple_path_too():

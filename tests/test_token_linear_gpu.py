@@ -20,7 +20,9 @@ from helpers import rel_close
 from oracle.duo_oracle import rmsnorm_ref, token_linear_ref
 
 # model-level bars: about twice the measured figure (gpurun_out/model_rel.log)
-BAR_FUSED_VS_MODULES = 2e-2
+# measured (round 6): logits 2.6e-3 ... 2.8e-3, retrieval V rows <= 7.3e-4
+BAR_FUSED_VS_MODULES = 6e-3
+BAR_FUSED_V_ROWS = 2e-3
 BAR_ARGMAX_AGREE = 0.9
 
 pytestmark = pytest.mark.gpu
@@ -177,11 +179,13 @@ def test_fused_decode_layer_matches_module_by_module(family, bsz, eager_decode_s
     assert n_f == 10 * 3 * 4 and n_m == 0          # four token-linear launches per layer and step; none module by module
     rel_close(l_f, l_m, BAR_FUSED_VS_MODULES, "token-linear: fused decode layers vs module by module, logits")
     agree = (l_f.argmax(-1) == l_m.argmax(-1)).float().mean().item()
+    from helpers import PARITY_LOG
+    PARITY_LOG["model: token-linear: fused vs module by module, greedy-token agreement"] = {"agreement": agree, "bar": BAR_ARGMAX_AGREE}
     assert agree >= BAR_ARGMAX_AGREE, agree
     assert c_f.kv_seq_len == c_m.kv_seq_len == 90
     for l in range(3):
         a, b = c_f.full_value_states_list[l][:, :90].float(), c_m.full_value_states_list[l][:, :90].float()
-        rel_close(a, b, BAR_FUSED_VS_MODULES, f"token-linear: fused vs module by module, layer {l} retrieval V rows")
+        rel_close(a, b, BAR_FUSED_V_ROWS, f"token-linear: fused vs module by module, layer {l} retrieval V rows")
 
 
 @pytest.mark.parametrize("shape,pad", [((2, 300, 1024), 0), ((1, 16384, 14336), 0), ((5, 7, 72), 8), ((1, 1, 8), 0)])

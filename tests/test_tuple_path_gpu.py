@@ -19,8 +19,9 @@ import torch
 from helpers import attn_close, rel_close
 
 # model-level bars: about twice the measured figure (gpurun_out/model_rel.log)
-BAR_HIP_VS_HF_CPU = 2e-2
-BAR_BATCH_VS_SOLO = 2e-2
+# measured (round 6): HIP logits vs HF eager on the CPU 5.1e-3 ... 7.0e-3 per chunk; batch rows vs solo bit-equal (0.0)
+BAR_HIP_VS_HF_CPU = 1.4e-2
+BAR_BATCH_VS_SOLO = 1e-5
 from oracle.duo_oracle import OracleBackend, flash_attn_func_ref, tuple_forward_ref
 from test_golden_and_model_gpu import _rel, tiny
 from test_oracle_golden import _hf_cos_sin, bf16, load, split_hidden
