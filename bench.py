@@ -95,8 +95,15 @@ class HotPath:
     def __init__(self, counts, layer_range, ctx, chunk, device):
         from duo_attn.patch.static_kv_cache import DuoAttentionStaticKVCache
 
-        self.l0, self.l1 = layer_range
-        self.counts = counts[self.l0:self.l1]
+        # layer_range: (first, last) — one contiguous block — or a list of blocks [(first, last), ...]: the layers of
+        # the rank's virtual stages (--virtual-stages 2), run one block per pass
+        blocks = [tuple(layer_range)] if isinstance(layer_range[0], int) else [tuple(b) for b in layer_range]
+        self.l0, self.l1 = blocks[0][0], blocks[-1][1]
+        self.counts = [c for lo, hi in blocks for c in counts[lo:hi]]
+        self.pass_layers, n0 = [], 0
+        for lo, hi in blocks:
+            self.pass_layers.append(range(n0, n0 + hi - lo))
+            n0 += hi - lo
         self.ctx, self.chunk, self.device = ctx, chunk, device
         heads = [[1.0] * nf + [0.0] * (HKV - nf) for nf in self.counts]
         self.cache = DuoAttentionStaticKVCache(_ShapeModel(len(self.counts), device), heads, 1, ctx + 5,
@@ -127,26 +134,30 @@ class HotPath:
         self.block_rows = rows
         self.blocks = [(ci, r0, min(rows, c - r0)) for ci, (_, c) in enumerate(self.chunks) for r0 in range(0, c, rows)]
 
-    def prefill_block_stage(self, i, x):
+    def _layers(self, ps):
+        return range(len(self.counts)) if ps is None else self.pass_layers[ps]
+
+    def prefill_block_stage(self, i, x, ps=None):
         from duo_attn.patch._duo import duo_static_attention_row_block
 
         ci, r0, n = self.blocks[i]
         c = self.chunks[ci][1]
-        for li in range(len(self.counts)):
+        for li in self._layers(ps):
             duo_static_attention_row_block(self.q_c[:, r0:r0 + n], self.k_c[:, r0:r0 + n], self.v_c[:, r0:r0 + n],
                                            self.cache, li, r0, c, ROPE_SCALE, ROPE_THETA)
         return x if x is not None else self.hidden_c[:, :n]
 
-    def prefill_stage(self, i, x):
+    def prefill_stage(self, i, x, ps=None):
         s, c = self.chunks[i]
-        for li in range(len(self.counts)):
+        for li in self._layers(ps):
             self.layer_core(li, c, s, self.q_c, self.k_c, self.v_c)
         return x if x is not None else self.hidden_c[:, :c]
 
-    def decode_stage(self, i, x):
-        for li in range(len(self.counts)):
+    def decode_stage(self, i, x, ps=None):
+        for li in self._layers(ps):
             self.layer_core(li, 1, self.ctx, self.q_1, self.k_1, self.v_1)
-        self.cache.evict_last(1)   # reference benchmark_static.py:104
+        if ps is None or ps == len(self.pass_layers) - 1:
+            self.cache.evict_last(1)   # reference benchmark_static.py:104 (once per token: behind the rank's last block)
         return x if x is not None else self.hidden_1
 
 
@@ -161,8 +172,9 @@ def run_job(hp: HotPath, pipe, n_decode, world, device, handoff=None):
     handoff = handoff or device
     blocked = getattr(hp, "blocks", None)
     pre_fn = hp.prefill_block_stage if blocked else hp.prefill_stage
-    pre = pre_fn if handoff == device else (lambda i, x: pre_fn(i, x).to(handoff))
-    dec = hp.decode_stage if handoff == device else (lambda i, x: hp.decode_stage(i, x).to(handoff))
+    # (one block per rank: stage_fn(i, x); two — InterleavedLayerPipeline — stage_fn(i, x, pass): *a carries the pass)
+    pre = pre_fn if handoff == device else (lambda i, x, *a: pre_fn(i, x, *a).to(handoff))
+    dec = hp.decode_stage if handoff == device else (lambda i, x, *a: hp.decode_stage(i, x, *a).to(handoff))
     hp.cache.clear()
     sync_all(world)
     t0 = time.perf_counter()
@@ -408,7 +420,7 @@ def measure_traffic(args):
 
 def traffic_probe(args, device):
     """child of measure_traffic: one prefill pass and a few decode steps, nothing timed"""
-    from duo_attn.pipeline import LayerPipeline
+    from duo_attn.pipeline import InterleavedLayerPipeline, LayerPipeline
 
     counts = PATTERNS[args.pattern][0][: args.layers]
     hp = HotPath(counts, (0, len(counts)), args.ctx, args.chunk, device)
@@ -908,6 +920,10 @@ def main():
     ap.add_argument("--row-block", type=int, default=-1,
                     help="N > 1: query rows per pipeline item (a chunk is handed through the stages in row blocks); "
                          "0 = whole chunks, -1 = automatic (4096 rows on up to 4 GPUs, 2048 on more)")
+    ap.add_argument("--virtual-stages", type=int, default=1, choices=[1, 2],
+                    help="N > 1: layer blocks per rank.  2 = duo_attn.pipeline.InterleavedLayerPipeline (rank r owns blocks r and "
+                         "N + r, an item goes round the ranks twice): better balance of the ragged layers, half the fill — "
+                         "gloo-tested, never run on RCCL, so opt-in")
     ap.add_argument("--no-full-baseline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
@@ -970,7 +986,7 @@ def main():
     if args.traffic_probe:
         return traffic_probe(args, device)
 
-    from duo_attn.pipeline import LayerPipeline
+    from duo_attn.pipeline import InterleavedLayerPipeline, LayerPipeline
 
     counts = PATTERNS[args.pattern][0][: args.layers]
     L = len(counts)
@@ -979,8 +995,14 @@ def main():
     # reference's even split lopsided: 6 vs 21 retrieval heads in the first/last 4-layer block)
     pf = prefill_flops(counts, args.ctx, args.chunk)
     layer_cost = [sum(row[l] for row in pf) for l in range(L)]
-    pipe = LayerPipeline(L, rank=rank, world_size=world, layer_costs=layer_cost if world > 1 else None)
-    lr = (pipe.first_layer, pipe.last_layer)
+    if args.virtual_stages == 2 and world > 1:
+        pipe = InterleavedLayerPipeline(L, rank=rank, world_size=world, layer_costs=layer_cost)
+        lr_blocks = list(pipe.blocks)
+    else:
+        pipe = LayerPipeline(L, rank=rank, world_size=world, layer_costs=layer_cost if world > 1 else None)
+        lr_blocks = [(pipe.first_layer, pipe.last_layer)]
+    lr = (lr_blocks[0][0], lr_blocks[-1][1])            # (reporting only when there are two blocks)
+    local_counts = [c for lo, hi in lr_blocks for c in counts[lo:hi]]
     n_tok = args.ctx + args.decode_tokens
 
     def timed(hp, steps, warmup):
@@ -1003,8 +1025,8 @@ def main():
         timed.last_jobs = each.tolist()
         return (t / steps).tolist()
 
-    hp = HotPath(counts, lr, args.ctx, args.chunk, device)
-    hp_counts_cost = sum(layer_cost[lr[0]:lr[1]])
+    hp = HotPath(counts, lr_blocks if len(lr_blocks) > 1 else lr, args.ctx, args.chunk, device)
+    hp_counts_cost = sum(sum(layer_cost[lo:hi]) for lo, hi in lr_blocks)
     # (DUO_BENCH_FORCE_BLOCKS=1: row blocks on one GPU too — measures what the finer launches cost)
     if args.row_block < 0:
         # finer blocks fill the pipeline sooner but run the kernels at smaller launches (one GPU, whole job:
@@ -1027,7 +1049,7 @@ def main():
         traffic, traffic_source = measure_traffic(args)
     roof = roof_dec = None
     if not args.no_kernel_roofline:
-        pre, dec = kernel_rooflines(hp, counts[lr[0]:lr[1]])
+        pre, dec = kernel_rooflines(hp, local_counts)
         tp, td = pre["flops"] / pre["seconds"], dec["bytes"] / dec["seconds"]
         roof = {"kernel": "duo_prefill_w64_kernel (4 waves x 64 rows: every prefill launch, whole chunks, key-range-split launches and row blocks alike)",
                 "bound": "mfma", "achieved": tp / 1e12, "peak": MFMA_BF16_PEAK / 1e12,
@@ -1035,10 +1057,10 @@ def main():
                 "traffic": traffic.get("duo_prefill"), "traffic_source": traffic_source,
                 "avg_launch_ms": pre["seconds"] / pre["launches"] * 1e3, "launches": pre["launches"],
                 "algorithmic_flops_per_launch": pre["flops"] / pre["launches"]}
-        step_bytes = float(sum(decode_bytes(counts[lr[0]:lr[1]], args.ctx)))
+        step_bytes = float(sum(decode_bytes(local_counts, args.ctx)))
         t_tok = t_dec / args.decode_tokens
         try:
-            graph_dec = decode_graph_leg(hp, counts[lr[0]:lr[1]]) if world == 1 else None
+            graph_dec = decode_graph_leg(hp, local_counts) if world == 1 else None
         except Exception as e:      # extra information: never at the price of the bench line
             graph_dec = {"error": f"{type(e).__name__}: {e}"}
         roof_dec = {"kernel": "duo_decode_scan_kernel", "bound": "hbm", "achieved": td / 1e9, "peak": HBM_PEAK / 1e9,
@@ -1049,7 +1071,7 @@ def main():
                     # the whole decode step of the timed job (per layer: scan with RoPE + append folded in, then the merge launch)
                     "whole_step": {"algorithmic_bytes_per_token": step_bytes, "ms_per_token": t_tok * 1e3,
                                    "achieved": step_bytes / t_tok / 1e9, "frac": step_bytes / t_tok / HBM_PEAK,
-                                   "launches_per_token": 2 * (lr[1] - lr[0])},
+                                   "launches_per_token": 2 * len(local_counts)},
                     "captured_step": graph_dec}
     def all_ranks_sum(x):
         t = torch.tensor([float(x)], device=handoff, dtype=torch.float64)
@@ -1062,7 +1084,7 @@ def main():
 
     full = None
     if not args.no_full_baseline:
-        hpf = HotPath([HKV] * L, lr, args.ctx, args.chunk, device)
+        hpf = HotPath([HKV] * L, lr_blocks if len(lr_blocks) > 1 else lr, args.ctx, args.chunk, device)
         if use_blocks:
             hpf.set_row_blocks(args.row_block)
         # same protocol as the duo job (warm-up, then timed jobs): the denominator of both speed-ups
@@ -1116,8 +1138,9 @@ def main():
             mlevel = {"error": f"{type(e).__name__}: {e}"}
     # per-rank view of the pipeline (N > 1): stage boundaries, this rank's own prefill / decode seconds per job,
     # bytes handed to the next stage per job
-    mine = torch.tensor([lr[0], lr[1], sum(j[0] for j in duo_local) / len(duo_local), sum(j[1] for j in duo_local) / len(duo_local),
-                         float(hp_counts_cost)], device=handoff, dtype=torch.float64)
+    b2 = lr_blocks[1] if len(lr_blocks) > 1 else (-1, -1)
+    mine = torch.tensor([lr_blocks[0][0], lr_blocks[0][1], sum(j[0] for j in duo_local) / len(duo_local), sum(j[1] for j in duo_local) / len(duo_local),
+                         float(hp_counts_cost), b2[0], b2[1]], device=handoff, dtype=torch.float64)
     per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
         dist.all_gather(per_rank, mine)
@@ -1146,8 +1169,9 @@ def main():
                 "seq_len": args.ctx,
                 "prefill_chunk": args.chunk,
                 "decode_tokens": args.decode_tokens,
-                "parallelism": (f"layer-pipeline pp{world}, {args.row_block}-row wavefront" if use_blocks
-                                else f"layer-pipeline pp{world}") if world > 1 else "single GPU",
+                "parallelism": ((f"layer-pipeline pp{world}, {args.row_block}-row wavefront" if use_blocks
+                                 else f"layer-pipeline pp{world}") + (", two layer blocks per rank" if args.virtual_stages == 2 else ""))
+                               if world > 1 else "single GPU",
             },
             "prefill_tok_s": args.ctx / t_pre,
             "decode_tok_s": args.decode_tokens / t_dec,
@@ -1175,7 +1199,9 @@ def main():
             "pipeline": None if world == 1 else {
                 "backend": dist.get_backend(), "world_size": dist.get_world_size(),
                 "handoff_bytes_per_job": (args.ctx + args.decode_tokens) * HIDDEN * 2 if world > 1 else 0,
-                "stages": [{"rank": r, "layers": [int(t[0]), int(t[1])], "prefill_s": float(t[2]), "decode_s": float(t[3]),
+                "virtual_stages": args.virtual_stages if world > 1 else 1,
+                "stages": [{"rank": r, "layers": [int(t[0]), int(t[1])], **({"second_block": [int(t[5]), int(t[6])]} if t[5] >= 0 else {}),
+                            "prefill_s": float(t[2]), "decode_s": float(t[3]),
                             "share_of_prefill_flops": float(t[4]) / sum(layer_cost)} for r, t in enumerate(per_rank)],
             },
         }

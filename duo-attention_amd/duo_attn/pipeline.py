@@ -185,6 +185,199 @@ class LayerPipeline:
 
 
 # =============================================================================
+# two layer blocks per rank (virtual stages)
+# =============================================================================
+def interleaved_layer_split(costs: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
+    """2 * world_size contiguous layer blocks; rank r owns blocks r and world_size + r.  Returns the 2 * world_size
+    ``(first, last)`` pairs, chosen to minimise the heaviest RANK (the cost of its two blocks together).
+
+    Why: 32 ragged layers cut into 8 contiguous pieces leave the idlest stage of the prefill pipeline 0.61 busy
+    (profiles/r5_scaling_model.md); with two smaller blocks per rank there are 15 cuts to place instead of 7 and a heavy
+    block can be paired with a light one.  Start from the bottleneck-minimising split into 2 * world_size blocks, then move
+    single cuts while the heaviest rank gets lighter (32 layers: a few hundred evaluations)."""
+    n, P = len(costs), int(world_size)
+    if 2 * P > n:
+        raise ValueError(f"{2 * P} blocks for {n} layers")
+    pre = [0.0]
+    for c in costs:
+        pre.append(pre[-1] + float(c))
+
+    def rank_loads(cuts):
+        b = [0] + cuts + [n]
+        blk = [pre[b[i + 1]] - pre[b[i]] for i in range(2 * P)]
+        return [blk[r] + blk[P + r] for r in range(P)]
+
+    # objective: the ranks' loads sorted heaviest first, compared lexicographically (so a move that leaves the heaviest rank
+    # alone but lightens the second heaviest is progress too — plain "max" search stalls on such plateaus); moves: one cut by
+    # one or two layers, or two cuts at once; several starting points
+    def key(cuts):
+        return tuple(sorted(rank_loads(cuts), reverse=True))
+
+    def climb(cuts):
+        best = key(cuts)
+        improved = True
+        while improved:
+            improved = False
+            m = len(cuts)
+            moves = [((i, d),) for i in range(m) for d in (-2, -1, 1, 2)]
+            moves += [((i, d), (j, e)) for i in range(m) for j in range(i + 1, m) for d in (-1, 1) for e in (-1, 1)]
+            for mv in moves:
+                trial = list(cuts)
+                for i, d in mv:
+                    trial[i] += d
+                bb = [0] + trial + [n]
+                if any(bb[t + 1] <= bb[t] for t in range(len(bb) - 1)):
+                    continue
+                k = key(trial)
+                if k < best:
+                    cuts, best, improved = trial, k, True
+                    break
+        return cuts, best
+
+    starts = [[hi for _, hi in balanced_layer_split(costs, 2 * P)][:-1], [hi for _, hi in even_layer_split(n, 2 * P)][:-1]]
+    # (two balanced halves: each half of the model cut into P blocks by itself, for every half-way point)
+    for h in range(P, n - P + 1):
+        a = [hi for _, hi in balanced_layer_split(costs[:h], P)]
+        bq = [h + hi for _, hi in balanced_layer_split(costs[h:], P)][:-1]
+        starts.append(a + bq)
+    cuts, best = None, None
+    for st in starts:
+        c, k = climb(st)
+        if best is None or k < best:
+            cuts, best = c, k
+    b = [0] + cuts + [n]
+    return [(b[i], b[i + 1]) for i in range(2 * P)]
+
+
+class InterleavedLayerPipeline:
+    """The layer pipeline with TWO layer blocks per rank: an item passes rank 0, 1, ..., P-1 (blocks 0 ... P-1), returns to
+    rank 0 and passes them all again (blocks P ... 2P-1).  Reference: the same contiguous layer sharding
+    (``duo_attn/utils.py:251-271``), cut finer; this form exists for balance and fill, it changes no arithmetic.
+
+    Schedule (every rank the same, so every link carries ONE ordered stream): items in groups of P; for each group first
+    pass 0 of its P items, then pass 1 of the same items.  Rank r is busy from tick r on with no gaps (pass 1 of item i
+    arrives exactly when pass 0 of the group is done), so the fill is r HALF-size units instead of r whole stages, and a
+    layer block still sees its items in order (its KV pools are appended in order).  An autoregressive stream (batch-1
+    decode, ``token_feedback``) is groups of one: pass 0, pass 1, token back to rank 0.
+
+    Hand-off discipline = ``LayerPipeline.run``'s: every point-to-point operation goes through ``batch_isend_irecv``; the send
+    of a unit and the receive of the NEXT unit are one batch (so neither queues behind the other on the in-order
+    communicator), never earlier — on rank 0 a receive from rank P-1 posted before the sends it depends on would stop the
+    ring.  Checked like the one-block pipeline: gloo runs equal to one process, ``helpers.P2PAudit`` replayed on an
+    in-order communicator in both initialisation modes.  Never run on RCCL (no multi-GPU node): opt-in
+    (``bench.py --virtual-stages 2``)."""
+
+    def __init__(self, num_layers: int, rank: Optional[int] = None, world_size: Optional[int] = None, group=None,
+                 layer_costs: Optional[Sequence[float]] = None):
+        self.group = group
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world_size = dist.get_world_size(group) if world_size is None else world_size
+        costs = list(layer_costs) if layer_costs is not None else [1.0] * num_layers
+        if len(costs) != num_layers:
+            raise ValueError("layer_costs must have one entry per layer")
+        self.bounds: List[Tuple[int, int]] = interleaved_layer_split(costs, self.world_size)
+        self.blocks = (self.bounds[self.rank], self.bounds[self.world_size + self.rank])      # (pass 0, pass 1)
+
+    def peer(self, stage: int) -> int:
+        return dist.get_global_rank(self.group, stage) if self.group is not None else stage
+
+    @property
+    def is_first(self):
+        return self.rank == 0
+
+    @property
+    def is_last(self):
+        return self.rank == self.world_size - 1
+
+    def layers(self, pass_idx: int):
+        lo, hi = self.blocks[pass_idx]
+        return range(lo, hi)
+
+    def units(self, n: int, group_size: int):
+        """this rank's work in order: (item, pass) — groups of ``group_size`` items, pass 0 of a group, then its pass 1"""
+        out = []
+        for g0 in range(0, n, group_size):
+            items = range(g0, min(n, g0 + group_size))
+            out += [(i, 0) for i in items] + [(i, 1) for i in items]
+        return out
+
+    def run(self, shapes: Sequence[Tuple[int, ...]], stage_fn: Callable[[int, Optional[torch.Tensor], int], torch.Tensor],
+            device, dtype=torch.bfloat16, token_feedback: Optional[Callable[[int, Optional[torch.Tensor]], torch.Tensor]] = None,
+            ) -> List[Optional[torch.Tensor]]:
+        """``stage_fn(i, x, pass_idx)``: item i through this rank's block of that pass; ``x`` is None for pass 0 on rank 0
+        (which owns the inputs).  Returns the outputs of pass 1 on the LAST rank (a list of None elsewhere).
+        ``token_feedback``: as ``LayerPipeline.run`` — item i+1 enters rank 0 only after item i left the last rank."""
+        n, P = len(shapes), self.world_size
+        if P == 1:
+            outs = []
+            for i in range(n):
+                outs.append(stage_fn(i, stage_fn(i, None, 0), 1))
+                if token_feedback is not None and i + 1 < n:
+                    token_feedback(i + 1, token_feedback(i, outs[-1]))
+            return outs
+        feedback = token_feedback is not None
+        seq = self.units(n, 1 if feedback else P)
+        prev_rank, next_rank = self.peer((self.rank - 1) % P), self.peer((self.rank + 1) % P)
+        first_rank, last_rank = self.peer(0), self.peer(P - 1)
+        needs_recv = lambda u: not (self.is_first and u[1] == 0)
+        needs_send = lambda u: not (self.is_last and u[1] == 1)
+
+        def p2p(*ops):
+            return dist.batch_isend_irecv([dist.P2POp(fn, t, peer, group=self.group) for fn, t, peer in ops])
+
+        recv_buf, recv_work = {}, {}        # unit index -> buffer / request group
+        send_work = [None, None]
+        keep_alive = [None, None]
+        outs: List[Optional[torch.Tensor]] = [None] * n
+
+        def recv_op(k):
+            recv_buf[k] = torch.empty(shapes[seq[k][0]], device=device, dtype=dtype)
+            return (dist.irecv, recv_buf[k], prev_rank)
+
+        if needs_recv(seq[0]):
+            recv_work[0] = _WorkGroup(p2p(recv_op(0)))
+        for k, (i, ps) in enumerate(seq):
+            if feedback and self.is_first and ps == 0 and i > 0:
+                tok = torch.empty(shapes[i][0], 1, device=device, dtype=torch.int64)
+                _WorkGroup(p2p((dist.irecv, tok, last_rank))).wait()
+                token_feedback(i, tok)
+            x = None
+            if needs_recv(seq[k]):
+                recv_work.pop(k).wait()
+                x = recv_buf.pop(k)
+            y = stage_fn(i, x, ps)
+            nxt = k + 1 if k + 1 < len(seq) and needs_recv(seq[k + 1]) else None
+            if not needs_send(seq[k]):
+                outs[i] = y
+                if feedback and i + 1 < n:
+                    tok_out = token_feedback(i, y).contiguous()
+                    _WorkGroup(p2p((dist.isend, tok_out, first_rank))).wait()
+                if nxt is not None:
+                    recv_work[nxt] = _WorkGroup(p2p(recv_op(nxt)))
+                continue
+            slot = k & 1
+            if send_work[slot] is not None:
+                send_work[slot].wait()          # the buffer of the send two units back has left
+            keep_alive[slot] = y.contiguous()
+            if nxt is None or feedback:
+                # autoregressive stream: the next receive depends on THIS send (directly, or through the token the last
+                # rank sends back): issue it behind the send, never in front of it
+                send_work[slot] = _WorkGroup(p2p((dist.isend, keep_alive[slot], next_rank)))
+                if nxt is not None:
+                    recv_work[nxt] = _WorkGroup(p2p(recv_op(nxt)))
+            else:
+                works = p2p((dist.isend, keep_alive[slot], next_rank), recv_op(nxt))
+                if len(works) == 2:
+                    send_work[slot], recv_work[nxt] = _WorkGroup(works[:1]), _WorkGroup(works[1:])
+                else:
+                    send_work[slot] = recv_work[nxt] = _WorkGroup(works)
+        for w in send_work:
+            if w is not None:
+                w.wait()
+        return outs
+
+
+# =============================================================================
 # model-level layer pipeline
 # =============================================================================
 class PPState:

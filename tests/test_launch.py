@@ -106,6 +106,27 @@ def test_plain_bench_gpus_2_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_gpus_2_with_two_layer_blocks_per_rank():
+    """`python bench.py --gpus 2 --virtual-stages 2` (shared-GPU rehearsal): rank r owns layer blocks r and 2 + r, every item goes
+    round the two ranks twice (duo_attn.pipeline.InterleavedLayerPipeline) — the N > 1 code path of the opt-in form end to
+    end on the HIP kernels, one JSON line, both blocks of every rank reported, every layer owned exactly once"""
+    r = _run_bench({"DUO_BENCH_DEBUG_SHARED_GPU": "1"}, "--gpus", "2", "--virtual-stages", "2", *SMALL)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1, r.stdout
+    line = json.loads(out[0])
+    pipe = line["pipeline"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and pipe["virtual_stages"] == 2
+    blocks = sorted([tuple(s["layers"]) for s in pipe["stages"]] + [tuple(s["second_block"]) for s in pipe["stages"]])
+    assert len(blocks) == 4 and blocks[0][0] == 0 and blocks[-1][1] == 4 and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    # rank r owns the r-th and the (2 + r)-th block in layer order
+    for s in pipe["stages"]:
+        assert blocks.index(tuple(s["layers"])) == s["rank"] and blocks.index(tuple(s["second_block"])) == 2 + s["rank"]
+    assert "two layer blocks per rank" in line["config"]["parallelism"]
+    assert abs(sum(s["share_of_prefill_flops"] for s in pipe["stages"]) - 1.0) < 1e-6
+
+
+@pytest.mark.gpu
 def test_plain_bench_gpus_2_on_one_gpu_is_a_clear_error():
     import torch
 
