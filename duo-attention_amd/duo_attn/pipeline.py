@@ -187,40 +187,70 @@ class LayerPipeline:
 # =============================================================================
 # two layer blocks per rank (virtual stages)
 # =============================================================================
-def interleaved_layer_split(costs: Sequence[float], world_size: int) -> List[Tuple[int, int]]:
-    """2 * world_size contiguous layer blocks; rank r owns blocks r and world_size + r.  Returns the 2 * world_size
-    ``(first, last)`` pairs, chosen to minimise the heaviest RANK (the cost of its two blocks together).
+def _interleaved_units(n: int, group_size: int):
+    """a rank's work in order: (item, pass) — groups of ``group_size`` items, pass 0 of a group, then its pass 1"""
+    out = []
+    for g0 in range(0, n, group_size):
+        items = range(g0, min(n, g0 + group_size))
+        out += [(i, 0) for i in items] + [(i, 1) for i in items]
+    return out
 
-    Why: 32 ragged layers cut into 8 contiguous pieces leave the idlest stage of the prefill pipeline 0.61 busy
-    (profiles/r5_scaling_model.md); with two smaller blocks per rank there are 15 cuts to place instead of 7 and a heavy
-    block can be paired with a light one.  Start from the bottleneck-minimising split into 2 * world_size blocks, then move
-    single cuts while the heaviest rank gets lighter (32 layers: a few hundred evaluations)."""
+
+def simulate_interleaved(block_costs: Sequence[float], world_size: int, group_size: int, n_items: int) -> float:
+    """makespan of ``n_items`` equal items through 2 * world_size blocks (rank r owns blocks r and world_size + r), every rank
+    working through ``_interleaved_units`` in order, a unit starting when its rank is free and its input exists (hand-off
+    time not counted) — the planning model ``interleaved_layer_split`` minimises, in units of ``block_costs``"""
+    P = world_size
+    seq = _interleaved_units(n_items, group_size)
+    done, free, pos = {}, [0.0] * P, [0] * P
+    progressed = True
+    while progressed:
+        progressed = False
+        for rk in range(P):
+            while pos[rk] < len(seq):
+                i, ps = seq[pos[rk]]
+                vs = ps * P + rk
+                if vs > 0 and (vs - 1, i) not in done:
+                    break
+                done[(vs, i)] = free[rk] = max(free[rk], done[(vs - 1, i)] if vs > 0 else 0.0) + block_costs[vs]
+                pos[rk] += 1
+                progressed = True
+    return done[(2 * P - 1, n_items - 1)]
+
+
+def interleaved_layer_split(costs: Sequence[float], world_size: int, group_sizes: Optional[Sequence[int]] = None,
+                            ) -> Tuple[List[Tuple[int, int]], int]:
+    """2 * world_size contiguous layer blocks, rank r owning blocks r and world_size + r, and the group size of the schedule:
+    ``(bounds, group_size)``, chosen to minimise the SIMULATED makespan of a stream of equal items (``simulate_interleaved``).
+
+    Why simulated: 32 ragged layers cut into 8 contiguous pieces leave the idlest stage 0.61 busy (profiles/
+    r5_scaling_model.md), and two blocks per rank give 15 cuts instead of 7 and let a heavy block be paired with a light one —
+    but balancing the ranks' LOADS alone (heaviest rank 4 % above the mean on 8 ranks) is not enough: every rank works
+    through the same fixed unit order, so blocks of very different size stall each other (a rank's pass 1 waits for the
+    item to come round), and the load-balanced split measured WORSE than one block per rank in the model.  The search —
+    single cuts by one or two layers, pairs of cuts, from several starting points, for group sizes P and 2P — is
+    deterministic (every rank computes the same answer) and a few seconds of host time at 32 layers / 8 ranks."""
     n, P = len(costs), int(world_size)
     if 2 * P > n:
         raise ValueError(f"{2 * P} blocks for {n} layers")
     pre = [0.0]
     for c in costs:
         pre.append(pre[-1] + float(c))
+    scale = pre[-1] if pre[-1] > 0 else 1.0
+    n_sim = 6 * P
 
-    def rank_loads(cuts):
+    def blocks_of(cuts):
         b = [0] + cuts + [n]
-        blk = [pre[b[i + 1]] - pre[b[i]] for i in range(2 * P)]
-        return [blk[r] + blk[P + r] for r in range(P)]
+        return [(pre[b[i + 1]] - pre[b[i]]) / scale for i in range(2 * P)]
 
-    # objective: the ranks' loads sorted heaviest first, compared lexicographically (so a move that leaves the heaviest rank
-    # alone but lightens the second heaviest is progress too — plain "max" search stalls on such plateaus); moves: one cut by
-    # one or two layers, or two cuts at once; several starting points
-    def key(cuts):
-        return tuple(sorted(rank_loads(cuts), reverse=True))
-
-    def climb(cuts):
-        best = key(cuts)
+    def climb(cuts, gs):
+        best = simulate_interleaved(blocks_of(cuts), P, gs, n_sim)
         improved = True
         while improved:
             improved = False
             m = len(cuts)
             moves = [((i, d),) for i in range(m) for d in (-2, -1, 1, 2)]
-            moves += [((i, d), (j, e)) for i in range(m) for j in range(i + 1, m) for d in (-1, 1) for e in (-1, 1)]
+            moves += [((i, d), (j, e)) for i in range(m) for j in range(i + 1, min(m, i + 4)) for d in (-1, 1) for e in (-1, 1)]
             for mv in moves:
                 trial = list(cuts)
                 for i, d in mv:
@@ -228,25 +258,24 @@ def interleaved_layer_split(costs: Sequence[float], world_size: int) -> List[Tup
                 bb = [0] + trial + [n]
                 if any(bb[t + 1] <= bb[t] for t in range(len(bb) - 1)):
                     continue
-                k = key(trial)
-                if k < best:
-                    cuts, best, improved = trial, k, True
+                v = simulate_interleaved(blocks_of(trial), P, gs, n_sim)
+                if v < best - 1e-12:
+                    cuts, best, improved = trial, v, True
                     break
         return cuts, best
 
     starts = [[hi for _, hi in balanced_layer_split(costs, 2 * P)][:-1], [hi for _, hi in even_layer_split(n, 2 * P)][:-1]]
-    # (two balanced halves: each half of the model cut into P blocks by itself, for every half-way point)
-    for h in range(P, n - P + 1):
-        a = [hi for _, hi in balanced_layer_split(costs[:h], P)]
-        bq = [h + hi for _, hi in balanced_layer_split(costs[h:], P)][:-1]
-        starts.append(a + bq)
-    cuts, best = None, None
-    for st in starts:
-        c, k = climb(st)
-        if best is None or k < best:
-            cuts, best = c, k
-    b = [0] + cuts + [n]
-    return [(b[i], b[i + 1]) for i in range(2 * P)]
+    h = next(i for i in range(1, n) if pre[i] >= pre[-1] / 2)      # two balanced halves around the half-way point
+    h = min(max(h, P), n - P)
+    starts.append([hi for _, hi in balanced_layer_split(costs[:h], P)] + [h + hi for _, hi in balanced_layer_split(costs[h:], P)][:-1])
+    best = None
+    for gs in (group_sizes or (P, 2 * P)):
+        for st in starts:
+            c, v = climb(list(st), gs)
+            if best is None or v < best[0] - 1e-12:
+                best = (v, c, gs)
+    b = [0] + best[1] + [n]
+    return [(b[i], b[i + 1]) for i in range(2 * P)], best[2]
 
 
 class InterleavedLayerPipeline:
@@ -254,10 +283,11 @@ class InterleavedLayerPipeline:
     rank 0 and passes them all again (blocks P ... 2P-1).  Reference: the same contiguous layer sharding
     (``duo_attn/utils.py:251-271``), cut finer; this form exists for balance and fill, it changes no arithmetic.
 
-    Schedule (every rank the same, so every link carries ONE ordered stream): items in groups of P; for each group first
-    pass 0 of its P items, then pass 1 of the same items.  Rank r is busy from tick r on with no gaps (pass 1 of item i
-    arrives exactly when pass 0 of the group is done), so the fill is r HALF-size units instead of r whole stages, and a
-    layer block still sees its items in order (its KV pools are appended in order).  An autoregressive stream (batch-1
+    Schedule (every rank the same, so every link carries ONE ordered stream): items in groups of ``group_size`` (P or 2P,
+    chosen with the split); for each group first pass 0 of its items, then pass 1 of the same items.  With equal blocks
+    rank r is busy from tick r on with no gaps (pass 1 of an item arrives exactly when pass 0 of its group is done), so the
+    fill is r HALF-size units instead of r whole stages; a layer block still sees its items in order (its KV pools are
+    appended in order).  An autoregressive stream (batch-1
     decode, ``token_feedback``) is groups of one: pass 0, pass 1, token back to rank 0.
 
     Hand-off discipline = ``LayerPipeline.run``'s: every point-to-point operation goes through ``batch_isend_irecv``; the send
@@ -268,14 +298,16 @@ class InterleavedLayerPipeline:
     (``bench.py --virtual-stages 2``)."""
 
     def __init__(self, num_layers: int, rank: Optional[int] = None, world_size: Optional[int] = None, group=None,
-                 layer_costs: Optional[Sequence[float]] = None):
+                 layer_costs: Optional[Sequence[float]] = None, group_size: Optional[int] = None):
+        """``group_size``: force the schedule's group size (a multiple of the ring length would be usual; any value >= 1 is
+        served, shorter-than-ring groups with bubbles); None = chosen with the split"""
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world_size = dist.get_world_size(group) if world_size is None else world_size
         costs = list(layer_costs) if layer_costs is not None else [1.0] * num_layers
         if len(costs) != num_layers:
             raise ValueError("layer_costs must have one entry per layer")
-        self.bounds: List[Tuple[int, int]] = interleaved_layer_split(costs, self.world_size)
+        self.bounds, self.group_size = interleaved_layer_split(costs, self.world_size, [int(group_size)] if group_size else None)
         self.blocks = (self.bounds[self.rank], self.bounds[self.world_size + self.rank])      # (pass 0, pass 1)
 
     def peer(self, stage: int) -> int:
@@ -294,12 +326,7 @@ class InterleavedLayerPipeline:
         return range(lo, hi)
 
     def units(self, n: int, group_size: int):
-        """this rank's work in order: (item, pass) — groups of ``group_size`` items, pass 0 of a group, then its pass 1"""
-        out = []
-        for g0 in range(0, n, group_size):
-            items = range(g0, min(n, g0 + group_size))
-            out += [(i, 0) for i in items] + [(i, 1) for i in items]
-        return out
+        return _interleaved_units(n, group_size)
 
     def run(self, shapes: Sequence[Tuple[int, ...]], stage_fn: Callable[[int, Optional[torch.Tensor], int], torch.Tensor],
             device, dtype=torch.bfloat16, token_feedback: Optional[Callable[[int, Optional[torch.Tensor]], torch.Tensor]] = None,
@@ -316,7 +343,7 @@ class InterleavedLayerPipeline:
                     token_feedback(i + 1, token_feedback(i, outs[-1]))
             return outs
         feedback = token_feedback is not None
-        seq = self.units(n, 1 if feedback else P)
+        seq = self.units(n, 1 if feedback else self.group_size)
         prev_rank, next_rank = self.peer((self.rank - 1) % P), self.peer((self.rank + 1) % P)
         first_rank, last_rank = self.peer(0), self.peer(P - 1)
         needs_recv = lambda u: not (self.is_first and u[1] == 0)
@@ -325,17 +352,50 @@ class InterleavedLayerPipeline:
         def p2p(*ops):
             return dist.batch_isend_irecv([dist.P2POp(fn, t, peer, group=self.group) for fn, t, peer in ops])
 
-        recv_buf, recv_work = {}, {}        # unit index -> buffer / request group
+        recv_buf, recv_work = {}, {}        # consuming unit (item, pass) -> buffer / request group
         send_work = [None, None]
         keep_alive = [None, None]
         outs: List[Optional[torch.Tensor]] = [None] * n
 
-        def recv_op(k):
-            recv_buf[k] = torch.empty(shapes[seq[k][0]], device=device, dtype=dtype)
-            return (dist.irecv, recv_buf[k], prev_rank)
+        # WHEN a receive is posted.  Every rank works through the same unit sequence, rank r one tick behind rank r-1, and a
+        # send completes only against the receive posted opposite it — so the receive for a message has to be in the batch
+        # this rank issues at the tick the ring-predecessor SENDS it, not at the tick this rank consumes it:
+        #   ranks 1 ... P-1: the predecessor (rank r-1) is at unit k+1 when this rank has done unit k, and what it sends then
+        #     is this rank's own unit k+1 — send(k) and recv(k+1) in one batch, as LayerPipeline.run;
+        #   rank 0: the predecessor is the LAST rank, P-1 ticks ahead on the ring — when rank 0 has done unit k, rank P-1
+        #     has done unit k+1-P; if that was pass 0 of item i, its output is rank 0's input for (i, 1), consumed up to
+        #     group_size - P units later (several buffers in flight when the groups are longer than the ring).
+        # Posting it later (with the unit that consumes it) stops the ring as soon as groups are longer than P: rank P-1
+        # blocks in a send nobody has posted a receive for, behind it every rank, and finally rank 0's own sends.
+        shift = P if self.is_first else 0
 
-        if needs_recv(seq[0]):
-            recv_work[0] = _WorkGroup(p2p(recv_op(0)))
+        def recv_for_tick(k):
+            """the receive that belongs in the batch issued after this rank's unit k (k = -1: before the first unit)"""
+            kp = k + 1 - shift
+            if not 0 <= kp < len(seq):
+                return None
+            i, ps = seq[kp]                              # the predecessor's unit of that tick
+            if self.is_first:
+                if ps == 1:                              # the last rank keeps pass 1's output: nothing comes
+                    return None
+                key = (i, 1)
+            else:
+                key = (i, ps)
+            if key in posted:                            # (a short last group: already asked for when it was needed, below)
+                return None
+            posted.add(key)
+            recv_buf[key] = torch.empty(shapes[i], device=device, dtype=dtype)
+            return key, (dist.irecv, recv_buf[key], prev_rank)
+
+        posted = set()
+
+        if not feedback:
+            r0 = recv_for_tick(-1)
+            if r0 is not None:
+                recv_work[r0[0]] = _WorkGroup(p2p(r0[1]))
+        elif needs_recv(seq[0]):
+            recv_buf[seq[0]] = torch.empty(shapes[seq[0][0]], device=device, dtype=dtype)
+            recv_work[seq[0]] = _WorkGroup(p2p((dist.irecv, recv_buf[seq[0]], prev_rank)))
         for k, (i, ps) in enumerate(seq):
             if feedback and self.is_first and ps == 0 and i > 0:
                 tok = torch.empty(shapes[i][0], 1, device=device, dtype=torch.int64)
@@ -343,34 +403,47 @@ class InterleavedLayerPipeline:
                 token_feedback(i, tok)
             x = None
             if needs_recv(seq[k]):
-                recv_work.pop(k).wait()
-                x = recv_buf.pop(k)
+                if seq[k] not in recv_work:
+                    # a last group shorter than the ring: the item has not come round yet when rank 0 reaches its pass 1
+                    # (a bubble the schedule cannot avoid) — ask for it now; the sender's tick has not come either
+                    posted.add(seq[k])
+                    recv_buf[seq[k]] = torch.empty(shapes[i], device=device, dtype=dtype)
+                    recv_work[seq[k]] = _WorkGroup(p2p((dist.irecv, recv_buf[seq[k]], prev_rank)))
+                recv_work.pop(seq[k]).wait()
+                x = recv_buf.pop(seq[k])
             y = stage_fn(i, x, ps)
-            nxt = k + 1 if k + 1 < len(seq) and needs_recv(seq[k + 1]) else None
+            if feedback:
+                # autoregressive stream (groups of one): the next receive depends on THIS send — directly, or through the
+                # token the last rank sends back — so it is issued behind the send, never in front of it
+                nxt = seq[k + 1] if k + 1 < len(seq) and needs_recv(seq[k + 1]) else None
+                rop = None
+                if nxt is not None:
+                    recv_buf[nxt] = torch.empty(shapes[nxt[0]], device=device, dtype=dtype)
+                    rop = (nxt, (dist.irecv, recv_buf[nxt], prev_rank))
+            else:
+                rop = recv_for_tick(k)
             if not needs_send(seq[k]):
                 outs[i] = y
                 if feedback and i + 1 < n:
                     tok_out = token_feedback(i, y).contiguous()
                     _WorkGroup(p2p((dist.isend, tok_out, first_rank))).wait()
-                if nxt is not None:
-                    recv_work[nxt] = _WorkGroup(p2p(recv_op(nxt)))
+                if rop is not None:
+                    recv_work[rop[0]] = _WorkGroup(p2p(rop[1]))
                 continue
             slot = k & 1
             if send_work[slot] is not None:
                 send_work[slot].wait()          # the buffer of the send two units back has left
             keep_alive[slot] = y.contiguous()
-            if nxt is None or feedback:
-                # autoregressive stream: the next receive depends on THIS send (directly, or through the token the last
-                # rank sends back): issue it behind the send, never in front of it
+            if rop is None or feedback:
                 send_work[slot] = _WorkGroup(p2p((dist.isend, keep_alive[slot], next_rank)))
-                if nxt is not None:
-                    recv_work[nxt] = _WorkGroup(p2p(recv_op(nxt)))
+                if rop is not None:
+                    recv_work[rop[0]] = _WorkGroup(p2p(rop[1]))
             else:
-                works = p2p((dist.isend, keep_alive[slot], next_rank), recv_op(nxt))
+                works = p2p((dist.isend, keep_alive[slot], next_rank), rop[1])
                 if len(works) == 2:
-                    send_work[slot], recv_work[nxt] = _WorkGroup(works[:1]), _WorkGroup(works[1:])
+                    send_work[slot], recv_work[rop[0]] = _WorkGroup(works[:1]), _WorkGroup(works[1:])
                 else:
-                    send_work[slot] = recv_work[nxt] = _WorkGroup(works)
+                    send_work[slot] = recv_work[rop[0]] = _WorkGroup(works)
         for w in send_work:
             if w is not None:
                 w.wait()

@@ -37,6 +37,50 @@ def block_flops(nf, s, r0, n):
     return G * (nf * full + (HKV - nf) * stream)
 
 
+def model_two_blocks(counts, ctx, chunk, world, rate, eff, link, hop, dec_fixed, dec_bw, n_decode):
+    """the same job with TWO layer blocks per rank (duo_attn.pipeline.InterleavedLayerPipeline, bench.py --virtual-stages 2):
+    rank r owns blocks r and world + r of ``interleaved_layer_split``; every rank works through (item, pass) units in groups
+    of `world` items — pass 0 of a group, then its pass 1 — a unit starting when the rank is free AND its input has arrived"""
+    from duo_attn.pipeline import interleaved_layer_split
+
+    import bench
+
+    pf = bench.prefill_flops(counts, ctx, chunk)
+    layer_cost = [sum(row[l] for row in pf) for l in range(len(counts))]
+    bounds, gs = interleaved_layer_split(layer_cost, world)
+    rb = 4096 if world <= 4 else 2048
+    blocks = [(s, r0, min(rb, min(chunk, ctx - s) - r0)) for s in range(0, ctx, chunk) for r0 in range(0, min(chunk, ctx - s), rb)]
+    r = rate * eff[rb]
+    n = len(blocks)
+    seq = []
+    for g0 in range(0, n, gs):
+        items = range(g0, min(n, g0 + gs))
+        seq += [(i, 0) for i in items] + [(i, 1) for i in items]
+    cost = lambda rk, i, ps: sum(block_flops(counts[l], *blocks[i]) for l in range(*bounds[ps * world + rk])) / r
+    done = {}           # (virtual stage, item) -> finish time
+    free = [0.0] * world
+    pos = [0] * world
+    progressed = True
+    while progressed:
+        progressed = False
+        for rk in range(world):
+            while pos[rk] < len(seq):
+                i, ps = seq[pos[rk]]
+                vs = ps * world + rk
+                if vs > 0 and (vs - 1, i) not in done:
+                    break
+                ready = done[(vs - 1, i)] + (blocks[i][2] * HIDDEN * 2 / link + hop) if vs > 0 else 0.0
+                done[(vs, i)] = free[rk] = max(free[rk], ready) + cost(rk, i, ps)
+                pos[rk] += 1
+                progressed = True
+    t_pre = done[(2 * world - 1, n - 1)]
+    t_tok = sum(dec_fixed + x / dec_bw for x in bench.decode_bytes(counts, ctx)) + (2 * world - 1) * hop + hop
+    busy = [sum(cost(rk, i, ps) for i in range(n) for ps in (0, 1)) / t_pre for rk in range(world)]
+    return {"n_gpus": world, "row_block": rb, "virtual_stages": 2, "group_size": gs, "stages": bounds, "prefill_s": t_pre, "prefill_tok_s": ctx / t_pre,
+            "decode_ms_per_token": t_tok * 1e3, "job_tok_s": (ctx + n_decode) / (t_pre + n_decode * t_tok),
+            "stage_busy_min_max": [min(busy), max(busy)]}
+
+
 def model(counts, ctx, chunk, world, rate, eff, link, hop, dec_fixed, dec_bw, n_decode):
     from duo_attn.utils import balanced_layer_split
 
@@ -66,7 +110,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--link-GBps", type=float, default=153.0, help="one xGMI link (MI355X_MICROARCH.md)")
     ap.add_argument("--hop-us", type=float, default=15.0, help="fixed latency of one RCCL point-to-point hop (assumed)")
-    ap.add_argument("--bench", default=os.path.join(ROOT, "profiles", "r5_a_bench.json"), help="the one-GPU bench line the rates come from")
+    ap.add_argument("--bench", default=os.path.join(ROOT, "profiles", "r6_a_bench.json"), help="the one-GPU bench line the rates come from")
+    ap.add_argument("--eff", default="0.951,0.918", help="one-GPU efficiency of 4096- / 2048-row blocks against whole chunks (profiles/r6_prefill_plan.md)")
     a = ap.parse_args()
     import bench
 
@@ -79,11 +124,14 @@ def main():
     t_duo, t_full = line["decode_ms_per_token"] * 1e-3, 1.0 / line["full_attention"]["decode_tok_s"]
     bw = (b_full - b_duo) / (t_full - t_duo)
     fixed = (t_duo - b_duo / bw) / 32
-    eff = {chunk: 1.0, 4096: 0.935, 2048: 0.872}        # profiles/r5_scaling_model.md: same-box one-GPU runs of this build
+    e4, e2 = (float(x) for x in a.eff.split(","))
+    eff = {chunk: 1.0, 4096: e4, 2048: e2}              # same-box one-GPU runs of this build (round 5: 0.935 / 0.872)
     out = {"inputs": {"one_gpu_prefill_PFLOPs": rate / 1e15, "decode_stream_TBps": bw / 1e12, "decode_fixed_us_per_layer": fixed * 1e6,
                       "block_efficiency": eff, "link_GBps": a.link_GBps, "hop_us": a.hop_us}, "rows": []}
     for world in (1, 2, 4, 8):
         out["rows"].append(model(counts, ctx, chunk, world, rate, eff, a.link_GBps * 1e9, a.hop_us * 1e-6, fixed, bw, n_dec))
+    for world in (2, 4, 8):
+        out["rows"].append(model_two_blocks(counts, ctx, chunk, world, rate, eff, a.link_GBps * 1e9, a.hop_us * 1e-6, fixed, bw, n_dec))
     print(json.dumps(out, indent=1))
 
 
