@@ -22,9 +22,6 @@ done
 # cfg4's workload on ONE GPU: 1 048 576-token chunked prefill (chunk 32 000, the reference's default) + 32 decode steps
 python bench.py --ctx 1048576 --chunk 32000 --decode-tokens 32 --steps 1 --warmup 0 --no-full-baseline $LEAN > $O/cfg4_1m_single_gpu.json 2>> $O/err.log
 # the full bench line of this build (what the driver runs) and the kernel trace of the same workload
-python bench.py > $O/bench_line.json 2>> $O/err.log
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o p -- python $R/bench.py --steps 1 --warmup 0 --no-full-baseline --no-cpu-baseline --no-traffic --no-model-level --no-parity > $O/prof_bench_line.json 2>> $O/err.log
-python $R/tools/rocpd_summary.py $(find /tmp/prof_$tag -name "*.db" | head -1) --top 14 > $O/kernels.md 2>> $O/err.log
+# (the full bench line and its kernel trace: tools/debug/r6_final.sh)
 tail -3 $O/err.log
 ls -la $O
