@@ -888,8 +888,10 @@ static void choose_splits(int n_kv_heads, int L, int max_splits, int budget_wgs,
     }
     const int bucket = plan_bucket_units(L);        // units <= bucket < 2 * units
     int s = budget_wgs / n_kv_heads;
-    // keep at least 256 tokens (four units) per workgroup so its epilogue stays small: bucket / 8 < units / 4
-    s = std::min(s, std::max(1, bucket / 8));
+    // keep a few units per workgroup so its epilogue stays small: bucket / 8 (256-512 tokens per workgroup; ADVICE r5 asked
+    // for bucket / 4 at short contexts — DUO_DECODE_SPLIT_DIV, measured in profiles/r6_decode_short.md)
+    static const int div = [] { const char *e = getenv("DUO_DECODE_SPLIT_DIV"); const int x = e ? atoi(e) : 0; return x >= 1 && x <= 64 ? x : 8; }();
+    s = std::min(s, std::max(1, bucket / div));
     s = std::max(1, std::min(s, max_splits));
     splits = s;
 }

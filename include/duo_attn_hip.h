@@ -47,7 +47,7 @@
  *   duo_token_linear_args.reserved became `flags` (DUO_LINEAR_NORM_HF), + duo_tuple_decode_prep_bf16 (the tuple-cache
  *   decode step), + duo_rope_hf_inplace_bf16 / duo_rmsnorm_hf_bf16 (its prefill chunks), + duo_decode_layer_batched_dev_bf16
  *   (batched decode step with device-side lengths).
- * ABI version 5 (round 5, one addition, no signature changed): + duo_decode_plan_bucket; every decode entry point sizes its
+ * ABI version 5 (round 5, one addition, no signature changed): + duo_decode_plan_bucket; every bf16 decode entry point sizes its
  *   split-KV grid from that bucket of the visible rows (static_kv_cache.py:44-45 keeps the lengths as Python ints, so the
  *   reference has no captured step to keep consistent — here a captured launch equals the eager launch of its bucket).
  * ABI version 6 (round 6, two additions, no signature changed): + duo_debug_prefill_last_plan, duo_debug_prefill_plan; the prefill entry points choose
@@ -302,7 +302,7 @@ int duo_stream_compress_batched_bf16(void *k_pool, void *v_pool, int64_t pool_ba
  * full_len / str_len / pos fields of `args` are only planning hints (they size the split-KV grid; the
  * balanced partition in the kernel adapts to the real length), so a captured launch stays valid as the
  * cache grows.  The caller keeps full_len + 1 <= full_capacity.
- * The split-KV grid of every decode entry point is a function of duo_decode_plan_bucket(visible rows) — the rows' 64-token
+ * The split-KV grid of every bf16 decode entry point (not the INT4 ones: no captured INT4 step exists) is a function of duo_decode_plan_bucket(visible rows) — the rows' 64-token
  * units rounded up to a power of two — not of the length itself: a captured launch therefore equals the eager launch of
  * every length in its bucket bit for bit, and the owner of a graph re-captures when the bucket of full_len + 1 (or of
  * str_len + 1) leaves the captured one (duo_attn/graph.py does); replaying beyond it stays correct, only the grid is the
