@@ -493,7 +493,7 @@ def live_parity(device):
         r1[:, h * G:(h + 1) * G] = ref_rows(q1[:, h * G:(h + 1) * G], sk[:, j], sv[:, j], one * W)
     res["decode_131072"] = stats(o1, r1)
     res["reference"] = "exact-P fp32 softmax attention in torch on the GPU, 32 sampled query rows x 32 q heads (prefill), all q heads (decode)"
-    res["bar"] = "tests/helpers.py attn_close: rms(err) <= 2.5e-3 rms(ref) + elementwise budget; per-config figures of the GPU test-suite: profiles/parity_r5.json"
+    res["bar"] = "tests/helpers.py attn_close: rms(err) <= 2.5e-3 rms(ref) + elementwise budget; per-config figures of the GPU test-suite: profiles/parity_r6.json"
     return res
 
 
