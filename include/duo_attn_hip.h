@@ -124,7 +124,8 @@ const char *duo_error_string(int code);
  *        invalid: the memory-side ceiling of the launch);
  * bit 7: bf16 prefill stays on the 8-wave x 32-row kernel (the 4-wave x 64-row kernel is the default where it
  *        applies);  bit 8: no key-range split of the prefill launch;  bits 12-15 / bits 16-19: force that many key-range
- *        splits of the retrieval / the streaming class (capped by the workspace and the tile count);  bit 9: decode scan on the long-prologue kernel
+ *        splits of the retrieval / the streaming class (capped by the workspace and the tile count);  bit 21: the prefill
+ *        kernel's first bulk run stops at the end of segment A instead of chaining into segment B (the round-1..5 form);  bit 9: decode scan on the long-prologue kernel
  *        (duo_decode_split_kernel) instead of the short-prologue one;  bit 10: prefill in the plain q-tile-major block
  *        order instead of the XCD-aware one;  bit 11: INT4 decode on the dequantising kernel whatever `fused` asks for.
  *        Measurement / test aids only. */

@@ -466,6 +466,26 @@ def test_prefill_key_range_splits_of_both_head_classes(S, group, nf, ns, lenA, k
     attn_close(out, ref, f"pieces ({k0}, {k1}) S={S} nf={nf} ns={ns} flags={flags}", bud)
 
 
+@pytest.mark.parametrize("flags", [0, 1 << 21], ids=["chained", "separate-runs"])
+@pytest.mark.parametrize("S,lenA,lenS,k0", [(1024, 1024, 384, 0), (700, 2048, 384, 0), (520, 192, 128, 0), (1500, 128, 64, 0), (900, 3072, 384, 3),
+                                            (2048, 0, 0, 0), (640, 64, 384, 0)])
+def test_prefill_bulk_run_across_the_pool_chunk_boundary(S, lenA, lenS, k0, flags):
+    """Round 6: when the cached segment ends on a 64-key tile boundary the kernel's first bulk run CHAINS into the chunk's own
+    tiles (the LDS-DMA source of tile t+2 switches from pool to chunk two tiles before the boundary) instead of dropping to the
+    general tile form around it; debug bit 21 keeps the two runs separate.  Pools of a whole number of tiles from one tile up, a
+    run that STARTS behind the switch point (no pool: the first chunk's shape; a one-tile pool), key-range pieces that begin
+    inside either segment — both forms against the oracle, and against each other within the two forms' rounding."""
+    h = _hip()
+    outs = []
+    h.set_debug_flags(flags | (k0 << 12))
+    try:
+        out, ref, bud = _attention_case(S, 4, 2 if lenA else 0, 2, lenA, lenS, True, seed=S + lenA, first_chunk=(lenA == 0 and lenS == 0))
+        torch.cuda.synchronize()
+    finally:
+        h.set_debug_flags(0)
+    attn_close(out, ref, f"bulk run across the boundary S={S} lenA={lenA} lenS={lenS} k0={k0} flags={flags}", bud)
+
+
 def test_split_launches_back_to_back_through_one_workspace():
     """the same workspace serves launch after launch: five split launches with DIFFERENT inputs back to back (no
     synchronisation in between), then the first one again — every output against the oracle, and the repeated launch bit-equal
