@@ -6,7 +6,7 @@ through the drop-in APIs, decode steps in every form the package has —
     tuple path (enable_duo_attention_eval):  module by module  |  fused decode layer
 
 — within a cache format all forms must agree: logits within 2e-2 relative L2 of that format's module-by-module run (the fused
-forms change only the summation order of the projections), greedy tokens >= 90 % equal, graph == eager bit for bit (both planned from the
+forms change only the summation order of the projections), greedy tokens >= 90 % equal where the reference's choice is not a tie, graph == eager bit for bit (both planned from the
 same length bucket); across the two formats a sanity bound only (different arithmetic by design).
 
     python tests/fuzz_model_decode.py --seconds 120 [--seed 1]"""
@@ -124,10 +124,20 @@ def run_case(c):
     def close(name, lg, to, to_name):
         assert torch.isfinite(lg).all(), f"{name}: non-finite logits"
         r = _rel(lg, to)
-        agree = (lg.argmax(-1) == to.argmax(-1)).float().mean().item()
         assert r < 2e-2, f"{name}: logits rel L2 {r:.3e} from {to_name}"
+        # Greedy tokens: a random-init model's logits are nearly flat, so a position whose two leading reference logits lie
+        # closer than 4x the rms logit difference of the two runs is a tie that either run may break either way — those
+        # positions are not counted (seed 6004 of the round-6 run drew 2 such ties in 10 tokens); the others must agree >= 90 %.
+        lf, tf = lg.float(), to.float()
+        rms = (lf - tf).pow(2).mean().sqrt().item()
+        top2 = tf.topk(2, dim=-1).values
+        decided = (top2[..., 0] - top2[..., 1]) > 4 * rms
+        same = lf.argmax(-1) == tf.argmax(-1)
+        n_decided = int(decided.sum())
+        agree = (same & decided).sum().item() / max(n_decided, 1)
         # (>= 0.9 up to float32 rounding of the mean: 9 of 10 tokens is 0.89999998)
-        assert agree >= 0.9 - 1e-6 or lg.shape[0] * lg.shape[1] < 10, f"{name}: greedy tokens agree with {to_name} on {agree:.2f}"
+        assert agree >= 0.9 - 1e-6 or n_decided < 10, \
+            f"{name}: greedy tokens agree with {to_name} on {agree:.2f} of {n_decided} decided positions (rms logit difference {rms:.2e})"
 
     close("static fused eager", forms["static fused eager"], ref, "the module-by-module static run")
     close("static reference loop, automatic graph", forms["static reference loop, automatic graph"], ref, "the module-by-module static run")
@@ -151,7 +161,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--case", default=None, help="re-run ONE drawn case (the dict a FAIL line printed) and exit")
     a = ap.parse_args()
+    if a.case:
+        import ast
+        run_case(ast.literal_eval(a.case))
+        print("case passed")
+        return
     rng = random.Random(a.seed)
     t0, n, bad = time.time(), 0, 0
     while time.time() - t0 < a.seconds:
