@@ -4,7 +4,7 @@
 #   -> gpurun_out/r6_final/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
 cd $R || exit 1
-O=$R/gpurun_out/r6_final; mkdir -p $O
+O=$R/gpurun_out/${OUT:-r6_final}; mkdir -p $O
 rm -f gpurun_out/model_rel.log gpurun_out/parity_report.json
 timeout 2400 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest.out 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.out; tail -3 $O/pytest.out
 cp gpurun_out/parity_report.json $O/parity_report.json 2>/dev/null; cp gpurun_out/model_rel.log $O/model_rel.log 2>/dev/null
@@ -31,5 +31,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   db=$(find /tmp/pmc_$i -name "*.db" | head -1)
   if [ -n "$db" ]; then python $R/tools/rocpd_summary.py $db --pmc --top 3 > $O/pmc_$i.md; else tail -5 /tmp/pmc_$i.log > $O/pmc_$i.md; fi
 done )
-bash tools/debug/other_configs.sh r6 > $O/other_configs.log 2>&1; tail -3 $O/other_configs.log
-ls $O gpurun_out/r6_other 2>/dev/null | head -60
+bash tools/debug/other_configs.sh ${OUT:-r6} > $O/other_configs.log 2>&1; tail -3 $O/other_configs.log
+ls $O gpurun_out/${OUT:-r6}_other 2>/dev/null | head -60
