@@ -137,18 +137,69 @@ class HotPath:
     def _layers(self, ps):
         return range(len(self.counts)) if ps is None else self.pass_layers[ps]
 
+    # (--block-streams 2, one GPU, measurement: consecutive row blocks run on alternating HIP streams.  Block i + 1 at layer l
+    #  needs block i's rows of layer l in the pools — nothing of block i's LATER layers — so (block i, layer l + 1) and
+    #  (block i + 1, layer l) are independent in a real model too; issued on two streams the second launch fills the CUs the
+    #  first one's tail leaves idle.  One event per (stream, layer) orders block i + 1 behind block i layer by layer.)
+    def set_block_streams(self, n, serial=False):
+        # (serial: the same code path and data flow on ONE side stream — what the tests compare the overlapped run with)
+        one = torch.cuda.Stream(self.device) if serial else None
+        self.block_streams = [one or torch.cuda.Stream(self.device) for _ in range(n)] if n > 1 else None
+        self.block_events = [[torch.cuda.Event() for _ in self.counts] for _ in range(n)] if n > 1 else None
+
     def prefill_block_stage(self, i, x, ps=None):
         from duo_attn.patch._duo import duo_static_attention_row_block
 
         ci, r0, n = self.blocks[i]
         c = self.chunks[ci][1]
+        streams = getattr(self, "block_streams", None)
+        keep = getattr(self, "keep_outputs", None)       # (tests: a list that collects every launch's output)
+        if streams and ps is None:
+            k = i % len(streams)
+            s, mine, prev = streams[k], self.block_events[k], self.block_events[(i - 1) % len(streams)]
+            if i == 0:
+                s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for j, li in enumerate(self._layers(ps)):
+                    if i > 0:
+                        s.wait_event(prev[j])
+                    o = duo_static_attention_row_block(self.q_c[:, r0:r0 + n], self.k_c[:, r0:r0 + n], self.v_c[:, r0:r0 + n],
+                                                       self.cache, li, r0, c, ROPE_SCALE, ROPE_THETA)
+                    mine[j].record(s)
+                    if keep is not None:
+                        keep.append(o)
+            return x if x is not None else self.hidden_c[:, :n]
         for li in self._layers(ps):
-            duo_static_attention_row_block(self.q_c[:, r0:r0 + n], self.k_c[:, r0:r0 + n], self.v_c[:, r0:r0 + n],
-                                           self.cache, li, r0, c, ROPE_SCALE, ROPE_THETA)
+            o = duo_static_attention_row_block(self.q_c[:, r0:r0 + n], self.k_c[:, r0:r0 + n], self.v_c[:, r0:r0 + n],
+                                               self.cache, li, r0, c, ROPE_SCALE, ROPE_THETA)
+            if keep is not None:
+                keep.append(o)
         return x if x is not None else self.hidden_c[:, :n]
 
     def prefill_stage(self, i, x, ps=None):
         s, c = self.chunks[i]
+        streams = getattr(self, "block_streams", None)
+        if streams and ps is None:
+            # (--block-streams with whole chunks: chunk i + 1 at layer l needs chunk i's rows of layer l in the pools and nothing
+            #  of chunk i's later layers — the same independence as between row blocks.  Each chunk rotates its OWN copy of the
+            #  synthetic q / k rows: the whole-chunk path shares one buffer between consecutive chunks.)
+            k = i % len(streams)
+            st, mine, prev = streams[k], self.block_events[k], self.block_events[(i - 1) % len(streams)]
+            if not hasattr(self, "qk_copies"):
+                self.qk_copies = [(self.q_c.clone(), self.k_c.clone()) for _ in streams]
+            q_c, k_c = self.qk_copies[k]
+            if i == 0:
+                for t in streams:
+                    t.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                for j, li in enumerate(self._layers(ps)):
+                    if i > 0:
+                        st.wait_event(prev[j])
+                    o = self.layer_core(li, c, s, q_c, k_c, self.v_c)
+                    mine[j].record(st)
+                    if getattr(self, "keep_outputs", None) is not None:
+                        self.keep_outputs.append(o)
+            return x if x is not None else self.hidden_c[:, :c]
         for li in self._layers(ps):
             self.layer_core(li, c, s, self.q_c, self.k_c, self.v_c)
         return x if x is not None else self.hidden_c[:, :c]
@@ -920,6 +971,8 @@ def main():
     ap.add_argument("--row-block", type=int, default=-1,
                     help="N > 1: query rows per pipeline item (a chunk is handed through the stages in row blocks); "
                          "0 = whole chunks, -1 = automatic (4096 rows on up to 4 GPUs, 2048 on more)")
+    ap.add_argument("--block-streams", type=int, default=1, choices=[1, 2, 3],
+                    help="one GPU only (measurement): consecutive row blocks (DUO_BENCH_FORCE_BLOCKS=1) or whole chunks on alternating HIP streams")
     ap.add_argument("--virtual-stages", type=int, default=1, choices=[1, 2],
                     help="N > 1: layer blocks per rank.  2 = duo_attn.pipeline.InterleavedLayerPipeline (rank r owns blocks r and "
                          "N + r, an item goes round the ranks twice): better balance of the ragged layers, half the fill — "
@@ -1038,6 +1091,10 @@ def main():
     use_blocks = args.row_block > 0 and (world > 1 or os.environ.get("DUO_BENCH_FORCE_BLOCKS") == "1")
     if use_blocks:
         hp.set_row_blocks(args.row_block)
+    if args.block_streams > 1:
+        if world > 1:
+            raise SystemExit("--block-streams is a one-GPU measurement")
+        hp.set_block_streams(args.block_streams)
     t_job, t_pre, t_dec = timed(hp, args.steps, args.warmup)
     duo_jobs, duo_local = timed.last_jobs, timed.local_jobs
 
@@ -1171,7 +1228,7 @@ def main():
                 "decode_tokens": args.decode_tokens,
                 "parallelism": ((f"layer-pipeline pp{world}, {args.row_block}-row wavefront" if use_blocks
                                  else f"layer-pipeline pp{world}") + (", two layer blocks per rank" if args.virtual_stages == 2 else ""))
-                               if world > 1 else "single GPU",
+                               if world > 1 else ("single GPU" + (f", {args.row_block}-row blocks" if use_blocks else "") + (f", consecutive items on {args.block_streams} streams" if args.block_streams > 1 else "")),
             },
             "prefill_tok_s": args.ctx / t_pre,
             "decode_tok_s": args.decode_tokens / t_dec,
